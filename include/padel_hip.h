@@ -1,0 +1,140 @@
+/* libpadel_hip.so — C-ABI of the MI355X (gfx950) inference engine behind the reference's trackers/.
+ *
+ * The reference is pure Python and has no FFI; the boundary this library replaces is the call the
+ * tracker plugins make into their numeric engines:
+ *
+ *   - `self.model.predict(sample, conf, iou, imgsz, device, classes)` on an `ultralytics.YOLO`
+ *       detect model  — trackers/players_tracker/players_tracker.py:351-359   -> pa_yolo_infer()
+ *       pose model    — trackers/players_keypoints_tracker/players_keypoints_tracker.py:285-292
+ *                       (preceded by the PIL resize of :260-266)               -> pa_yolo_infer()
+ *   - `YOLO(model_path)` / `self.model.to(device)` — players_tracker.py:303,338-339 -> pa_model_create()
+ *   - `tracknet(x)` on the 27-channel window stack — trackers/ball_tracker/ball_tracker.py:445-446
+ *                                                                              -> pa_tracknet_infer()
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer and the
+ * library never keeps a caller pointer past return; every call is synchronous at this boundary; one
+ * engine per GPU, not thread-safe; return 0 on success, non-zero on failure with the message in
+ * pa_last_error().  The Python binding (`padel_analytics_amd/engine.py`, ctypes) is the only caller.
+ */
+#ifndef PADEL_HIP_H
+#define PADEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pa_engine pa_engine;
+typedef struct pa_model pa_model;
+
+#define PA_ABI_VERSION 1
+
+/* ---- graph description (built on the host from a state_dict; see padel_analytics_amd/graph.py) ---- */
+
+enum pa_op_kind {
+    PA_OP_STEM = 1,       /* model.0: Conv 3x3 s2 + SiLU straight from the u8 network input      */
+    PA_OP_CONV = 2,       /* Conv kxk (k in 1,3; stride 1,2) + bias + act (+ residual)           */
+    PA_OP_SPPF_POOL = 3,  /* three chained MaxPool2d(5,1,2): slice c -> slices c+1..c+3          */
+    PA_OP_UPSAMPLE2X = 4, /* nearest x2 of a slice into a slice of a buffer one level finer      */
+    PA_OP_MAXPOOL2 = 5    /* MaxPool2d(2,2) into a buffer one level coarser                      */
+};
+
+enum pa_act { PA_ACT_NONE = 0, PA_ACT_SILU = 1, PA_ACT_RELU = 2, PA_ACT_SIGMOID = 3 };
+
+/* activation buffer: fp32 NHWC, spatial size = network input >> level, `channels` floats per pixel */
+typedef struct pa_buf_desc {
+    int32_t level;
+    int32_t channels;
+} pa_buf_desc;
+
+typedef struct pa_op_desc {
+    int32_t kind;
+    int32_t in_buf, in_choff, cin;      /* slice read  (cin multiple of 16 for PA_OP_CONV)          */
+    int32_t out_buf, out_choff, cout;   /* slice written (cout = real channels)                     */
+    int32_t ksize, stride, act;
+    int32_t res_buf, res_choff;         /* residual slice added after the activation; res_buf < 0: none */
+    int32_t npad;                       /* PA_OP_CONV: rows of the packed weight matrix (multiple of 16) */
+    int32_t reserved;
+    int64_t w_off, b_off;               /* offsets (in floats) of packed weights / bias in the blob */
+} pa_op_desc;
+
+enum pa_task { PA_TASK_DETECT = 0, PA_TASK_POSE = 1, PA_TASK_TRACKNET = 2 };
+
+typedef struct pa_model_desc {
+    int32_t task;
+    int32_t nc;                 /* classes (detect / pose)                                          */
+    int32_t nk, kpt_dim;        /* pose: nk = K * kpt_dim                                           */
+    int32_t n_bufs;
+    const pa_buf_desc* bufs;
+    int32_t n_ops;
+    const pa_op_desc* ops;
+    int32_t head_buf[3];        /* detect/pose: per-level head maps, channels >= 64 + nc + nk (pixel stride);
+                                   tracknet: head_buf[0] = output heat-map buffer                   */
+    int32_t in_channels;        /* tracknet: channels of the fp32 input buffer (buffer 0)           */
+} pa_model_desc;
+
+/* ---- engine ---- */
+int pa_abi_version(void);
+int pa_device_count(void);
+int pa_engine_create(int device_id, pa_engine** out);
+void pa_engine_destroy(pa_engine* eng);
+/* message of the last failure on this engine (eng may be NULL for creation failures) */
+const char* pa_last_error(pa_engine* eng);
+int pa_engine_synchronize(pa_engine* eng);
+
+/* raw device memory helpers (bench keeps frames resident in HBM with these) */
+int pa_device_malloc(pa_engine* eng, size_t nbytes, void** out_dev);
+int pa_device_free(pa_engine* eng, void* dev);
+int pa_memcpy_h2d(pa_engine* eng, void* dst_dev, const void* src_host, size_t nbytes);
+int pa_memcpy_d2h(pa_engine* eng, void* dst_host, const void* src_dev, size_t nbytes);
+
+/* ---- models ---- */
+/* weights: packed blob produced by the host graph builder; copied to HBM, caller keeps ownership */
+int pa_model_create(pa_engine* eng, const pa_model_desc* desc, const float* weights, size_t n_floats,
+                    pa_model** out);
+void pa_model_destroy(pa_model* m);
+/* frames / windows processed per replay of the graph (activation buffers are sized for it); default 64 */
+int pa_model_set_max_batch(pa_model* m, int max_batch);
+
+enum pa_pre_mode {
+    PA_PRE_LETTERBOX = 0,   /* ultralytics LetterBox(auto, stride 32), cv2 INTER_LINEAR, pad 114    */
+    PA_PRE_PIL_STRETCH = 1  /* PIL Image.resize((imgsz, imgsz)) bicubic, then LetterBox == identity */
+};
+
+typedef struct pa_yolo_params {
+    int32_t imgsz;            /* 640 / 1280                                                         */
+    int32_t pre_mode;         /* enum pa_pre_mode                                                   */
+    int32_t channel_reverse;  /* 1: network channel c = frame channel 2-c      */
+    int32_t letterbox_auto;   /* LetterBox auto flag (1 when all frames of the call share a shape)  */
+    float conf, iou;
+    int32_t max_det;          /* <= 300 rows are returned per image                                 */
+    int32_t n_classes;        /* 0: keep every class                                                */
+    const int32_t* classes;   /* host array                                                         */
+    int32_t frames_on_device; /* 1: `frames` is an HBM pointer from pa_device_malloc                */
+} pa_yolo_params;
+
+/* frames: n x h x w x 3 uint8 (HWC).  out_boxes: n x max_det x 6 {x1,y1,x2,y2,conf,cls} in source
+ * pixels; out_kpts: n x max_det x nk (NULL for detect); out_counts: n.                              */
+int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
+                  float* out_boxes, float* out_kpts, int32_t* out_counts);
+
+/* raw head maps of the last pa_yolo_infer call (level 0..2): n x H_l x W_l x c fp32 (c from
+ * pa_yolo_head_shape; channels [0,64) box DFL logits, [64,64+nc) class logits, then nk keypoint values) */
+int pa_yolo_head_shape(pa_model* m, int level, int* h, int* w, int* c);
+int pa_yolo_read_head(pa_model* m, int level, int n, float* out);
+
+/* TrackNet forward: x = n x H x W x C_in fp32 NHWC (C_in padded as in the model desc) -> n x H x W x 8 */
+int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on_device, float* out,
+                      int out_on_device);
+
+/* ---- profiling (bench.py roofline): per-op device times of the LAST inference, HIP events on the
+ * engine's stream.  kinds/ms/flops are host arrays of capacity cap; returns the number of records. */
+int pa_engine_set_profiling(pa_engine* eng, int enable);
+int pa_model_last_profile(pa_model* m, int cap, int32_t* kinds, float* ms, double* flops, int32_t* ksizes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PADEL_HIP_H */

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libpadel_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+set -e
+cd "$(dirname "$0")"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value"
+mkdir -p build
+pids=()
+for f in conv_igemm.hip kernels_misc.hip postproc.hip tracknet_post.hip; do
+  [ -f "$f" ] || continue
+  hipcc $FLAGS -c "$f" -o "build/${f%.hip}.o" &
+  pids+=($!)
+done
+hipcc $FLAGS -x hip -c engine.cpp -o build/engine.o &
+pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpadel_hip.so build/*.o -Wl,-rpath,/opt/rocm/lib
+echo "built $(cd .. && pwd)/libpadel_hip.so"

@@ -1,0 +1,636 @@
+// libpadel_hip.so — engine: owns one HIP stream per GPU, the packed weights and every activation
+// buffer in HBM, plans a graph for a (source size, imgsz, batch) and replays it per batch.
+// C-ABI declared in include/padel_hip.h.
+#include "../../include/padel_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace padel;
+
+static thread_local std::string g_err;
+
+struct pa_engine {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+    float* zeros = nullptr;   // 256 B of zeros: source of padded conv taps
+};
+
+#define PA_FAIL(eng, ...)                                        \
+    do {                                                         \
+        char _b[512];                                            \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                   \
+        if (eng) (eng)->err = _b; else g_err = _b;               \
+        return 1;                                                \
+    } while (0)
+
+#define PA_HIP(eng, call)                                                                  \
+    do {                                                                                   \
+        hipError_t _e = (call);                                                            \
+        if (_e != hipSuccess) PA_FAIL(eng, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct ProfRec { int kind; int ksize; double flops; hipEvent_t e0, e1; float ms; };
+
+struct pa_model {
+    pa_engine* e = nullptr;
+    pa_model_desc d{};
+    std::vector<pa_buf_desc> bufs;
+    std::vector<pa_op_desc> ops;
+    float* d_w = nullptr;
+    size_t n_w = 0;
+    int max_batch = 64;
+
+    // plan
+    bool planned = false;
+    int p_h0 = 0, p_w0 = 0, p_imgsz = 0, p_pre = 0, p_auto = 0, p_batch = 0;
+    int net_h = 0, net_w = 0;
+    int rw = 0, rh = 0, top = 0, left = 0, lb_mode = 0;
+    std::vector<float*> bptr;
+    uint8_t* d_frames = nullptr; size_t frames_cap = 0;
+    uint8_t* d_netin = nullptr;
+    uint8_t* d_tmp = nullptr;
+    int32_t *d_xtab = nullptr, *d_ytab = nullptr;                 // cv2 bilinear tables
+    int32_t *d_hb = nullptr, *d_hk = nullptr, *d_vb = nullptr, *d_vk = nullptr;   // PIL tables
+    int hks = 0, vks = 0;
+    // post
+    int A = 0, P2 = 0;
+    HeadLevel lv[3]{};
+    float* d_cand = nullptr; int32_t* d_cidx = nullptr; int32_t* d_ccnt = nullptr;
+    uint64_t* d_keys = nullptr; int32_t* d_order = nullptr; uint8_t* d_supp = nullptr;
+    float* d_oboxes = nullptr; float* d_okpts = nullptr; int32_t* d_ocnt = nullptr;
+    int32_t* d_classes = nullptr; int classes_cap = 0;
+    int last_n = 0;
+    std::vector<ProfRec> prof;
+    size_t n_prof = 0;
+};
+
+extern "C" {
+
+int pa_abi_version(void) { return PA_ABI_VERSION; }
+
+int pa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* pa_last_error(pa_engine* eng) { return eng ? eng->err.c_str() : g_err.c_str(); }
+
+int pa_engine_create(int device_id, pa_engine** out) {
+    if (!out) PA_FAIL((pa_engine*)nullptr, "pa_engine_create: out is NULL");
+    int n = 0;
+    PA_HIP((pa_engine*)nullptr, hipGetDeviceCount(&n));
+    if (device_id < 0 || device_id >= n) PA_FAIL((pa_engine*)nullptr, "pa_engine_create: device %d of %d", device_id, n);
+    PA_HIP((pa_engine*)nullptr, hipSetDevice(device_id));
+    pa_engine* e = new pa_engine();
+    e->dev = device_id;
+    hipError_t r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "hipStreamCreate: %s", hipGetErrorString(r)); }
+    r = hipMalloc((void**)&e->zeros, 256);
+    if (r == hipSuccess) r = hipMemset(e->zeros, 0, 256);
+    if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "zero page: %s", hipGetErrorString(r)); }
+    *out = e;
+    return 0;
+}
+
+void pa_engine_destroy(pa_engine* e) {
+    if (!e) return;
+    hipSetDevice(e->dev);
+    if (e->zeros) hipFree(e->zeros);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int pa_engine_synchronize(pa_engine* e) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int pa_engine_set_profiling(pa_engine* e, int enable) { e->profiling = enable != 0; return 0; }
+
+int pa_device_malloc(pa_engine* e, size_t nbytes, void** out) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipMalloc(out, nbytes));
+    return 0;
+}
+int pa_device_free(pa_engine* e, void* p) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipFree(p));
+    return 0;
+}
+int pa_memcpy_h2d(pa_engine* e, void* dst, const void* src, size_t n) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+int pa_memcpy_d2h(pa_engine* e, void* dst, const void* src, size_t n) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------- model
+static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) {
+    if (d->n_bufs <= 0 || d->n_ops <= 0 || !d->bufs || !d->ops) PA_FAIL(e, "model desc: empty graph");
+    for (int i = 0; i < d->n_bufs; ++i)
+        if (d->bufs[i].level < 0 || d->bufs[i].level > 6 || d->bufs[i].channels <= 0 || (d->bufs[i].channels & 3))
+            PA_FAIL(e, "model desc: buffer %d (level %d, channels %d)", i, d->bufs[i].level, d->bufs[i].channels);
+    auto okslice = [&](int b, int off, int c) {
+        return b >= 0 && b < d->n_bufs && off >= 0 && c > 0 && off + c <= d->bufs[b].channels;
+    };
+    for (int i = 0; i < d->n_ops; ++i) {
+        const pa_op_desc& o = d->ops[i];
+        if (!okslice(o.out_buf, o.out_choff, o.cout)) PA_FAIL(e, "op %d: bad output slice", i);
+        if (o.kind != PA_OP_STEM && !okslice(o.in_buf, o.in_choff, o.cin)) PA_FAIL(e, "op %d: bad input slice", i);
+        if (o.kind == PA_OP_CONV) {
+            if ((o.cin & 15) || (o.in_choff & 3) || (o.ksize != 1 && o.ksize != 3) || (o.stride != 1 && o.stride != 2))
+                PA_FAIL(e, "op %d: unsupported conv (cin %d k %d s %d)", i, o.cin, o.ksize, o.stride);
+            if (o.npad < o.cout || (o.npad & 15)) PA_FAIL(e, "op %d: npad %d for cout %d", i, o.npad, o.cout);
+            const size_t wn = (size_t)o.npad * o.cin * o.ksize * o.ksize;
+            if (o.w_off < 0 || (o.w_off & 3) || (size_t)o.w_off + wn > n_floats || o.b_off < 0 ||
+                (size_t)o.b_off + o.npad > n_floats)
+                PA_FAIL(e, "op %d: weights outside the blob", i);
+            if (o.res_buf >= 0 && !okslice(o.res_buf, o.res_choff, o.cout)) PA_FAIL(e, "op %d: bad residual slice", i);
+            const int lin = d->bufs[o.in_buf].level, lout = d->bufs[o.out_buf].level;
+            if (lout != lin + (o.stride == 2 ? 1 : 0)) PA_FAIL(e, "op %d: level mismatch", i);
+        } else if (o.kind == PA_OP_STEM) {
+            if ((o.cout & 15) || (size_t)o.w_off + (size_t)o.cout * 27 > n_floats || (size_t)o.b_off + o.cout > n_floats)
+                PA_FAIL(e, "op %d: bad stem", i);
+            if (d->bufs[o.out_buf].level != 1) PA_FAIL(e, "op %d: stem output must be level 1", i);
+        } else if (o.kind == PA_OP_SPPF_POOL) {
+            if ((o.cin & 3) || o.in_buf != o.out_buf || !okslice(o.in_buf, o.in_choff, 4 * o.cin))
+                PA_FAIL(e, "op %d: bad sppf slices", i);
+        } else if (o.kind == PA_OP_UPSAMPLE2X) {
+            if (d->bufs[o.out_buf].level != d->bufs[o.in_buf].level - 1 || o.cin != o.cout || (o.cin & 3))
+                PA_FAIL(e, "op %d: bad upsample", i);
+        } else if (o.kind == PA_OP_MAXPOOL2) {
+            if (d->bufs[o.out_buf].level != d->bufs[o.in_buf].level + 1 || o.cin != o.cout || (o.cin & 3))
+                PA_FAIL(e, "op %d: bad maxpool", i);
+        } else {
+            PA_FAIL(e, "op %d: unknown kind %d", i, o.kind);
+        }
+    }
+    if (d->task == PA_TASK_DETECT || d->task == PA_TASK_POSE) {
+        for (int l = 0; l < 3; ++l) {
+            const int b = d->head_buf[l];
+            if (b < 0 || b >= d->n_bufs || d->bufs[b].channels < 64 + d->nc + d->nk || d->bufs[b].level != 3 + l ||
+                d->bufs[b].channels != d->bufs[d->head_buf[0]].channels)
+                PA_FAIL(e, "model desc: head buffer %d", l);
+        }
+        if (d->nk && (d->kpt_dim < 2 || d->kpt_dim > 3 || d->nk % d->kpt_dim)) PA_FAIL(e, "model desc: kpt shape");
+    }
+    return 0;
+}
+
+int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weights, size_t n_floats, pa_model** out) {
+    if (!e || !desc || !weights || !out) PA_FAIL(e, "pa_model_create: NULL argument");
+    if (validate_desc(e, desc, n_floats)) return 1;
+    PA_HIP(e, hipSetDevice(e->dev));
+    pa_model* m = new pa_model();
+    m->e = e;
+    m->d = *desc;
+    m->bufs.assign(desc->bufs, desc->bufs + desc->n_bufs);
+    m->ops.assign(desc->ops, desc->ops + desc->n_ops);
+    m->d.bufs = m->bufs.data();
+    m->d.ops = m->ops.data();
+    m->n_w = n_floats;
+    hipError_t r = hipMalloc((void**)&m->d_w, n_floats * sizeof(float));
+    if (r == hipSuccess) r = hipMemcpyAsync(m->d_w, weights, n_floats * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
+    if (r != hipSuccess) { delete m; PA_FAIL(e, "weights upload: %s", hipGetErrorString(r)); }
+    *out = m;
+    return 0;
+}
+
+static void free_plan(pa_model* m) {
+    for (float* p : m->bptr) if (p) hipFree(p);
+    m->bptr.clear();
+    void* ptrs[] = {m->d_netin, m->d_tmp, m->d_xtab, m->d_ytab, m->d_hb, m->d_hk, m->d_vb, m->d_vk, m->d_cand,
+                    m->d_cidx, m->d_ccnt, m->d_keys, m->d_order, m->d_supp, m->d_oboxes, m->d_okpts, m->d_ocnt};
+    for (void* p : ptrs) if (p) hipFree(p);
+    m->d_netin = m->d_tmp = nullptr;
+    m->d_xtab = m->d_ytab = m->d_hb = m->d_hk = m->d_vb = m->d_vk = nullptr;
+    m->d_cand = nullptr; m->d_cidx = m->d_ccnt = nullptr; m->d_keys = nullptr; m->d_order = nullptr; m->d_supp = nullptr;
+    m->d_oboxes = m->d_okpts = nullptr; m->d_ocnt = nullptr;
+    m->planned = false;
+}
+
+void pa_model_destroy(pa_model* m) {
+    if (!m) return;
+    hipSetDevice(m->e->dev);
+    hipStreamSynchronize(m->e->stream);
+    free_plan(m);
+    for (auto& r : m->prof) { hipEventDestroy(r.e0); hipEventDestroy(r.e1); }
+    if (m->d_frames) hipFree(m->d_frames);
+    if (m->d_classes) hipFree(m->d_classes);
+    if (m->d_w) hipFree(m->d_w);
+    delete m;
+}
+
+int pa_model_set_max_batch(pa_model* m, int max_batch) {
+    if (max_batch < 1) PA_FAIL(m->e, "max_batch %d", max_batch);
+    if (max_batch != m->max_batch) { hipSetDevice(m->e->dev); hipStreamSynchronize(m->e->stream); free_plan(m); m->max_batch = max_batch; }
+    return 0;
+}
+
+// ---- host-side coefficient tables --------------------------------------------------------------
+// cv2.resize INTER_LINEAR u8 (see oracle/yolov8_ref.py:cv2_resize_linear_u8)
+static void cv2_linear_table(int src, int dst, std::vector<int32_t>& tab) {
+    tab.resize((size_t)dst * 3);
+    const double scale = (double)src / dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = (int)std::floor(f);
+        f -= s;
+        if (s < 0) { s = 0; f = 0.f; }
+        if (s >= src - 1) { s = src - 1; f = 0.f; }
+        tab[d * 3 + 0] = s;
+        tab[d * 3 + 1] = (int)std::nearbyint((1.f - f) * 2048.f);
+        tab[d * 3 + 2] = (int)std::nearbyint(f * 2048.f);
+    }
+}
+
+// Pillow ImagingResample precompute_coeffs + normalize_coeffs_8bpc, bicubic a = -0.5
+static double pil_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+static int pil_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& kk) {
+    const double scale = (double)in_size / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    bounds.assign((size_t)out_size * 2, 0);
+    kk.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        const double ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) { k[x] = pil_bicubic((x + xmin - center + 0.5) * ss); ww += k[x]; }
+        for (int x = 0; x < xmax; ++x) {
+            double v = ww != 0.0 ? k[x] / ww : k[x];
+            kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
+        }
+        bounds[xx * 2] = xmin;
+        bounds[xx * 2 + 1] = xmax;
+    }
+    return ksize;
+}
+
+static hipError_t upload(pa_engine* e, int32_t** dptr, const std::vector<int32_t>& v) {
+    hipError_t r = hipMalloc((void**)dptr, v.size() * sizeof(int32_t));
+    if (r != hipSuccess) return r;
+    r = hipMemcpyAsync(*dptr, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    if (r != hipSuccess) return r;
+    return hipStreamSynchronize(e->stream);
+}
+
+static int plan_buffers(pa_model* m, int batch) {
+    pa_engine* e = m->e;
+    if ((m->net_h & 31) || (m->net_w & 31)) PA_FAIL(e, "network input %dx%d is not a multiple of 32", m->net_h, m->net_w);
+    m->bptr.assign(m->bufs.size(), nullptr);
+    for (size_t i = 0; i < m->bufs.size(); ++i) {
+        const size_t H = m->net_h >> m->bufs[i].level, W = m->net_w >> m->bufs[i].level;
+        const size_t bytes = (size_t)batch * H * W * m->bufs[i].channels * sizeof(float);
+        PA_HIP(e, hipMalloc((void**)&m->bptr[i], bytes));
+        PA_HIP(e, hipMemsetAsync(m->bptr[i], 0, bytes, e->stream));
+    }
+    m->p_batch = batch;
+    return 0;
+}
+
+static int plan_yolo(pa_model* m, int h0, int w0, const pa_yolo_params* p) {
+    pa_engine* e = m->e;
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    free_plan(m);
+    const int S = p->imgsz;
+    if (S <= 0 || (S & 31)) PA_FAIL(e, "imgsz %d must be a positive multiple of 32", S);
+    if (p->pre_mode == PA_PRE_LETTERBOX) {
+        const double r = std::min((double)S / h0, (double)S / w0);
+        m->rw = (int)std::nearbyint(w0 * r);
+        m->rh = (int)std::nearbyint(h0 * r);
+        double dw = S - m->rw, dh = S - m->rh;
+        if (p->letterbox_auto) { dw = std::fmod(dw, 32.0); dh = std::fmod(dh, 32.0); }
+        dw /= 2; dh /= 2;
+        m->top = (int)std::nearbyint(dh - 0.1);
+        const int bottom = (int)std::nearbyint(dh + 0.1);
+        m->left = (int)std::nearbyint(dw - 0.1);
+        const int right = (int)std::nearbyint(dw + 0.1);
+        m->net_h = m->rh + m->top + bottom;
+        m->net_w = m->rw + m->left + right;
+        if (w0 == m->rw && h0 == m->rh) m->lb_mode = 0;
+        else if (w0 == 2 * m->rw && h0 == 2 * m->rh) m->lb_mode = 1;
+        else {
+            m->lb_mode = 2;
+            std::vector<int32_t> xt, yt;
+            cv2_linear_table(w0, m->rw, xt);
+            cv2_linear_table(h0, m->rh, yt);
+            PA_HIP(e, upload(e, &m->d_xtab, xt));
+            PA_HIP(e, upload(e, &m->d_ytab, yt));
+        }
+    } else if (p->pre_mode == PA_PRE_PIL_STRETCH) {
+        m->net_h = m->net_w = S;
+        m->rw = m->rh = S; m->top = m->left = 0; m->lb_mode = 0;
+        std::vector<int32_t> b, k;
+        if (w0 != S) { m->hks = pil_coeffs(w0, S, b, k); PA_HIP(e, upload(e, &m->d_hb, b)); PA_HIP(e, upload(e, &m->d_hk, k)); }
+        if (h0 != S) { m->vks = pil_coeffs(h0, S, b, k); PA_HIP(e, upload(e, &m->d_vb, b)); PA_HIP(e, upload(e, &m->d_vk, k)); }
+        if (w0 != S && h0 != S) PA_HIP(e, hipMalloc((void**)&m->d_tmp, (size_t)m->max_batch * h0 * S * 3));
+    } else {
+        PA_FAIL(e, "unknown pre_mode %d", p->pre_mode);
+    }
+    const int B = m->max_batch;
+    PA_HIP(e, hipMalloc((void**)&m->d_netin, (size_t)B * m->net_h * m->net_w * 4));
+    if (plan_buffers(m, B)) return 1;
+    int a0 = 0;
+    for (int l = 0; l < 3; ++l) {
+        const int b = m->d.head_buf[l];
+        m->lv[l].buf = m->bptr[b];
+        m->lv[l].H = m->net_h >> (3 + l);
+        m->lv[l].W = m->net_w >> (3 + l);
+        m->lv[l].stride = 8 << l;
+        m->lv[l].anchor0 = a0;
+        a0 += m->lv[l].H * m->lv[l].W;
+    }
+    m->A = a0;
+    if (m->A >= 65536) PA_FAIL(e, "%d anchors per image exceed the 16-bit sort key", m->A);
+    m->P2 = 1;
+    while (m->P2 < m->A) m->P2 <<= 1;
+    PA_HIP(e, hipMalloc((void**)&m->d_cand, (size_t)B * m->A * 6 * sizeof(float)));
+    PA_HIP(e, hipMalloc((void**)&m->d_cidx, (size_t)B * m->A * sizeof(int32_t)));
+    PA_HIP(e, hipMalloc((void**)&m->d_ccnt, (size_t)B * sizeof(int32_t)));
+    PA_HIP(e, hipMalloc((void**)&m->d_keys, (size_t)B * m->P2 * sizeof(uint64_t)));
+    PA_HIP(e, hipMalloc((void**)&m->d_order, (size_t)B * m->A * sizeof(int32_t)));
+    PA_HIP(e, hipMalloc((void**)&m->d_supp, (size_t)B * m->A));
+    PA_HIP(e, hipMalloc((void**)&m->d_oboxes, (size_t)B * 300 * 6 * sizeof(float)));
+    PA_HIP(e, hipMalloc((void**)&m->d_ocnt, (size_t)B * sizeof(int32_t)));
+    if (m->d.nk) PA_HIP(e, hipMalloc((void**)&m->d_okpts, (size_t)B * 300 * m->d.nk * sizeof(float)));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    m->p_h0 = h0; m->p_w0 = w0; m->p_imgsz = S; m->p_pre = p->pre_mode; m->p_auto = p->letterbox_auto;
+    m->planned = true;
+    return 0;
+}
+
+static ProfRec* prof_begin(pa_model* m, size_t idx, int kind, int ksize, double flops) {
+    if (!m->e->profiling) return nullptr;
+    if (m->prof.size() <= idx) {
+        m->prof.resize(idx + 1);
+        hipEventCreate(&m->prof[idx].e0);
+        hipEventCreate(&m->prof[idx].e1);
+    }
+    ProfRec* r = &m->prof[idx];
+    r->kind = kind; r->ksize = ksize; r->flops = flops; r->ms = 0.f;
+    hipEventRecord(r->e0, m->e->stream);
+    return r;
+}
+static void prof_end(pa_model* m, ProfRec* r) { if (r) hipEventRecord(r->e1, m->e->stream); }
+
+// replay the op list for `n` images (prof records appended starting at *pi)
+static int run_ops(pa_model* m, int n, size_t* pi) {
+    pa_engine* e = m->e;
+    hipStream_t s = e->stream;
+    for (size_t i = 0; i < m->ops.size(); ++i) {
+        const pa_op_desc& o = m->ops[i];
+        const pa_buf_desc& ob = m->bufs[o.out_buf];
+        const int Ho = m->net_h >> ob.level, Wo = m->net_w >> ob.level;
+        hipError_t r = hipSuccess;
+        ProfRec* pr = nullptr;
+        if (o.kind == PA_OP_CONV) {
+            const pa_buf_desc& ib = m->bufs[o.in_buf];
+            ConvArgs a{};
+            a.in = m->bptr[o.in_buf]; a.in_cs = ib.channels; a.in_choff = o.in_choff;
+            a.out = m->bptr[o.out_buf]; a.out_cs = ob.channels; a.out_choff = o.out_choff;
+            a.res = o.res_buf >= 0 ? m->bptr[o.res_buf] : nullptr;
+            a.res_cs = o.res_buf >= 0 ? m->bufs[o.res_buf].channels : 0; a.res_choff = o.res_choff;
+            a.zeros = e->zeros;
+            a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;
+            a.H = m->net_h >> ib.level; a.W = m->net_w >> ib.level; a.Ho = Ho; a.Wo = Wo;
+            a.cin = o.cin; a.cout = o.cout; a.n16 = o.npad / 16; a.ksize = o.ksize; a.stride = o.stride; a.act = o.act;
+            a.M = n * Ho * Wo;
+            int mf, nf;
+            choose_conv_tile(a.M, a.n16, &mf, &nf);
+            pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
+            r = launch_conv_igemm(a, mf, nf, s);
+        } else if (o.kind == PA_OP_STEM) {
+            StemArgs a{};
+            a.in = m->d_netin; a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;
+            a.out = m->bptr[o.out_buf]; a.out_cs = ob.channels; a.out_choff = o.out_choff;
+            a.H = m->net_h; a.W = m->net_w; a.Ho = Ho; a.Wo = Wo; a.cout = o.cout; a.B = n;
+            pr = prof_begin(m, (*pi)++, o.kind, 3, 2.0 * n * Ho * Wo * (double)o.cout * 27);
+            r = launch_stem(a, s);
+        } else if (o.kind == PA_OP_SPPF_POOL) {
+            pr = prof_begin(m, (*pi)++, o.kind, 5, 0.0);
+            r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s);
+        } else if (o.kind == PA_OP_UPSAMPLE2X) {
+            pr = prof_begin(m, (*pi)++, o.kind, 0, 0.0);
+            r = launch_upsample2x(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
+                                  ob.channels, o.out_choff, o.cin, n, Ho / 2, Wo / 2, s);
+        } else if (o.kind == PA_OP_MAXPOOL2) {
+            pr = prof_begin(m, (*pi)++, o.kind, 2, 0.0);
+            r = launch_maxpool2(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
+                                ob.channels, o.out_choff, o.cin, n, Ho * 2, Wo * 2, s);
+        }
+        prof_end(m, pr);
+        if (r != hipSuccess) PA_FAIL(e, "op %zu (kind %d) launch failed: %s", i, o.kind, hipGetErrorString(r));
+    }
+    return 0;
+}
+
+static int finish_profile(pa_model* m, size_t n_rec) {
+    if (!m->e->profiling) { m->n_prof = 0; return 0; }
+    for (size_t i = 0; i < n_rec && i < m->prof.size(); ++i)
+        hipEventElapsedTime(&m->prof[i].ms, m->prof[i].e0, m->prof[i].e1);
+    m->n_prof = n_rec;
+    return 0;
+}
+
+enum { PROF_PRE = 100, PROF_DECODE = 101, PROF_NMS = 102 };
+
+int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
+                  float* out_boxes, float* out_kpts, int32_t* out_counts) {
+    if (!m || !p) return 1;
+    pa_engine* e = m->e;
+    if (m->d.task != PA_TASK_DETECT && m->d.task != PA_TASK_POSE) PA_FAIL(e, "pa_yolo_infer on a non-YOLO model");
+    if (!frames || n <= 0 || h <= 0 || w <= 0 || !out_boxes || !out_counts) PA_FAIL(e, "pa_yolo_infer: bad arguments");
+    if (m->d.nk && !out_kpts) PA_FAIL(e, "pa_yolo_infer: out_kpts is NULL for a pose model");
+    if (p->max_det < 1 || p->max_det > 300) PA_FAIL(e, "max_det %d outside [1,300]", p->max_det);
+    PA_HIP(e, hipSetDevice(e->dev));
+    if (!m->planned || m->p_h0 != h || m->p_w0 != w || m->p_imgsz != p->imgsz || m->p_pre != p->pre_mode ||
+        m->p_auto != p->letterbox_auto || m->p_batch != m->max_batch)
+        if (plan_yolo(m, h, w, p)) return 1;
+    hipStream_t s = e->stream;
+    if (p->n_classes > 0) {
+        if (p->n_classes > m->classes_cap) {
+            if (m->d_classes) hipFree(m->d_classes);
+            PA_HIP(e, hipMalloc((void**)&m->d_classes, p->n_classes * sizeof(int32_t)));
+            m->classes_cap = p->n_classes;
+        }
+        PA_HIP(e, hipMemcpyAsync(m->d_classes, p->classes, p->n_classes * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    const size_t frame_bytes = (size_t)h * w * 3;
+    const int S = p->imgsz;
+    // scale_boxes / scale_coords parameters (upstream treats the PIL-resized image as the source)
+    const int oh = p->pre_mode == PA_PRE_PIL_STRETCH ? S : h, ow = p->pre_mode == PA_PRE_PIL_STRETCH ? S : w;
+    const double gain = std::min((double)m->net_h / oh, (double)m->net_w / ow);
+    const double kpx = (m->net_w - ow * gain) / 2, kpy = (m->net_h - oh * gain) / 2;
+    size_t pi = 0;
+    for (int c0 = 0; c0 < n; c0 += m->max_batch) {
+        const int nb = std::min(m->max_batch, n - c0);
+        const uint8_t* src = frames + (size_t)c0 * frame_bytes;
+        if (!p->frames_on_device) {
+            if (m->frames_cap < (size_t)nb * frame_bytes) {
+                if (m->d_frames) hipFree(m->d_frames);
+                m->frames_cap = (size_t)m->max_batch * frame_bytes;
+                PA_HIP(e, hipMalloc((void**)&m->d_frames, m->frames_cap));
+            }
+            PA_HIP(e, hipMemcpyAsync(m->d_frames, src, (size_t)nb * frame_bytes, hipMemcpyHostToDevice, s));
+            src = m->d_frames;
+        }
+        // ---- preprocessing -> u8 NHWC4 network input
+        ProfRec* pr = prof_begin(m, pi++, PROF_PRE, 0, 0.0);
+        hipError_t r = hipSuccess;
+        if (p->pre_mode == PA_PRE_LETTERBOX || (h == S && w == S)) {
+            LetterboxArgs a{};
+            a.src = src; a.dst = m->d_netin; a.B = nb; a.h0 = h; a.w0 = w; a.rw = m->rw; a.rh = m->rh;
+            a.top = m->top; a.left = m->left; a.nh = m->net_h; a.nw = m->net_w; a.mode = m->lb_mode;
+            a.reverse = p->channel_reverse; a.xtab = m->d_xtab; a.ytab = m->d_ytab;
+            r = launch_letterbox(a, s);
+        } else {
+            const uint8_t* cur = src; int ch = h, cw = w, cc = 3;
+            if (w != S) {
+                ResamplePassArgs a{};
+                const bool last = (h == S);
+                a.in = cur; a.out = last ? m->d_netin : m->d_tmp; a.B = nb; a.in_h = ch; a.in_w = cw; a.in_c = cc;
+                a.out_h = ch; a.out_w = S; a.out_c = last ? 4 : 3; a.vertical = 0; a.bounds = m->d_hb; a.coefs = m->d_hk;
+                a.ksize = m->hks; a.reverse = last ? p->channel_reverse : 0;
+                r = launch_resample_pass(a, s);
+                cur = m->d_tmp; cw = S;
+            }
+            if (r == hipSuccess && h != S) {
+                ResamplePassArgs a{};
+                a.in = cur; a.out = m->d_netin; a.B = nb; a.in_h = ch; a.in_w = cw; a.in_c = cc;
+                a.out_h = S; a.out_w = cw; a.out_c = 4; a.vertical = 1; a.bounds = m->d_vb; a.coefs = m->d_vk;
+                a.ksize = m->vks; a.reverse = p->channel_reverse;
+                r = launch_resample_pass(a, s);
+            }
+        }
+        prof_end(m, pr);
+        if (r != hipSuccess) PA_FAIL(e, "preprocess launch failed: %s", hipGetErrorString(r));
+        // ---- network
+        if (run_ops(m, nb, &pi)) return 1;
+        // ---- decode + NMS
+        DecodeArgs da{};
+        for (int l = 0; l < 3; ++l) da.lv[l] = m->lv[l];
+        da.cs = m->bufs[m->d.head_buf[0]].channels; da.nc = m->d.nc; da.nk = m->d.nk; da.kdim = m->d.kpt_dim;
+        da.A = m->A; da.B = nb; da.conf = p->conf; da.classes = m->d_classes; da.n_classes = p->n_classes;
+        da.cand = m->d_cand; da.cand_idx = m->d_cidx; da.cand_cnt = m->d_ccnt;
+        pr = prof_begin(m, pi++, PROF_DECODE, 0, 0.0);
+        r = launch_decode(da, s);
+        prof_end(m, pr);
+        if (r != hipSuccess) PA_FAIL(e, "decode launch failed: %s", hipGetErrorString(r));
+        NmsArgs na{};
+        na.cand = m->d_cand; na.cand_idx = m->d_cidx; na.cand_cnt = m->d_ccnt; na.keys = m->d_keys;
+        na.order = m->d_order; na.supp = m->d_supp;
+        for (int l = 0; l < 3; ++l) na.lv[l] = m->lv[l];
+        na.cs = da.cs; na.nc = m->d.nc; na.nk = m->d.nk; na.kdim = m->d.kpt_dim; na.A = m->A; na.B = nb; na.P2 = m->P2;
+        na.iou = p->iou; na.max_det = p->max_det; na.max_nms = 30000;
+        na.gain = (float)gain;
+        na.pad_x = (float)std::nearbyint(kpx - 0.1); na.pad_y = (float)std::nearbyint(kpy - 0.1);
+        na.kpad_x = (float)kpx; na.kpad_y = (float)kpy;
+        na.w0 = (float)ow; na.h0 = (float)oh;
+        na.out_boxes = m->d_oboxes; na.out_kpts = m->d_okpts; na.out_cnt = m->d_ocnt;
+        pr = prof_begin(m, pi++, PROF_NMS, 0, 0.0);
+        r = launch_nms(na, s);
+        prof_end(m, pr);
+        if (r != hipSuccess) PA_FAIL(e, "nms launch failed: %s", hipGetErrorString(r));
+        // ---- results back to the caller's arrays (rows beyond max_det are never written on device)
+        PA_HIP(e, hipMemcpyAsync(out_counts + c0, m->d_ocnt, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        PA_HIP(e, hipMemcpyAsync(out_boxes + (size_t)c0 * p->max_det * 6, m->d_oboxes,
+                                 (size_t)nb * p->max_det * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+        if (m->d.nk)
+            PA_HIP(e, hipMemcpyAsync(out_kpts + (size_t)c0 * p->max_det * m->d.nk, m->d_okpts,
+                                     (size_t)nb * p->max_det * m->d.nk * sizeof(float), hipMemcpyDeviceToHost, s));
+        PA_HIP(e, hipStreamSynchronize(s));
+        m->last_n = nb;
+    }
+    finish_profile(m, pi);
+    return 0;
+}
+
+int pa_yolo_head_shape(pa_model* m, int level, int* h, int* w, int* c) {
+    if (!m->planned || level < 0 || level > 2) PA_FAIL(m->e, "pa_yolo_head_shape: no plan / bad level");
+    *h = m->lv[level].H; *w = m->lv[level].W; *c = m->bufs[m->d.head_buf[0]].channels;
+    return 0;
+}
+
+int pa_yolo_read_head(pa_model* m, int level, int n, float* out) {
+    pa_engine* e = m->e;
+    if (!m->planned || level < 0 || level > 2 || n > m->last_n) PA_FAIL(e, "pa_yolo_read_head: no plan / bad level / n");
+    PA_HIP(e, hipSetDevice(e->dev));
+    const size_t bytes = (size_t)n * m->lv[level].H * m->lv[level].W * m->bufs[m->d.head_buf[0]].channels * sizeof(float);
+    PA_HIP(e, hipMemcpyAsync(out, m->lv[level].buf, bytes, hipMemcpyDeviceToHost, e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on_device, float* out, int out_on_device) {
+    if (!m) return 1;
+    pa_engine* e = m->e;
+    if (m->d.task != PA_TASK_TRACKNET) PA_FAIL(e, "pa_tracknet_infer on a non-TrackNet model");
+    if (!x || !out || n <= 0) PA_FAIL(e, "pa_tracknet_infer: bad arguments");
+    PA_HIP(e, hipSetDevice(e->dev));
+    if (!m->planned || m->net_h != h || m->net_w != w || m->p_batch != m->max_batch) {
+        PA_HIP(e, hipStreamSynchronize(e->stream));
+        free_plan(m);
+        m->net_h = h; m->net_w = w;
+        if (plan_buffers(m, m->max_batch)) return 1;
+        m->planned = true;
+    }
+    hipStream_t s = e->stream;
+    const int cin = m->bufs[0].channels;
+    const int ob = m->d.head_buf[0];
+    const int cout = m->bufs[ob].channels;
+    size_t pi = 0;
+    for (int c0 = 0; c0 < n; c0 += m->max_batch) {
+        const int nb = std::min(m->max_batch, n - c0);
+        const size_t in_bytes = (size_t)nb * h * w * cin * sizeof(float);
+        PA_HIP(e, hipMemcpyAsync(m->bptr[0], x + (size_t)c0 * h * w * cin, in_bytes,
+                                 x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        if (run_ops(m, nb, &pi)) return 1;
+        const size_t out_bytes = (size_t)nb * h * w * cout * sizeof(float);
+        PA_HIP(e, hipMemcpyAsync(out + (size_t)c0 * h * w * cout, m->bptr[ob], out_bytes,
+                                 out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+        PA_HIP(e, hipStreamSynchronize(s));
+    }
+    finish_profile(m, pi);
+    return 0;
+}
+
+int pa_model_last_profile(pa_model* m, int cap, int32_t* kinds, float* ms, double* flops, int32_t* ksizes) {
+    int n = 0;
+    for (size_t i = 0; i < m->n_prof && i < m->prof.size() && n < cap; ++i, ++n) {
+        kinds[n] = m->prof[i].kind; ms[n] = m->prof[i].ms; flops[n] = m->prof[i].flops; ksizes[n] = m->prof[i].ksize;
+    }
+    return n;
+}
+
+}  // extern "C"

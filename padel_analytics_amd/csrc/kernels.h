@@ -1,0 +1,122 @@
+// Internal kernel-launch interface of libpadel_hip.so (not part of the C-ABI).
+// All activation tensors are fp32 NHWC in HBM: element (n, y, x, c) of a buffer with
+// pixel stride `cs` lives at  base[((n*H + y)*W + x)*cs + c].  A layer reads / writes a
+// channel slice [choff, choff+C) of such a buffer, which is how torch.cat / chunk of the
+// YOLOv8 / TrackNet graphs are realised without ever copying.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace padel {
+
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+
+struct ConvArgs {
+    const float* in;      // input buffer base
+    const float* w;       // packed weights [Npad][Ktot], K order = (c32 chunk, tap, c16 half)
+    const float* bias;    // [Npad]
+    const float* res;     // optional residual buffer base (added AFTER the activation) or nullptr
+    const float* zeros;   // >= 64 bytes of zeros in HBM (source of padded taps)
+    float* out;           // output buffer base
+    int in_cs, in_choff;  // input pixel stride (channels) and channel offset of the slice read
+    int out_cs, out_choff;
+    int res_cs, res_choff;
+    int H, W;             // input spatial size
+    int Ho, Wo;           // output spatial size
+    int cin;              // channels read (multiple of 16)
+    int cout;             // real output channels (stores are masked to < cout)
+    int n16;              // rows of the packed weight matrix / 16 (cout padded up to 16)
+    int ksize, stride;    // 1 or 3 ; 1 or 2   (pad = ksize/2)
+    int act;
+    int M;                // batch * Ho * Wo
+    int n_mtiles;         // ceil(M / (4 * MF * 16))
+};
+
+// implicit-GEMM conv on v_mfma_f32_16x16x4_f32; MF in {1,2,4}, NF in {1..6}
+hipError_t launch_conv_igemm(const ConvArgs& a, int mf, int nf, hipStream_t s);
+// heuristic tile choice for a (M, npad16) problem: returns mf, nf and the N padding it implies
+void choose_conv_tile(int M, int n16, int* mf, int* nf);
+
+struct StemArgs {
+    const uint8_t* in;    // net input u8 NHWC4 [B][H][W][4]
+    const float* w;       // [cout][27] (ky,kx,c) fused BN
+    const float* bias;    // [cout]
+    float* out;           // NHWC fp32, pixel stride out_cs
+    int out_cs, out_choff;
+    int H, W, Ho, Wo, cout, B;
+};
+hipError_t launch_stem(const StemArgs& a, hipStream_t s);
+
+// SPPF: three chained MaxPool2d(5,1,2) of slice [choff, choff+c) written to the next three slices
+hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s);
+// nearest x2 upsample of a slice into a slice of a buffer with twice the spatial size
+hipError_t launch_upsample2x(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
+                             int c, int B, int H, int W, hipStream_t s);
+// MaxPool2d(2,2)
+hipError_t launch_maxpool2(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
+                           int c, int B, int H, int W, hipStream_t s);
+
+// ---- preprocessing -----------------------------------------------------------------
+struct LetterboxArgs {
+    const uint8_t* src;   // [B][h0][w0][3] u8
+    uint8_t* dst;         // [B][nh][nw][4] u8 (4th byte 0)
+    int B, h0, w0;        // source size
+    int rw, rh;           // resized (unpadded) size
+    int top, left;        // letterbox offsets
+    int nh, nw;           // network input size
+    int mode;             // 0 copy, 1 exact 2x2 area, 2 fixed-point bilinear (cv2 INTER_LINEAR)
+    int reverse;          // 1: dst channel c = src channel 2-c
+    const int32_t* xtab;  // mode 2: [rw][3] = {sx, a0, a1}
+    const int32_t* ytab;  // mode 2: [rh][3] = {sy, b0, b1}
+};
+hipError_t launch_letterbox(const LetterboxArgs& a, hipStream_t s);
+
+// Pillow-style separable resample pass over u8 images (coefficients precomputed on host):
+// out[b][y][x][c] = clip8((sum_k coef[o][k] * in[...lo[o]+k...] + (1<<21)) >> 22)
+struct ResamplePassArgs {
+    const uint8_t* in; uint8_t* out;
+    int B, in_h, in_w, in_c;      // input dims (in_c = 3 or 4 bytes per pixel)
+    int out_h, out_w, out_c;      // output dims
+    int vertical;                 // 0: horizontal pass (out_h == in_h), 1: vertical (out_w == in_w)
+    const int32_t* bounds;        // [out][2] = {lo, n}
+    const int32_t* coefs;         // [out][ksize]
+    int ksize;
+    int reverse;                  // reverse the 3 colour channels while writing
+};
+hipError_t launch_resample_pass(const ResamplePassArgs& a, hipStream_t s);
+
+// ---- detect / pose post-processing -------------------------------------------------
+struct HeadLevel { const float* buf; int H, W, stride, anchor0; };
+struct DecodeArgs {
+    HeadLevel lv[3];
+    int cs;               // head pixel stride = 64 + nc + nk
+    int nc, nk, kdim;
+    int A, B;
+    float conf;
+    const int32_t* classes; int n_classes;   // device array or nullptr
+    // outputs: per image candidate list
+    float* cand;          // [B][A][6]  x1,y1,x2,y2 (net px), score, cls
+    int32_t* cand_idx;    // [B][A] anchor index
+    int32_t* cand_cnt;    // [B]
+};
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s);
+
+struct NmsArgs {
+    const float* cand; const int32_t* cand_idx; const int32_t* cand_cnt;
+    uint64_t* keys;       // [B][P2] sort scratch (P2 = pow2 >= A)
+    int32_t* order;       // [B][A] scratch
+    uint8_t* supp;        // [B][A] scratch
+    HeadLevel lv[3];
+    int cs, nc, nk, kdim, A, B, P2;
+    float iou; int max_det; int max_nms;
+    // scale_boxes / scale_coords
+    float gain; float pad_x, pad_y;        // rounded pads for boxes
+    float kpad_x, kpad_y;                  // unrounded pads for keypoints
+    float w0, h0;
+    float* out_boxes;     // [B][max_det][6]
+    float* out_kpts;      // [B][max_det][K*kdim] or nullptr
+    int32_t* out_cnt;     // [B]
+};
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
+
+}  // namespace padel

@@ -1,0 +1,202 @@
+// K8/K9 — Detect/Pose decode + confidence filter + per-image batched NMS + scale_boxes/scale_coords
+// (gfx950).  Restates on device what the reference gets from
+//   [upstream] ultralytics Detect/Pose inference branch + ops.non_max_suppression + torchvision.ops.nms
+//   + ops.scale_boxes / scale_coords, reached from players_tracker.py:351-359 and
+//   players_keypoints_tracker.py:285-292.
+//
+// Layout: the head of level l is an NHWC fp32 map [B][H_l][W_l][64 + nc + nk]; anchors are numbered
+// P3,P4,P5 row-major (y outer) exactly like upstream's make_anchors.
+//
+// decode_kernel : one thread per (image, anchor).  Reads the nc class logits (contiguous), keeps the
+//                 anchor iff max sigmoid > conf and its arg-max class is allowed, only then runs the
+//                 DFL softmax-expectation and dist2bbox, and appends to the image's candidate list
+//                 (one atomic per survivor; order is restored by the sort in nms_kernel).
+// nms_kernel    : one workgroup per image: bitonic sort of 64-bit keys (~score | anchor | slot) ==
+//                 torchvision's stable descending sort, greedy IoU suppression, then the kept boxes /
+//                 keypoints are rescaled to source-frame pixels and written in rank order.
+#include "kernels.h"
+
+namespace padel {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ void __launch_bounds__(256) decode_kernel(const DecodeArgs a) {
+    const int b = blockIdx.y;
+    const int ai = blockIdx.x * 256 + threadIdx.x;
+    if (ai >= a.A) return;
+    int l = 0;
+    if (ai >= a.lv[2].anchor0) l = 2; else if (ai >= a.lv[1].anchor0) l = 1;
+    const HeadLevel lv = a.lv[l];
+    const int pix = ai - lv.anchor0;
+    const float* h = lv.buf + ((long long)b * lv.H * lv.W + pix) * a.cs;
+
+    // class scores: max over sigmoid == sigmoid of max logit (monotone); arg-max in sigmoid space,
+    // first index wins, like torch.max
+    const float* cl = h + 64;
+    float mx = cl[0];
+    for (int c = 1; c < a.nc; ++c) mx = fmaxf(mx, cl[c]);
+    const float score = sigmoidf_(mx);
+    if (!(score > a.conf)) return;
+    int cls = 0;
+    for (int c = 0; c < a.nc; ++c) {
+        if (sigmoidf_(cl[c]) == score) { cls = c; break; }
+    }
+    if (a.n_classes > 0) {
+        bool ok = false;
+        for (int k = 0; k < a.n_classes; ++k) ok |= (a.classes[k] == cls);
+        if (!ok) return;
+    }
+
+    // DFL: softmax over 16 bins, expectation with arange(16)
+    float d[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        float v[16];
+        float m = h[s * 16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[i] = h[s * 16 + i]; m = fmaxf(m, v[i]); }
+        float sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - m); sum += v[i]; }
+        float e = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) e += (v[i] / sum) * (float)i;
+        d[s] = e;
+    }
+    const float ax = (float)(pix % lv.W) + 0.5f, ay = (float)(pix / lv.W) + 0.5f;
+    const float st = (float)lv.stride;
+    // dist2bbox(xywh=True) * stride, then xywh2xyxy (same op order as upstream)
+    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+    const float cx = ((x1 + x2) / 2.0f) * st, cy = ((y1 + y2) / 2.0f) * st;
+    const float w = (x2 - x1) * st, hh = (y2 - y1) * st;
+    const float hw = w / 2.0f, hhh = hh / 2.0f;
+
+    const int slot = atomicAdd(&a.cand_cnt[b], 1);
+    float* o = a.cand + ((long long)b * a.A + slot) * 6;
+    o[0] = cx - hw; o[1] = cy - hhh; o[2] = cx + hw; o[3] = cy + hhh; o[4] = score; o[5] = (float)cls;
+    a.cand_idx[(long long)b * a.A + slot] = ai;
+}
+
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(a.cand_cnt, 0, sizeof(int32_t) * a.B, s);
+    if (e != hipSuccess) return e;
+    dim3 grid((a.A + 255) / 256, a.B, 1);
+    hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------- NMS
+#define NMS_THREADS 1024
+#define NMS_LDS_KEYS 4096
+
+__global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
+    __shared__ uint64_t skeys[NMS_LDS_KEYS];
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    int n = a.cand_cnt[b];
+    if (n > a.A) n = a.A;
+    const float* cand = a.cand + (long long)b * a.A * 6;
+    const int32_t* cidx = a.cand_idx + (long long)b * a.A;
+    int32_t* order = a.order + (long long)b * a.A;
+    uint8_t* supp = a.supp + (long long)b * a.A;
+
+    int p2 = 1;
+    while (p2 < n) p2 <<= 1;
+    uint64_t* keys = (p2 <= NMS_LDS_KEYS) ? skeys : (a.keys + (long long)b * a.P2);
+
+    for (int i = tid; i < p2; i += NMS_THREADS) {
+        uint64_t k = ~0ull;
+        if (i < n) {
+            const uint32_t sb = __float_as_uint(cand[i * 6 + 4]);     // score > 0: bits are order-preserving
+            k = ((uint64_t)(~sb) << 32) | ((uint64_t)(uint32_t)cidx[i] << 16) | (uint32_t)i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < p2; i += NMS_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = keys[i], y = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { keys[i] = y; keys[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    int ne = n < a.max_nms ? n : a.max_nms;
+    for (int i = tid; i < ne; i += NMS_THREADS) { order[i] = (int)(keys[i] & 0xffffu); supp[i] = 0; }
+    __syncthreads();
+
+    // greedy suppression in rank order; boxes are offset by cls * 7680 like upstream (agnostic=False)
+    int kept = 0;
+    for (int i = 0; i < ne; ++i) {
+        if (supp[i]) continue;                       // uniform: every thread reads the same byte
+        const int slot_i = order[i];
+        if (tid == 0) order[kept] = slot_i;          // compacted list of kept slots (kept <= i: consumed already)
+        ++kept;
+        if (kept >= a.max_det) break;
+        const float* bi = cand + slot_i * 6;
+        const float off_i = bi[5] * 7680.0f;
+        const float ix1 = bi[0] + off_i, iy1 = bi[1] + off_i, ix2 = bi[2] + off_i, iy2 = bi[3] + off_i;
+        const float iarea = (ix2 - ix1) * (iy2 - iy1);
+        for (int j = i + 1 + tid; j < ne; j += NMS_THREADS) {
+            if (supp[j]) continue;
+            const float* bj = cand + order[j] * 6;
+            const float off_j = bj[5] * 7680.0f;
+            const float jx1 = bj[0] + off_j, jy1 = bj[1] + off_j, jx2 = bj[2] + off_j, jy2 = bj[3] + off_j;
+            const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
+            const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
+            const float inter = w * h;
+            const float ovr = inter / (iarea + (jx2 - jx1) * (jy2 - jy1) - inter);
+            if (ovr > a.iou) supp[j] = 1;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) a.out_cnt[b] = kept;
+
+    // write kept detections in rank order, rescaled to the source frame
+    const int nkv = a.nk;
+    for (int k = tid; k < kept; k += NMS_THREADS) {
+        const int slot = order[k];
+        const float* c = cand + slot * 6;
+        float* o = a.out_boxes + ((long long)b * a.max_det + k) * 6;
+        float x1 = (c[0] - a.pad_x) / a.gain, y1 = (c[1] - a.pad_y) / a.gain;
+        float x2 = (c[2] - a.pad_x) / a.gain, y2 = (c[3] - a.pad_y) / a.gain;
+        o[0] = fminf(fmaxf(x1, 0.0f), a.w0); o[1] = fminf(fmaxf(y1, 0.0f), a.h0);
+        o[2] = fminf(fmaxf(x2, 0.0f), a.w0); o[3] = fminf(fmaxf(y2, 0.0f), a.h0);
+        o[4] = c[4]; o[5] = c[5];
+        if (nkv > 0 && a.out_kpts) {
+            const int ai = cidx[slot];
+            int l = 0;
+            if (ai >= a.lv[2].anchor0) l = 2; else if (ai >= a.lv[1].anchor0) l = 1;
+            const HeadLevel lv = a.lv[l];
+            const int pix = ai - lv.anchor0;
+            const float* h = lv.buf + ((long long)b * lv.H * lv.W + pix) * a.cs + 64 + a.nc;
+            const float ax = (float)(pix % lv.W) + 0.5f, ay = (float)(pix / lv.W) + 0.5f;
+            const float st = (float)lv.stride;
+            float* ko = a.out_kpts + ((long long)b * a.max_det + k) * nkv;
+            const int K = nkv / a.kdim;
+            for (int q = 0; q < K; ++q) {
+                float kx = (h[q * a.kdim] * 2.0f + (ax - 0.5f)) * st;
+                float ky = (h[q * a.kdim + 1] * 2.0f + (ay - 0.5f)) * st;
+                kx = (kx - a.kpad_x) / a.gain;
+                ky = (ky - a.kpad_y) / a.gain;
+                ko[q * a.kdim] = fminf(fmaxf(kx, 0.0f), a.w0);
+                ko[q * a.kdim + 1] = fminf(fmaxf(ky, 0.0f), a.h0);
+                if (a.kdim == 3) ko[q * a.kdim + 2] = sigmoidf_(h[q * a.kdim + 2]);
+            }
+        }
+    }
+}
+
+hipError_t launch_nms(const NmsArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(nms_kernel, dim3(a.B), dim3(NMS_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace padel

@@ -1,0 +1,268 @@
+"""ctypes binding of ``libpadel_hip.so`` (C-ABI: ``include/padel_hip.h``).
+
+This is the only place the package talks to the GPU.  There is deliberately NO CPU fallback: if
+the shared library or a GPU is missing every entry point raises ``EngineUnavailable`` (the product
+path must fail loudly rather than silently route through a CPU restatement).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import graph as G
+
+_LIB_PATH = Path(__file__).resolve().parent / "libpadel_hip.so"
+_lib = None
+
+
+class EngineUnavailable(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class pa_buf_desc(C.Structure):
+    _fields_ = [("level", C.c_int32), ("channels", C.c_int32)]
+
+
+class pa_op_desc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_buf", C.c_int32), ("in_choff", C.c_int32), ("cin", C.c_int32),
+                ("out_buf", C.c_int32), ("out_choff", C.c_int32), ("cout", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32),
+                ("res_buf", C.c_int32), ("res_choff", C.c_int32), ("npad", C.c_int32), ("reserved", C.c_int32),
+                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class pa_model_desc(C.Structure):
+    _fields_ = [("task", C.c_int32), ("nc", C.c_int32), ("nk", C.c_int32), ("kpt_dim", C.c_int32),
+                ("n_bufs", C.c_int32), ("bufs", C.POINTER(pa_buf_desc)),
+                ("n_ops", C.c_int32), ("ops", C.POINTER(pa_op_desc)),
+                ("head_buf", C.c_int32 * 3), ("in_channels", C.c_int32)]
+
+
+class pa_yolo_params(C.Structure):
+    _fields_ = [("imgsz", C.c_int32), ("pre_mode", C.c_int32), ("channel_reverse", C.c_int32),
+                ("letterbox_auto", C.c_int32), ("conf", C.c_float), ("iou", C.c_float),
+                ("max_det", C.c_int32), ("n_classes", C.c_int32), ("classes", C.POINTER(C.c_int32)),
+                ("frames_on_device", C.c_int32)]
+
+
+PRE_LETTERBOX, PRE_PIL_STRETCH = 0, 1
+
+# every symbol include/padel_hip.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = [
+    "pa_abi_version", "pa_device_count", "pa_engine_create", "pa_engine_destroy", "pa_last_error",
+    "pa_engine_synchronize", "pa_device_malloc", "pa_device_free", "pa_memcpy_h2d", "pa_memcpy_d2h",
+    "pa_model_create", "pa_model_destroy", "pa_model_set_max_batch", "pa_yolo_infer", "pa_yolo_head_shape",
+    "pa_yolo_read_head", "pa_tracknet_infer", "pa_engine_set_profiling", "pa_model_last_profile",
+]
+
+
+def lib_path() -> Path:
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen libpadel_hip.so (once).  torch is imported first so that the process holds a single
+    HIP runtime (torch's bundled libamdhip64.so.7 satisfies our DT_NEEDED by SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise EngineUnavailable(f"{_LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+    if os.environ.get("PADEL_HIP_STANDALONE") != "1":
+        import torch  # noqa: F401  (shares one libamdhip64 with RCCL/torch.distributed users)
+    lib = C.CDLL(str(_LIB_PATH))
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.pa_abi_version.restype = i32
+    lib.pa_device_count.restype = i32
+    lib.pa_engine_create.argtypes = [i32, C.POINTER(vp)]
+    lib.pa_engine_destroy.argtypes = [vp]
+    lib.pa_engine_destroy.restype = None
+    lib.pa_last_error.argtypes = [vp]
+    lib.pa_last_error.restype = C.c_char_p
+    lib.pa_engine_synchronize.argtypes = [vp]
+    lib.pa_device_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.pa_device_free.argtypes = [vp, vp]
+    lib.pa_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    lib.pa_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    lib.pa_model_create.argtypes = [vp, C.POINTER(pa_model_desc), vp, sz, C.POINTER(vp)]
+    lib.pa_model_destroy.argtypes = [vp]
+    lib.pa_model_destroy.restype = None
+    lib.pa_model_set_max_batch.argtypes = [vp, i32]
+    lib.pa_yolo_infer.argtypes = [vp, vp, i32, i32, i32, C.POINTER(pa_yolo_params), vp, vp, vp]
+    lib.pa_yolo_head_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.pa_yolo_read_head.argtypes = [vp, i32, i32, vp]
+    lib.pa_tracknet_infer.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32]
+    lib.pa_engine_set_profiling.argtypes = [vp, i32]
+    lib.pa_model_last_profile.argtypes = [vp, i32, vp, vp, vp, vp]
+    if lib.pa_abi_version() != 1:
+        raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+class DeviceBuffer:
+    """Raw HBM allocation owned by an Engine (bench keeps frame batches resident with it)."""
+
+    def __init__(self, engine: "Engine", nbytes: int):
+        self.engine, self.nbytes = engine, nbytes
+        p = C.c_void_p()
+        engine._check(engine.lib.pa_device_malloc(engine.handle, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.engine._check(self.engine.lib.pa_memcpy_h2d(self.engine.handle, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, arr: np.ndarray) -> np.ndarray:
+        assert arr.flags.c_contiguous and arr.nbytes <= self.nbytes
+        self.engine._check(self.engine.lib.pa_memcpy_d2h(self.engine.handle, arr.ctypes.data, self.ptr, arr.nbytes))
+        return arr
+
+    def free(self):
+        if self.ptr:
+            self.engine.lib.pa_device_free(self.engine.handle, self.ptr)
+            self.ptr = None
+
+
+class Engine:
+    """One engine (HIP stream + device) per GPU."""
+
+    def __init__(self, device_id: int = 0):
+        self.lib = load_library()
+        if self.lib.pa_device_count() <= 0:
+            raise EngineUnavailable("no HIP device visible: the padel_analytics_amd engine needs an AMD GPU (gfx950)")
+        h = C.c_void_p()
+        if self.lib.pa_engine_create(device_id, C.byref(h)) != 0:
+            raise EngineUnavailable(self.lib.pa_last_error(None).decode())
+        self.handle = h
+        self.device_id = device_id
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(self.lib.pa_last_error(self.handle).decode())
+
+    def synchronize(self):
+        self._check(self.lib.pa_engine_synchronize(self.handle))
+
+    def set_profiling(self, on: bool):
+        self._check(self.lib.pa_engine_set_profiling(self.handle, 1 if on else 0))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def close(self):
+        if self.handle:
+            self.lib.pa_engine_destroy(self.handle)
+            self.handle = None
+
+
+_default_engines: dict = {}
+
+
+def default_engine(device_id: Optional[int] = None) -> Engine:
+    if device_id is None:
+        device_id = int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("PADEL_DEVICE") is None \
+            else int(os.environ["PADEL_DEVICE"])
+        load_library()
+        n = _lib.pa_device_count()
+        if n > 0:
+            device_id %= n
+    if device_id not in _default_engines:
+        _default_engines[device_id] = Engine(device_id)
+    return _default_engines[device_id]
+
+
+class Model:
+    """A graph + weights resident in HBM on one engine."""
+
+    def __init__(self, engine: Engine, graph: G.Graph, blob: Optional[np.ndarray] = None):
+        self.engine, self.graph = engine, graph
+        blob = graph.blob() if blob is None else np.ascontiguousarray(blob, np.float32)
+        bufs = (pa_buf_desc * len(graph.bufs))(*[pa_buf_desc(l, c) for l, c in graph.bufs])
+        ops = (pa_op_desc * len(graph.ops))()
+        for i, o in enumerate(graph.ops):
+            for k, v in o.items():
+                setattr(ops[i], k, int(v))
+        d = pa_model_desc(task=graph.task, nc=graph.nc, nk=graph.nk, kpt_dim=graph.kpt_dim, n_bufs=len(graph.bufs),
+                          bufs=bufs, n_ops=len(graph.ops), ops=ops, in_channels=graph.in_channels)
+        for i in range(3):
+            d.head_buf[i] = graph.head_buf[i] if i < len(graph.head_buf) else -1
+        h = C.c_void_p()
+        engine._check(engine.lib.pa_model_create(engine.handle, C.byref(d), blob.ctypes.data, blob.size, C.byref(h)))
+        self.handle = h
+        self.max_batch = 64
+
+    def set_max_batch(self, n: int):
+        self.engine._check(self.engine.lib.pa_model_set_max_batch(self.handle, int(n)))
+        self.max_batch = int(n)
+
+    def yolo_infer(self, frames, n: int, h: int, w: int, *, imgsz: int, conf: float, iou: float,
+                   classes: Optional[Sequence[int]] = None, max_det: int = 300, pre_mode: int = PRE_LETTERBOX,
+                   channel_reverse: bool = False, letterbox_auto: bool = True):
+        """frames: (n,h,w,3) uint8 ndarray, or a DeviceBuffer holding the same bytes.
+        Returns (boxes (n,max_det,6), kpts (n,max_det,nk) | None, counts (n,))."""
+        on_dev = isinstance(frames, DeviceBuffer)
+        if on_dev:
+            ptr = frames.ptr
+            assert frames.nbytes >= n * h * w * 3
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            assert frames.shape == (n, h, w, 3), frames.shape
+            ptr = frames.ctypes.data
+        cls_arr = None
+        p = pa_yolo_params(imgsz=imgsz, pre_mode=pre_mode, channel_reverse=int(channel_reverse),
+                           letterbox_auto=int(letterbox_auto), conf=conf, iou=iou, max_det=max_det,
+                           n_classes=0, classes=None, frames_on_device=int(on_dev))
+        if classes is not None and len(classes):
+            cls_arr = (C.c_int32 * len(classes))(*[int(c) for c in classes])
+            p.n_classes = len(classes)
+            p.classes = cls_arr
+        boxes = np.zeros((n, max_det, 6), np.float32)
+        counts = np.zeros((n,), np.int32)
+        nk = self.graph.nk
+        kpts = np.zeros((n, max_det, nk), np.float32) if nk else None
+        self.engine._check(self.engine.lib.pa_yolo_infer(
+            self.handle, ptr, n, h, w, C.byref(p), boxes.ctypes.data,
+            kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
+        return boxes, kpts, counts
+
+    def read_head(self, level: int, n: int) -> np.ndarray:
+        hh, ww, cc = C.c_int(), C.c_int(), C.c_int()
+        self.engine._check(self.engine.lib.pa_yolo_head_shape(self.handle, level, C.byref(hh), C.byref(ww), C.byref(cc)))
+        out = np.empty((n, hh.value, ww.value, cc.value), np.float32)
+        self.engine._check(self.engine.lib.pa_yolo_read_head(self.handle, level, n, out.ctypes.data))
+        return out
+
+    def tracknet_infer(self, x: np.ndarray) -> np.ndarray:
+        """x: (n, H, W, C_in) fp32 NHWC -> (n, H, W, C_out) fp32."""
+        x = np.ascontiguousarray(x, np.float32)
+        n, h, w, c = x.shape
+        assert c == self.graph.bufs[0][1], (c, self.graph.bufs[0])
+        cout = self.graph.bufs[self.graph.head_buf[0]][1]
+        out = np.empty((n, h, w, cout), np.float32)
+        self.engine._check(self.engine.lib.pa_tracknet_infer(self.handle, x.ctypes.data, n, h, w, 0, out.ctypes.data, 0))
+        return out
+
+    def last_profile(self, cap: int = 4096):
+        kinds = np.zeros(cap, np.int32)
+        ms = np.zeros(cap, np.float32)
+        fl = np.zeros(cap, np.float64)
+        ks = np.zeros(cap, np.int32)
+        n = self.engine.lib.pa_model_last_profile(self.handle, cap, kinds.ctypes.data, ms.ctypes.data, fl.ctypes.data,
+                                                  ks.ctypes.data)
+        return [dict(kind=int(kinds[i]), ms=float(ms[i]), flops=float(fl[i]), ksize=int(ks[i])) for i in range(n)]
+
+    def close(self):
+        if self.handle:
+            self.engine.lib.pa_model_destroy(self.handle)
+            self.handle = None

@@ -1,0 +1,251 @@
+"""Host-side graph builder: ``state_dict`` -> (buffer table, op list, packed fp32 weight blob).
+
+This is the one-time work ``YOLO(model_path)`` + ``AutoBackend(fuse=True)`` do upstream
+(``players_tracker.py:303``, SURVEY.md Appendix A "Checkpoint"): fold BatchNorm into the conv
+(``W' = W * g/sqrt(var+eps)``, ``b' = beta - g*mu/sqrt(var+eps)``, fp32), then lay the weights out the
+way the gfx950 kernels read them (``csrc/conv_igemm.hip``):
+
+* conv weights ``[Npad][Ktot]`` with K ordered (32-channel chunk, 3x3 tap, 16-channel half) so that
+  one k-step of the implicit GEMM is one contiguous 64-byte run per output channel;
+* torch.cat / chunk / nn.Upsample never materialise: producers write channel slices of the
+  consumer's concat buffer (C2f, SPPF, the FPN/PAN concats, the Detect/Pose head map).
+
+Nothing here touches a device; the result is handed to ``libpadel_hip.so`` through
+``pa_model_create`` (include/padel_hip.h).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+from . import yolo_arch
+
+# mirror of include/padel_hip.h
+OP_STEM, OP_CONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_MAXPOOL2 = 1, 2, 3, 4, 5
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+TASK_DETECT, TASK_POSE, TASK_TRACKNET = 0, 1, 2
+
+
+def pad16(c: int) -> int:
+    return (c + 15) // 16 * 16
+
+
+def kstep_order(cin: int, ksize: int):
+    """[(tap, c0)] in the order conv_igemm.hip walks K (cin must be a multiple of 16)."""
+    taps = ksize * ksize
+    steps = []
+    for c32 in range(cin // 32):
+        for tap in range(taps):
+            for half in (0, 1):
+                steps.append((tap, c32 * 32 + half * 16))
+    if cin % 32:
+        for tap in range(taps):
+            steps.append((tap, (cin // 32) * 32))
+    return steps
+
+
+def pack_conv_weight(w: np.ndarray) -> np.ndarray:
+    """(Cout, Cin, k, k) fp32 with Cout, Cin multiples of 16 -> [Cout][Ktot] in kernel K order."""
+    cout, cin, k, _ = w.shape
+    assert cout % 16 == 0 and cin % 16 == 0
+    steps = kstep_order(cin, k)
+    out = np.empty((cout, len(steps) * 16), np.float32)
+    for i, (tap, c0) in enumerate(steps):
+        out[:, i * 16:(i + 1) * 16] = w[:, c0:c0 + 16, tap // k, tap % k]
+    return out
+
+
+def fold_bn(sd, prefix: str, eps: float):
+    """Conv+BN fold in fp32, same operation order as ultralytics' fuse_conv_and_bn."""
+    w = np.asarray(sd[f"{prefix}.conv.weight"], np.float32)
+    g = np.asarray(sd[f"{prefix}.bn.weight"], np.float32)
+    beta = np.asarray(sd[f"{prefix}.bn.bias"], np.float32)
+    mu = np.asarray(sd[f"{prefix}.bn.running_mean"], np.float32)
+    var = np.asarray(sd[f"{prefix}.bn.running_var"], np.float32)
+    scale = g / np.sqrt(np.float32(eps) + var)
+    wf = (w.reshape(w.shape[0], -1) * scale[:, None]).reshape(w.shape).astype(np.float32)
+    bf = (beta - (g * mu) / np.sqrt(var + np.float32(eps))).astype(np.float32)
+    return wf, bf
+
+
+@dataclass
+class Graph:
+    task: int
+    nc: int = 0
+    nk: int = 0
+    kpt_dim: int = 0
+    bufs: list = field(default_factory=list)      # (level, channels)
+    ops: list = field(default_factory=list)       # dicts mirroring pa_op_desc
+    chunks: list = field(default_factory=list)    # weight blob pieces
+    n_floats: int = 0
+    head_buf: tuple = (-1, -1, -1)
+    in_channels: int = 0
+
+    # ---- construction helpers
+    def buf(self, level: int, channels: int) -> int:
+        self.bufs.append((level, channels))
+        return len(self.bufs) - 1
+
+    def _add(self, arr: np.ndarray) -> int:
+        arr = np.ascontiguousarray(arr, np.float32).reshape(-1)
+        off = self.n_floats
+        padn = (-arr.size) % 4
+        self.chunks.append(arr)
+        if padn:
+            self.chunks.append(np.zeros(padn, np.float32))
+        self.n_floats += arr.size + padn
+        return off
+
+    def conv(self, src, dst, w, b, k, s, act, res=None, out_width=None):
+        """src = (buf, choff, width read), dst = (buf, choff).  ``w`` is (cout, cin, k, k) with the
+        real channel counts; input channels are zero-padded up to the slice width, output channels up
+        to ``out_width`` (those rows are zero, so the kernel writes act(0) there)."""
+        sb, so, sw = src
+        cout, cin = w.shape[:2]
+        assert sw % 16 == 0 and sw >= cin, (sw, cin)
+        ow = cout if out_width is None else out_width
+        npad = pad16(ow)
+        wp = np.zeros((npad, sw, k, k), np.float32)
+        wp[:cout, :cin] = w
+        bp = np.zeros(npad, np.float32)
+        bp[:cout] = b
+        w_off = self._add(pack_conv_weight(wp))
+        b_off = self._add(bp)
+        self.ops.append(dict(kind=OP_CONV, in_buf=sb, in_choff=so, cin=sw, out_buf=dst[0], out_choff=dst[1],
+                             cout=ow, ksize=k, stride=s, act=act, res_buf=-1 if res is None else res[0],
+                             res_choff=0 if res is None else res[1], npad=npad, w_off=w_off, b_off=b_off))
+
+    def blob(self) -> np.ndarray:
+        return np.concatenate(self.chunks) if self.chunks else np.zeros(0, np.float32)
+
+    def conv_flops(self, net_h: int, net_w: int) -> float:
+        """Real (unpadded would need the spec; this counts the op list as executed) 2*MAC per image."""
+        total = 0.0
+        for o in self.ops:
+            if o["kind"] not in (OP_CONV, OP_STEM):
+                continue
+            lvl = self.bufs[o["out_buf"]][0]
+            hw = (net_h >> lvl) * (net_w >> lvl)
+            kk = 27 if o["kind"] == OP_STEM else o["cin"] * o["ksize"] ** 2
+            total += 2.0 * hw * o["cout"] * kk
+        return total
+
+
+def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None) -> Graph:
+    """YOLOv8 detect / pose graph (SURVEY.md Appendix A layer table) over the engine's op set."""
+    info = yolo_arch.infer_arch_from_state_dict(sd)
+    d = yolo_arch.arch_dims(info["scale"])
+    assert info["nc"] == nc, (info, nc)
+    c2h, c3h, c4h, nk = yolo_arch.head_dims(d, nc, kpt_shape)
+    assert nk == info["nk"], (nk, info)
+    g = Graph(task=TASK_POSE if kpt_shape else TASK_DETECT, nc=nc, nk=nk, kpt_dim=int(kpt_shape[1]) if kpt_shape else 0)
+    eps = yolo_arch.BN_EPS
+    fuse = lambda p: fold_bn(sd, p, eps)
+
+    def cbs(prefix, src, dst, k, s, res=None, out_width=None):
+        w, b = fuse(prefix)
+        g.conv(src, dst, w, b, k, s, ACT_SILU, res, out_width)
+
+    def nblocks(i):
+        n = 0
+        while f"model.{i}.m.{n}.cv1.conv.weight" in sd:
+            n += 1
+        return n
+
+    def c2f(i, src, cout, shortcut, level, dst):
+        n = nblocks(i)
+        c = cout // 2
+        assert c % 16 == 0
+        cat = g.buf(level, (2 + n) * c)
+        tmp = g.buf(level, c)
+        cbs(f"model.{i}.cv1", src, (cat, 0), 1, 1)
+        for j in range(n):
+            cbs(f"model.{i}.m.{j}.cv1", (cat, (1 + j) * c, c), (tmp, 0), 3, 1)
+            cbs(f"model.{i}.m.{j}.cv2", (tmp, 0, c), (cat, (2 + j) * c), 3, 1,
+                res=(cat, (1 + j) * c) if shortcut else None)
+        cbs(f"model.{i}.cv2", (cat, 0, (2 + n) * c), dst, 1, 1)
+
+    c1, c2, c3, c4, c5 = d.c1, d.c2, d.c3, d.c4, d.c5
+    # stem: straight from the u8 network input
+    b0 = g.buf(1, c1)
+    w0, bias0 = fuse("model.0")
+    w_off = g._add(np.ascontiguousarray(w0.transpose(0, 2, 3, 1)).reshape(c1, 27))   # [cout][ky][kx][c]
+    b_off = g._add(bias0)
+    g.ops.append(dict(kind=OP_STEM, in_buf=0, in_choff=0, cin=3, out_buf=b0, out_choff=0, cout=c1, ksize=3, stride=2,
+                      act=ACT_SILU, res_buf=-1, res_choff=0, npad=c1, w_off=w_off, b_off=b_off))
+    b1 = g.buf(2, c2)
+    cbs("model.1", (b0, 0, c1), (b1, 0), 3, 2)
+    b2 = g.buf(2, c2)
+    c2f(2, (b1, 0, c2), c2, True, 2, (b2, 0))
+    b3 = g.buf(3, c3)
+    cbs("model.3", (b2, 0, c2), (b3, 0), 3, 2)
+    cat14 = g.buf(3, c4 + c3)      # [upsample(model.12) | model.4]
+    c2f(4, (b3, 0, c3), c3, True, 3, (cat14, c4))
+    b5 = g.buf(4, c4)
+    cbs("model.5", (cat14, c4, c3), (b5, 0), 3, 2)
+    cat11 = g.buf(4, c5 + c4)      # [upsample(model.9) | model.6]
+    c2f(6, (b5, 0, c4), c4, True, 4, (cat11, c5))
+    b7 = g.buf(5, c5)
+    cbs("model.7", (cat11, c5, c4), (b7, 0), 3, 2)
+    b8 = g.buf(5, c5)
+    c2f(8, (b7, 0, c5), c5, True, 5, (b8, 0))
+    cat20 = g.buf(5, c4 + c5)      # [model.19 | model.9]
+    ch = c5 // 2
+    cat9 = g.buf(5, 4 * ch)
+    cbs("model.9.cv1", (b8, 0, c5), (cat9, 0), 1, 1)
+    g.ops.append(dict(kind=OP_SPPF_POOL, in_buf=cat9, in_choff=0, cin=ch, out_buf=cat9, out_choff=ch, cout=3 * ch,
+                      ksize=5, stride=1, act=0, res_buf=-1, res_choff=0, npad=0, w_off=0, b_off=0))
+    cbs("model.9.cv2", (cat9, 0, 4 * ch), (cat20, c4), 1, 1)
+
+    def upsample(src, dst):
+        g.ops.append(dict(kind=OP_UPSAMPLE2X, in_buf=src[0], in_choff=src[1], cin=src[2], out_buf=dst[0],
+                          out_choff=dst[1], cout=src[2], ksize=0, stride=0, act=0, res_buf=-1, res_choff=0, npad=0,
+                          w_off=0, b_off=0))
+
+    upsample((cat20, c4, c5), (cat11, 0))
+    cat17 = g.buf(4, c3 + c4)      # [model.16 | model.12]
+    c2f(12, (cat11, 0, c5 + c4), c4, False, 4, (cat17, c3))
+    upsample((cat17, c3, c4), (cat14, 0))
+    b15 = g.buf(3, c3)
+    c2f(15, (cat14, 0, c4 + c3), c3, False, 3, (b15, 0))
+    cbs("model.16", (b15, 0, c3), (cat17, 0), 3, 2)
+    b18 = g.buf(4, c4)
+    c2f(18, (cat17, 0, c3 + c4), c4, False, 4, (b18, 0))
+    cbs("model.19", (b18, 0, c4), (cat20, 0), 3, 2)
+    b21 = g.buf(5, c5)
+    c2f(21, (cat20, 0, c4 + c5), c5, False, 5, (b21, 0))
+
+    # Detect / Pose head: the first 3x3 convs of the box / cls / kpt branches share their input, so
+    # they run as ONE conv with concatenated (16-padded) output slices
+    head_cs = (64 + nc + nk + 3) // 4 * 4
+    heads = []
+    branches = [("cv2", c2h, 4 * yolo_arch.REG_MAX, 0), ("cv3", c3h, nc, 64)]
+    if kpt_shape:
+        branches.append(("cv4", c4h, nk, 64 + nc))
+    for l, (feat, chn, lvl) in enumerate(((b15, c3, 3), (b18, c4, 4), (b21, c5, 5))):
+        widths = [pad16(wd) for (_, wd, _, _) in branches]
+        tot = sum(widths)
+        wcat = np.zeros((tot, chn, 3, 3), np.float32)
+        bcat = np.zeros(tot, np.float32)
+        offs = []
+        o = 0
+        for (br, wd, _, _), pw in zip(branches, widths):
+            w, b = fuse(f"model.22.{br}.{l}.0")
+            wcat[o:o + wd] = w
+            bcat[o:o + wd] = b
+            offs.append(o)
+            o += pw
+        h0 = g.buf(lvl, tot)
+        g.conv((feat, 0, chn), (h0, 0), wcat, bcat, 3, 1, ACT_SILU)
+        hd = g.buf(lvl, head_cs)
+        for (br, wd, nout, hoff), pw, o in zip(branches, widths, offs):
+            h1 = g.buf(lvl, pw)
+            cbs(f"model.22.{br}.{l}.1", (h0, o, pw), (h1, 0), 3, 1, out_width=pw)
+            w = np.asarray(sd[f"model.22.{br}.{l}.2.weight"], np.float32)
+            b = np.asarray(sd[f"model.22.{br}.{l}.2.bias"], np.float32)
+            g.conv((h1, 0, pw), (hd, hoff), w, b, 1, 1, ACT_NONE)
+        heads.append(hd)
+    g.head_buf = tuple(heads)
+    return g

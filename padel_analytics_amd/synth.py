@@ -1,0 +1,28 @@
+"""Seeded synthetic inputs: there is no sample video in the reference checkout
+(`.MISSING_LARGE_BLOBS:1-2`), so frames are generated: uint8 HWC **BGR** like
+`sv.get_video_frames_generator` yields (`trackers/runner.py:215-220`), a low-frequency background plus
+a few rectangles so activations sit in a realistic range (not white noise)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def synthetic_frames(n: int, h: int, w: int, seed: int = 0) -> np.ndarray:
+    rng = np.random.default_rng(seed)
+    ys = np.linspace(0, 1, h, dtype=np.float32)[:, None]
+    xs = np.linspace(0, 1, w, dtype=np.float32)[None, :]
+    out = np.empty((n, h, w, 3), np.uint8)
+    for i in range(n):
+        img = np.empty((h, w, 3), np.float32)
+        for c in range(3):
+            a, b, p, q = rng.uniform(0.5, 3.0, 4)
+            ph = rng.uniform(0, 6.28, 2)
+            img[..., c] = 120 + 60 * np.sin(a * 6.28 * xs + ph[0]) * np.cos(b * 6.28 * ys + ph[1]) \
+                + 30 * np.sin(p * 6.28 * (xs + ys)) + 10 * np.cos(q * 12.56 * (xs - ys))
+        for _ in range(int(rng.integers(4, 9))):
+            rh, rw = int(rng.integers(h // 12, h // 3)), int(rng.integers(w // 24, w // 6))
+            y0, x0 = int(rng.integers(0, h - rh)), int(rng.integers(0, w - rw))
+            img[y0:y0 + rh, x0:x0 + rw] = rng.uniform(0, 255, 3).astype(np.float32)
+        img += rng.normal(0, 3.0, img.shape).astype(np.float32)
+        out[i] = np.clip(img, 0, 255).astype(np.uint8)
+    return out

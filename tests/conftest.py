@@ -1,0 +1,20 @@
+import os
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def gpu_engine():
+    """The HIP engine on cuda:0 — fails loudly (no skip, no CPU fallback) if the extension is missing."""
+    from padel_analytics_amd import engine
+    return engine.default_engine(0)
