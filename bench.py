@@ -1,0 +1,244 @@
+#!/usr/bin/env python
+"""bench.py — frames/sec of the trackers' hot path on MI355X (BASELINE.json metric).
+
+One "step" = one pass of one synthetic batch of 1280x720 BGR frames (resident in HBM) through ALL
+trackers of the workload, sequentially like `trackers/runner.py:185` does: for each tracker
+preprocessing -> network forward -> decode -> NMS -> results on the host.  frames/sec = frames / sum of
+tracker times.  One process per GPU (RANK/LOCAL_RANK/WORLD_SIZE from torch.distributed.run); frames
+shard by batch, per-GPU batch fixed (weak scaling); the only collective is a one-time RCCL broadcast
+of the packed weight blobs from rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--batch 64]
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` and `cpu_baseline`.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+# tracker table: name -> (scale, nc, kpt_shape, imgsz, conf, classes, pre_mode, channel_reverse)
+TRACKERS = {
+    # reference default players model is yolov8m.pt (config.py:22), COCO-80, classes=[0], conf .5
+    "players": dict(scale="m", nc=80, kpt=None, imgsz=640, conf=0.5, classes=[0], pre="letterbox", rev=False),
+    # BASELINE configs name a YOLOv8 detect instance for the ball (nc=1); no reference scale -> n
+    "ball": dict(scale="n", nc=1, kpt=None, imgsz=640, conf=0.25, classes=None, pre="letterbox", rev=False),
+    # 13-keypoint pose at train_image_size 1280 (config.py:29-31), conf .25; custom checkpoint of unknown
+    # scale in the reference -> same family as the players default (m)
+    "pose": dict(scale="m", nc=1, kpt=(13, 3), imgsz=1280, conf=0.25, classes=[0], pre="pil", rev=True),
+}
+WORKLOADS = {
+    "c2": ("BASELINE configs[1]: 1280x720 batch=64, players + ball YOLOv8 detect", ["players", "ball"]),
+    "c3": ("BASELINE configs[2]: 1280x720 batch=64, players + ball detect + 13-kpt pose", ["players", "ball", "pose"]),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--chunk", type=int, default=0, help="frames per graph replay (0 = auto)")
+    ap.add_argument("--scales", default="", help="override scales, e.g. players=n,pose=n")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def source_for_oracle(cfg, frames):
+    """What the reference hands to YOLO.predict for these frames (players_tracker.py:346-349,
+    players_keypoints_tracker.py:260-266) — used for weight calibration and the CPU baseline."""
+    if cfg["pre"] == "pil":
+        from PIL import Image
+        S = cfg["imgsz"]
+        return [np.asarray(Image.fromarray(f[..., ::-1].copy()).resize((S, S)))[..., ::-1] for f in frames]
+    return [f[..., ::-1] for f in frames]
+
+
+def make_state_dict(name, cfg, frames):
+    """Setup (untimed): seeded synthetic checkpoint with data-calibrated BatchNorm statistics
+    (oracle/synth_weights.py — weight synthesis, not part of the measured path)."""
+    from oracle import synth_weights, yolov8_ref as ref
+    srcs = source_for_oracle(cfg, frames[:2])
+    im = ref.preprocess(srcs, cfg["imgsz"])
+    return synth_weights.calibrated_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], im, cfg["conf"],
+                                               seed=sum(map(ord, name)))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    import torch
+    from padel_analytics_amd import engine as E, graph as G, synth, yolo_arch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
+
+    for kv in filter(None, a.scales.split(",")):
+        k, v = kv.split("=")
+        TRACKERS[k]["scale"] = v
+    desc, names = WORKLOADS[a.workload]
+    H, W, B = a.height, a.width, a.batch
+
+    eng = E.Engine(local)
+    frames = synth.synthetic_frames(B, H, W, seed=1000 + rank)          # each rank its own shard
+    d_frames = eng.alloc(frames.nbytes).upload(frames)                   # resident in HBM before timing
+
+    # ---- weights: rank 0 synthesises + packs, everyone receives the blob over RCCL
+    models, flops_per_frame = {}, {}
+    for name in names:
+        cfg = TRACKERS[name]
+        if rank == 0:
+            sd = make_state_dict(name, cfg, frames)
+            g = G.build_yolov8(sd, cfg["nc"], cfg["kpt"])
+            blob = g.blob()
+        else:
+            g = G.build_yolov8(yolo_arch.synth_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], 0), cfg["nc"], cfg["kpt"])
+            blob = np.empty(g.n_floats, np.float32)
+        if world > 1:
+            t = torch.from_numpy(blob).cuda(local)
+            dist.broadcast(t, src=0)
+            blob = t.cpu().numpy()
+            del t
+        m = E.Model(eng, g, blob)
+        chunk = a.chunk or (16 if (cfg["imgsz"] >= 1280 and cfg["scale"] in "mlx") else (32 if cfg["imgsz"] >= 1280 else 64))
+        m.set_max_batch(min(B, chunk))
+        models[name] = m
+        S = cfg["imgsz"]
+        if cfg["pre"] == "pil":
+            nh = nw = S
+        else:
+            r = min(S / H, S / W)
+            nw, nh = int(round(W * r)), int(round(H * r))
+            nw, nh = nw + (S - nw) % 32, nh + (S - nh) % 32
+        flops_per_frame[name] = yolo_arch.conv_flops(yolo_arch.conv_inventory(cfg["scale"], cfg["nc"], cfg["kpt"], nh, nw))
+
+    def step():
+        tot = 0
+        for name in names:
+            cfg = TRACKERS[name]
+            boxes, kpts, counts = models[name].yolo_infer(
+                d_frames, B, H, W, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7, classes=cfg["classes"],
+                pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg["rev"])
+            tot += int(counts.sum())
+        return tot
+
+    def fence():
+        eng.synchronize()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ndet = 0
+    for _ in range(a.warmup):
+        ndet = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    fps = world * B * a.steps / dt
+
+    out = {
+        "metric": "frames/sec (all trackers) on 1280x720", "value": round(fps, 2), "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": desc, "frames_per_gpu_per_step": B, "frame_hw": [H, W],
+            "trackers": {n: {"graph": f"yolov8{TRACKERS[n]['scale']}-{'pose13x3' if TRACKERS[n]['kpt'] else 'detect'}"
+                                      f"-nc{TRACKERS[n]['nc']}", "imgsz": TRACKERS[n]["imgsz"],
+                             "conv_gflop_per_frame": round(flops_per_frame[n] / 1e9, 2)} for n in names},
+            "parallelism": f"frames sharded by batch over {world} GPU(s), one-time RCCL weight broadcast",
+            "inputs": "uint8 BGR frames resident in HBM; results (boxes/keypoints after NMS) returned to host",
+            "detections_per_step_rank0": ndet,
+        },
+    }
+
+    if rank == 0 and not a.no_roofline:
+        # ---- roofline of the dominant kernel (conv3x3 implicit GEMM, fp32 MFMA): HIP events recorded on
+        # the engine's own stream around every launch of one extra (untimed) step
+        eng.set_profiling(True)
+        step()
+        recs = []
+        for name in names:
+            recs += models[name].last_profile()
+        eng.set_profiling(False)
+        c3 = [r for r in recs if r["kind"] == 2 and r["ksize"] == 3]
+        c1 = [r for r in recs if r["kind"] == 2 and r["ksize"] == 1]
+        ms3, fl3 = sum(r["ms"] for r in c3), sum(r["flops"] for r in c3)
+        ms1, fl1 = sum(r["ms"] for r in c1), sum(r["flops"] for r in c1)
+        ms_all = sum(r["ms"] for r in recs)
+        ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "conv_igemm_kernel<*,*,3> (3x3 conv+BN+SiLU implicit GEMM, v_mfma_f32_16x16x4_f32)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches": len(c3), "avg_launch_ms": round(ms3 / max(len(c3), 1), 4),
+            "flops_per_step": fl3, "kernel_ms_per_step": round(ms3, 3),
+            "conv1x1": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0, "ms_per_step": round(ms1, 3)},
+            "all_kernels_ms_per_step": round(ms_all, 3),
+            "other_ms_per_step": {str(k): round(sum(r["ms"] for r in recs if r["kind"] == k), 3)
+                                  for k in sorted({r["kind"] for r in recs}) if k != 2},
+        }
+
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        # ---- CPU baseline: the oracle (a restatement, kind "port") on this box's host cores, bounded sample
+        from oracle import yolov8_ref as ref
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        ns = a.cpu_sample or 4
+        sample = frames[:ns]
+        tcpu = 0.0
+        for name in names:
+            cfg = TRACKERS[name]
+            sd = make_state_dict(name, cfg, frames)       # same weights as the GPU run (deterministic)
+            model = ref.YoloV8Ref(sd, cfg["nc"], cfg["kpt"])
+            ref.predict(model, source_for_oracle(cfg, sample[:1]), cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])  # warm
+            t1 = time.perf_counter()
+            # host-side processor (BGR2RGB / PIL resize) + predict, like predict_sample() times it
+            ref.predict(model, source_for_oracle(cfg, sample), cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
+            tcpu += time.perf_counter() - t1
+        out["cpu_baseline"] = {"value": round(ns / tcpu, 3), "unit": "frames/s", "cores": ncores, "kind": "port",
+                               "sample": f"{ns} frames of the same workload through the torch-CPU fp32 oracle "
+                                         f"(oracle/yolov8_ref.py), all {len(names)} trackers, torch threads={ncores}"}
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    for m in models.values():
+        m.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -56,8 +56,11 @@ def fuse_conv_bn(sd, prefix):
 class YoloV8Ref:
     """Fused-BN YOLOv8 detect/pose forward on CPU fp32 (Conv = conv + BN + SiLU)."""
 
-    def __init__(self, state_dict, nc: int, kpt_shape: Optional[tuple] = None):
+    def __init__(self, state_dict, nc: int, kpt_shape: Optional[tuple] = None, dtype=torch.float32):
+        """dtype=torch.float64 evaluates the SAME fp32-folded weights in double precision: the
+        rounding-free value every fp32 implementation (this oracle included) approximates."""
         self.sd = state_dict
+        self.dtype = dtype
         self.nc = nc
         self.kpt_shape = tuple(kpt_shape) if kpt_shape else None
         self._fused = {}
@@ -70,7 +73,8 @@ class YoloV8Ref:
 
     def _conv(self, x, prefix, k, s):
         if prefix not in self._fused:
-            self._fused[prefix] = fuse_conv_bn(self.sd, prefix)
+            w, b = fuse_conv_bn(self.sd, prefix)
+            self._fused[prefix] = (w.to(self.dtype), b.to(self.dtype))
         w, b = self._fused[prefix]
         return F.silu(F.conv2d(x, w, b, stride=s, padding=k // 2))
 
@@ -113,7 +117,8 @@ class YoloV8Ref:
         p = f"model.22.{br}.{l}"
         x = self._conv(x, f"{p}.0", 3, 1)
         x = self._conv(x, f"{p}.1", 3, 1)
-        return F.conv2d(x, _t(self.sd, f"{p}.2.weight").float(), _t(self.sd, f"{p}.2.bias").float())
+        return F.conv2d(x, _t(self.sd, f"{p}.2.weight").float().to(self.dtype),
+                        _t(self.sd, f"{p}.2.bias").float().to(self.dtype))
 
     def head_raw(self, feats):
         """Per level raw head maps: (B, 64+nc, H, W) and, for pose, (B, nk, H, W)."""
@@ -127,13 +132,14 @@ class YoloV8Ref:
     @staticmethod
     def make_anchors(feats, strides=(8, 16, 32), offset=0.5):
         pts, st = [], []
+        dt = feats[0].dtype
         for f, s in zip(feats, strides):
             h, w = f.shape[2:]
-            sx = torch.arange(w, dtype=torch.float32) + offset
-            sy = torch.arange(h, dtype=torch.float32) + offset
+            sx = torch.arange(w, dtype=dt) + offset
+            sy = torch.arange(h, dtype=dt) + offset
             sy, sx = torch.meshgrid(sy, sx, indexing="ij")
             pts.append(torch.stack((sx, sy), -1).view(-1, 2))
-            st.append(torch.full((h * w, 1), float(s), dtype=torch.float32))
+            st.append(torch.full((h * w, 1), float(s), dtype=dt))
         return torch.cat(pts).transpose(0, 1), torch.cat(st).transpose(0, 1)   # (2,A), (1,A)
 
     def decode(self, det, kpt):
@@ -145,7 +151,7 @@ class YoloV8Ref:
         box, cls = x_cat.split((4 * REG_MAX, self.nc), 1)
         a = box.shape[-1]
         prob = box.view(bs, 4, REG_MAX, a).transpose(2, 1).softmax(1)           # (B,16,4,A)
-        proj = torch.arange(REG_MAX, dtype=torch.float32).view(1, REG_MAX, 1, 1)
+        proj = torch.arange(REG_MAX, dtype=box.dtype).view(1, REG_MAX, 1, 1)
         dist = (prob * proj).sum(1)                                              # (B,4,A)
         lt, rb = dist.chunk(2, 1)
         x1y1 = anchors.unsqueeze(0) - lt
@@ -165,7 +171,7 @@ class YoloV8Ref:
 
     @torch.no_grad()
     def forward(self, x):
-        det, kpt = self.head_raw(self.features(x))
+        det, kpt = self.head_raw(self.features(x.to(self.dtype)))
         return self.decode(det, kpt)
 
 
@@ -255,12 +261,14 @@ def preprocess(sources: Sequence[np.ndarray], imgsz: int) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- post-processing
 
-def nms_torchvision(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> torch.Tensor:
-    """torchvision.ops.nms CPU kernel: stable descending sort, suppress when IoU > thr."""
+def nms_torchvision(boxes: torch.Tensor, scores: torch.Tensor, thr: float, flip=None) -> torch.Tensor:
+    """torchvision.ops.nms CPU kernel: stable descending sort, suppress when IoU > thr.
+    ``flip``: optional set of (i, j) candidate-index pairs whose suppress decision is inverted (used by
+    the parity harness to prove that a count mismatch is a threshold-adjacent IoU decision)."""
     n = boxes.shape[0]
     if n == 0:
         return torch.empty((0,), dtype=torch.int64)
-    b = boxes.numpy().astype(np.float32)
+    b = boxes.numpy()
     x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
     areas = (x2 - x1) * (y2 - y1)
     order = torch.sort(scores, stable=True, descending=True)[1].numpy()
@@ -276,18 +284,24 @@ def nms_torchvision(boxes: torch.Tensor, scores: torch.Tensor, thr: float) -> to
         yy1 = np.maximum(y1[i], y1[rest])
         xx2 = np.minimum(x2[i], x2[rest])
         yy2 = np.minimum(y2[i], y2[rest])
-        w = np.maximum(np.float32(0), xx2 - xx1)
-        h = np.maximum(np.float32(0), yy2 - yy1)
+        w = np.maximum(b.dtype.type(0), xx2 - xx1)
+        h = np.maximum(b.dtype.type(0), yy2 - yy1)
         inter = w * h
         with np.errstate(divide="ignore", invalid="ignore"):
             ovr = inter / (areas[i] + areas[rest] - inter)
-        suppressed[rest[ovr > np.float32(thr)]] = True
+        sup = ovr > b.dtype.type(thr)
+        if flip:
+            for (fi, fj) in flip:
+                if fi == i:
+                    sup[rest == fj] = ~sup[rest == fj]
+        suppressed[rest[sup]] = True
     return torch.as_tensor(np.asarray(keep, dtype=np.int64))
 
 
 def non_max_suppression(prediction: torch.Tensor, conf_thres: float, iou_thres: float,
-                        classes=None, max_det: int = 300, nc: int = 0):
-    """ultralytics.utils.ops.non_max_suppression (multi_label=False, agnostic=False, no time limit)."""
+                        classes=None, max_det: int = 300, nc: int = 0, return_candidates: bool = False):
+    """ultralytics.utils.ops.non_max_suppression (multi_label=False, agnostic=False, no time limit).
+    With ``return_candidates`` also returns, per image, the pre-NMS candidate rows."""
     bs = prediction.shape[0]
     nc = nc or (prediction.shape[1] - 4)
     nm = prediction.shape[1] - nc - 4
@@ -297,15 +311,16 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float, iou_thres: 
     xy, wh = prediction[..., :2].clone(), prediction[..., 2:4] / 2
     prediction[..., :2] = xy - wh
     prediction[..., 2:4] = xy + wh
-    cls_t = None if classes is None else torch.tensor(classes, dtype=torch.float32)
-    out = [torch.zeros((0, 6 + nm))] * bs
+    cls_t = None if classes is None else torch.tensor(classes, dtype=prediction.dtype)
+    out = [torch.zeros((0, 6 + nm), dtype=prediction.dtype)] * bs
+    cands = [torch.zeros((0, 6 + nm), dtype=prediction.dtype)] * bs
     for xi, x in enumerate(prediction):
         x = x[xc[xi]]
         if not x.shape[0]:
             continue
         box, cls, mask = x.split((4, nc, nm), 1)
         conf, j = cls.max(1, keepdim=True)
-        x = torch.cat((box, conf, j.float(), mask), 1)[conf.view(-1) > conf_thres]
+        x = torch.cat((box, conf, j.to(box.dtype), mask), 1)[conf.view(-1) > conf_thres]
         if cls_t is not None:
             x = x[(x[:, 5:6] == cls_t).any(1)]
         n = x.shape[0]
@@ -316,7 +331,8 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float, iou_thres: 
         c = x[:, 5:6] * MAX_WH
         i = nms_torchvision(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]
         out[xi] = x[i]
-    return out
+        cands[xi] = x
+    return (out, cands) if return_candidates else out
 
 
 def scale_boxes(net_hw, boxes: torch.Tensor, orig_hw) -> torch.Tensor:
@@ -368,7 +384,7 @@ def predict(model: YoloV8Ref, sources: Sequence[np.ndarray], conf: float, iou: f
     the parity harness to detect threshold-adjacent decisions."""
     im = preprocess(sources, imgsz)
     pred = model.forward(im)
-    dets = non_max_suppression(pred, conf, iou, classes, max_det, nc=model.nc)
+    dets, cands = non_max_suppression(pred, conf, iou, classes, max_det, nc=model.nc, return_candidates=True)
     res = []
     for i, d in enumerate(dets):
         h0, w0 = sources[i].shape[:2]
@@ -380,5 +396,6 @@ def predict(model: YoloV8Ref, sources: Sequence[np.ndarray], conf: float, iou: f
             k = scale_coords(im.shape[2:], k, (h0, w0))
         sc = pred[i, 4:4 + model.nc].amax(0)
         res.append({"boxes": d[:, :6].numpy(), "kpts": None if k is None else k.numpy(),
-                    "conf_margin": float((sc - conf).abs().min())})
+                    "conf_margin": float((sc - conf).abs().min()), "cands": cands[i].numpy(),
+                    "net_hw": tuple(im.shape[2:]), "orig_hw": (h0, w0)})
     return res
