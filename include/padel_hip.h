@@ -133,6 +133,8 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
  * engine's stream.  kinds/ms/flops are host arrays of capacity cap; returns the number of records. */
 int pa_engine_set_profiling(pa_engine* eng, int enable);
 int pa_model_last_profile(pa_model* m, int cap, int32_t* kinds, float* ms, double* flops, int32_t* ksizes);
+/* same records as CSV text: kind,ksize,M,cout,cin,stride,mf,nf,ms,flops per line; returns bytes written */
+int pa_model_profile_text(pa_model* m, char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

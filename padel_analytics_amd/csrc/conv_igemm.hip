@@ -88,11 +88,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NF; ++j) wrow[j] = (long long)min(nt * NF + j, a.n16 - 1) * 16 * Ktot;
 
-    f32x4 acc[MF][NF];
+    // two-level (blocked) accumulation: `part` collects one block of FLUSH k-steps (a 32-channel
+    // chunk x all taps for 3x3), then is added into `acc`.  Rounding error of a length-K fp32 sum grows
+    // like sqrt(K); blocking makes it sqrt(K/b) + sqrt(b), which keeps the long reductions of the
+    // m-scale graphs (K up to 5184) closer to the exact result than a plain sequential chain.
+    f32x4 acc[MF][NF], part[MF][NF];
 #pragma unroll
     for (int f = 0; f < MF; ++f)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     // position of k-step `ks` in the (c32 chunk, tap, c16 half) order: pure function of the
     // wave-uniform loop counter (KS is a template constant, so the divisions are SALU mul-shifts)
@@ -130,7 +134,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
             for (int f = 0; f < MF; ++f)
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
-                    acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[f][kk], B[j][kk], acc[f][j], 0, 0, 0);
+                    part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[f][kk], B[j][kk], part[f][j], 0, 0, 0);
     };
 
     // software pipeline: set 0 holds step ks, set 1 is being fetched.  The main loop has no
@@ -141,6 +145,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     // cover); pinned, every load has a full k-step (>= MF*NF*128 cycles) to land.
     load(0, A0, B0);
     int ks = 0;
+    constexpr int FLUSH = (KS == 3) ? TAPS * 2 : 16;      // k-steps per accumulation block (even)
+    int blk = 0;
     for (; ks + 2 < nks; ks += 2) {
         load(ks + 1, A1, B1);
         __builtin_amdgcn_sched_barrier(0);
@@ -150,6 +156,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         compute(A1, B1);
         __builtin_amdgcn_sched_barrier(0);
+        blk += 2;
+        if (blk == FLUSH) {
+            blk = 0;
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
     }
     if (ks + 1 < nks) {
         load(ks + 1, A1, B1);
@@ -159,6 +173,10 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     } else {
         compute(A0, B0);
     }
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];
 
     // epilogue: lane holds D[row = lq*4 + r][col = lr] of each 16x16 fragment
     const int act = a.act;
@@ -210,8 +228,10 @@ void choose_conv_tile(int M, int n16, int* mf_out, int* nf_out) {
         if (waste < best_waste || (waste == best_waste && nf > best_nf)) { best_waste = waste; best_nf = nf; }
     }
     const int ntiles = (n16 + best_nf - 1) / best_nf;
+    // at most 8 fragments per wave: with the two-level accumulators that is <= ~165 registers,
+    // i.e. 3 waves per SIMD to cover each other's load phases
     int mf = 4;
-    if (best_nf > 4) mf = 2;
+    while (mf > 1 && mf * best_nf > 8) mf >>= 1;
     // keep >= 2 workgroups per CU in flight (256 CUs) when the problem allows it
     while (mf > 1 && (long long)((M + 64 * mf - 1) / (64 * mf)) * ntiles < 512) mf >>= 1;
     *mf_out = mf;

@@ -37,7 +37,7 @@ struct pa_engine {
         if (_e != hipSuccess) PA_FAIL(eng, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
-struct ProfRec { int kind; int ksize; double flops; hipEvent_t e0, e1; float ms; };
+struct ProfRec { int kind; int ksize; double flops; hipEvent_t e0, e1; float ms; int M, cout, cin, stride, mf, nf; };
 
 struct pa_model {
     pa_engine* e = nullptr;
@@ -399,6 +399,7 @@ static ProfRec* prof_begin(pa_model* m, size_t idx, int kind, int ksize, double 
     }
     ProfRec* r = &m->prof[idx];
     r->kind = kind; r->ksize = ksize; r->flops = flops; r->ms = 0.f;
+    r->M = r->cout = r->cin = r->stride = r->mf = r->nf = 0;
     hipEventRecord(r->e0, m->e->stream);
     return r;
 }
@@ -429,6 +430,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             int mf, nf;
             choose_conv_tile(a.M, a.n16, &mf, &nf);
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
+            if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = mf; pr->nf = nf; }
             r = launch_conv_igemm(a, mf, nf, s);
         } else if (o.kind == PA_OP_STEM) {
             StemArgs a{};
@@ -623,6 +625,19 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
     }
     finish_profile(m, pi);
     return 0;
+}
+
+int pa_model_profile_text(pa_model* m, char* buf, size_t cap) {
+    size_t off = 0;
+    for (size_t i = 0; i < m->n_prof && i < m->prof.size(); ++i) {
+        const ProfRec& r = m->prof[i];
+        int n = snprintf(buf + off, off < cap ? cap - off : 0, "%d,%d,%d,%d,%d,%d,%d,%d,%.5f,%.0f\n", r.kind, r.ksize, r.M, r.cout,
+                         r.cin, r.stride, r.mf, r.nf, r.ms, r.flops);
+        if (n < 0 || off + n >= cap) break;
+        off += n;
+    }
+    if (off < cap) buf[off] = 0;
+    return (int)off;
 }
 
 int pa_model_last_profile(pa_model* m, int cap, int32_t* kinds, float* ms, double* flops, int32_t* ksizes) {

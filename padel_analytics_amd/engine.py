@@ -61,6 +61,7 @@ ABI_SYMBOLS = [
     "pa_engine_synchronize", "pa_device_malloc", "pa_device_free", "pa_memcpy_h2d", "pa_memcpy_d2h",
     "pa_model_create", "pa_model_destroy", "pa_model_set_max_batch", "pa_yolo_infer", "pa_yolo_head_shape",
     "pa_yolo_read_head", "pa_tracknet_infer", "pa_engine_set_profiling", "pa_model_last_profile",
+    "pa_model_profile_text",
 ]
 
 
@@ -102,6 +103,7 @@ def load_library():
     lib.pa_tracknet_infer.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32]
     lib.pa_engine_set_profiling.argtypes = [vp, i32]
     lib.pa_model_last_profile.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.pa_model_profile_text.argtypes = [vp, C.c_char_p, sz]
     if lib.pa_abi_version() != 1:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
@@ -261,6 +263,17 @@ class Model:
         n = self.engine.lib.pa_model_last_profile(self.handle, cap, kinds.ctypes.data, ms.ctypes.data, fl.ctypes.data,
                                                   ks.ctypes.data)
         return [dict(kind=int(kinds[i]), ms=float(ms[i]), flops=float(fl[i]), ksize=int(ks[i])) for i in range(n)]
+
+    def profile_rows(self):
+        """Per-op records of the last profiled inference: dicts with shape, tile and milliseconds."""
+        buf = C.create_string_buffer(1 << 20)
+        self.engine.lib.pa_model_profile_text(self.handle, buf, len(buf))
+        rows = []
+        for line in buf.value.decode().splitlines():
+            k, ks, M, co, ci, st, mf, nf, ms, fl = line.split(",")
+            rows.append(dict(kind=int(k), ksize=int(ks), M=int(M), cout=int(co), cin=int(ci), stride=int(st),
+                             mf=int(mf), nf=int(nf), ms=float(ms), flops=float(fl)))
+        return rows
 
     def close(self):
         if self.handle:
