@@ -125,7 +125,8 @@ int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const
 int pa_yolo_head_shape(pa_model* m, int level, int* h, int* w, int* c);
 int pa_yolo_read_head(pa_model* m, int level, int n, float* out);
 
-/* TrackNet forward: x = n x H x W x C_in fp32 NHWC (C_in padded as in the model desc) -> n x H x W x 8 */
+/* generic graph forward (TrackNet): x = n x H x W x C_in fp32 NHWC (C_in = channels of buffer 0) ->
+ * contents of buffer head_buf[0]: n x (H>>level) x (W>>level) x channels fp32 */
 int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on_device, float* out,
                       int out_on_device);
 

@@ -27,6 +27,7 @@
 //  * blockIdx -> pixel-tile map is XCD-aware (each XCD walks a contiguous range of tiles so the
 //    halo rows shared by neighbouring tiles stay in that XCD's L2).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace padel {
 
@@ -215,27 +216,35 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, int mf, int nf, hipStream_t s
 #define PADEL_CASE(MFv, NFv) if (mf == MFv && nf == NFv) return launch_t<MFv, NFv>(a, s);
     PADEL_CASE(1, 1) PADEL_CASE(1, 2) PADEL_CASE(1, 3) PADEL_CASE(1, 4) PADEL_CASE(1, 5) PADEL_CASE(1, 6)
     PADEL_CASE(2, 1) PADEL_CASE(2, 2) PADEL_CASE(2, 3) PADEL_CASE(2, 4) PADEL_CASE(2, 5) PADEL_CASE(2, 6)
-    PADEL_CASE(4, 1) PADEL_CASE(4, 2) PADEL_CASE(4, 3) PADEL_CASE(4, 4)
+    PADEL_CASE(4, 1) PADEL_CASE(4, 2) PADEL_CASE(4, 3) PADEL_CASE(4, 4) PADEL_CASE(4, 5) PADEL_CASE(4, 6)
 #undef PADEL_CASE
     return hipErrorInvalidValue;
 }
 
 void choose_conv_tile(int M, int n16, int* mf_out, int* nf_out) {
-    // NF: least zero-padding of the channel dimension, then the widest tile
-    int best_nf = 1, best_waste = 1 << 30;
-    for (int nf = 1; nf <= 6; ++nf) {
-        const int waste = ((n16 + nf - 1) / nf) * nf - n16;
-        if (waste < best_waste || (waste == best_waste && nf > best_nf)) { best_waste = waste; best_nf = nf; }
+    // tuning override (tools/conv_bench.py): PADEL_CONV_MF / PADEL_CONV_NF
+    static const int env_mf = getenv("PADEL_CONV_MF") ? atoi(getenv("PADEL_CONV_MF")) : 0;
+    static const int env_nf = getenv("PADEL_CONV_NF") ? atoi(getenv("PADEL_CONV_NF")) : 0;
+    if (env_mf > 0 && env_nf > 0) { *mf_out = env_mf; *nf_out = env_nf; return; }
+    // measured on MI355X (tools/conv_bench.py, profiles/conv_tile_sweep_r1.txt): throughput rises with
+    // fragments per wave (fewer operand loads per MFMA) even at 1-2 waves/SIMD, so score each legal
+    // tile by (relative speed of the shape) x (fraction of the channel tiles that is not padding)
+    static const struct { int mf, nf; float speed; } cand[] = {
+        {4, 4, 1.00f}, {4, 3, 0.97f}, {2, 6, 0.95f}, {4, 2, 0.88f}, {2, 4, 0.86f}, {2, 5, 0.86f}, {2, 3, 0.82f},
+        {4, 1, 0.72f}, {2, 2, 0.74f}, {1, 6, 0.70f}, {1, 4, 0.62f}, {2, 1, 0.50f}, {1, 3, 0.50f}, {1, 2, 0.40f}, {1, 1, 0.30f}};
+    float best = -1.f;
+    int bm = 1, bn = 1;
+    for (const auto& t : cand) {
+        const int ntiles = (n16 + t.nf - 1) / t.nf;
+        const float fill = (float)n16 / (float)(ntiles * t.nf);
+        // keep >= 2 workgroups per CU in flight when the problem allows it (256 CUs)
+        const long long blocks = (long long)((M + 64 * t.mf - 1) / (64 * t.mf)) * ntiles;
+        const float occ = blocks >= 512 ? 1.f : (blocks >= 256 ? 0.9f : (float)blocks / 256.f * 0.8f);
+        const float sc = t.speed * fill * occ;
+        if (sc > best) { best = sc; bm = t.mf; bn = t.nf; }
     }
-    const int ntiles = (n16 + best_nf - 1) / best_nf;
-    // at most 8 fragments per wave: with the two-level accumulators that is <= ~165 registers,
-    // i.e. 3 waves per SIMD to cover each other's load phases
-    int mf = 4;
-    while (mf > 1 && mf * best_nf > 8) mf >>= 1;
-    // keep >= 2 workgroups per CU in flight (256 CUs) when the problem allows it
-    while (mf > 1 && (long long)((M + 64 * mf - 1) / (64 * mf)) * ntiles < 512) mf >>= 1;
-    *mf_out = mf;
-    *nf_out = best_nf;
+    *mf_out = bm;
+    *nf_out = bn;
 }
 
 }  // namespace padel

@@ -307,7 +307,10 @@ static hipError_t upload(pa_engine* e, int32_t** dptr, const std::vector<int32_t
 
 static int plan_buffers(pa_model* m, int batch) {
     pa_engine* e = m->e;
-    if ((m->net_h & 31) || (m->net_w & 31)) PA_FAIL(e, "network input %dx%d is not a multiple of 32", m->net_h, m->net_w);
+    int maxl = 0;
+    for (const auto& b : m->bufs) maxl = std::max(maxl, b.level);
+    const int mask = (1 << maxl) - 1;
+    if ((m->net_h & mask) || (m->net_w & mask)) PA_FAIL(e, "network input %dx%d is not a multiple of %d", m->net_h, m->net_w, mask + 1);
     m->bptr.assign(m->bufs.size(), nullptr);
     for (size_t i = 0; i < m->bufs.size(); ++i) {
         const size_t H = m->net_h >> m->bufs[i].level, W = m->net_w >> m->bufs[i].level;
@@ -618,8 +621,9 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
         PA_HIP(e, hipMemcpyAsync(m->bptr[0], x + (size_t)c0 * h * w * cin, in_bytes,
                                  x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
         if (run_ops(m, nb, &pi)) return 1;
-        const size_t out_bytes = (size_t)nb * h * w * cout * sizeof(float);
-        PA_HIP(e, hipMemcpyAsync(out + (size_t)c0 * h * w * cout, m->bptr[ob], out_bytes,
+        const size_t ohw = (size_t)(h >> m->bufs[ob].level) * (w >> m->bufs[ob].level);
+        const size_t out_bytes = (size_t)nb * ohw * cout * sizeof(float);
+        PA_HIP(e, hipMemcpyAsync(out + (size_t)c0 * ohw * cout, m->bptr[ob], out_bytes,
                                  out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
         PA_HIP(e, hipStreamSynchronize(s));
     }

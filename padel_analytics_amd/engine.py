@@ -250,8 +250,8 @@ class Model:
         x = np.ascontiguousarray(x, np.float32)
         n, h, w, c = x.shape
         assert c == self.graph.bufs[0][1], (c, self.graph.bufs[0])
-        cout = self.graph.bufs[self.graph.head_buf[0]][1]
-        out = np.empty((n, h, w, cout), np.float32)
+        lvl, cout = self.graph.bufs[self.graph.head_buf[0]]
+        out = np.empty((n, h >> lvl, w >> lvl, cout), np.float32)
         self.engine._check(self.engine.lib.pa_tracknet_infer(self.handle, x.ctypes.data, n, h, w, 0, out.ctypes.data, 0))
         return out
 

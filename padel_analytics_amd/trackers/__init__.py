@@ -1,0 +1,5 @@
+"""Drop-in replacements for the reference's ``trackers`` package exports (``trackers/__init__.py:1-7``)."""
+from .tracker import NoPredictFrames, NoPredictSample, Object, Tracker, TrackingResults
+from .players_tracker import Player, Players, PlayerTracker
+from .players_keypoints_tracker import PlayerKeypoint, PlayerKeypoints, PlayersKeypoints, PlayerKeypointsTracker
+from .runner import TrackingRunner

@@ -1,0 +1,139 @@
+"""Players keypoints tracker — drop-in for the reference's
+``trackers/players_keypoints_tracker/players_keypoints_tracker.py`` (``PlayerKeypoint`` :14-42,
+``PlayerKeypoints`` :59-135, ``PlayersKeypoints`` :165-197, ``PlayerKeypointsTracker`` :207-325).
+
+Hot path (``predict_sample`` :271-322): BGR frame -> RGB -> Pillow bicubic stretch to SxS (S in {640,1280})
+-> YOLOv8-pose (conf .25, iou .7, ``classes=[0]``) -> ``keypoints.xy`` scaled back by (w/S, h/S).  The
+resize, the network, NMS and the keypoint decode all run on the GPU (``pil_stretch=True``).
+
+Divergence from the reference, on purpose: the reference's
+``xy.squeeze(0)`` logic (:299-301) raises for exactly 1 or 2 detections; here every n yields n x 13 keypoints.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from pathlib import Path
+from typing import Iterable, Optional, Type
+
+import numpy as np
+
+from ..yolo import YOLO
+from .tracker import NoPredictFrames, Object, Tracker
+
+
+@dataclass
+class PlayerKeypoint:
+    id: int
+    name: str
+    xy: tuple
+
+    def asint(self) -> tuple: return tuple(int(v) for v in self.xy)
+
+    @classmethod
+    def from_json(cls, x: dict): return cls(**x)
+
+    def serialize(self) -> dict: return {"id": self.id, "name": self.name, "xy": self.xy}
+
+
+class PlayerKeypoints:
+    KEYPOINTS_NAMES = ["left_foot", "right_foot", "torso", "right_shoulder", "left_shoulder", "head", "neck",
+                       "left_hand", "right_hand", "right_knee", "left_knee", "right_elbow", "left_elbow"]
+    CONNECTIONS = [("left_foot", "left_knee"), ("left_knee", "torso"), ("right_foot", "right_knee"),
+                   ("right_knee", "torso"), ("torso", "left_shoulder"), ("torso", "right_shoulder"),
+                   ("left_hand", "left_elbow"), ("left_elbow", "left_shoulder"), ("left_shoulder", "neck"),
+                   ("neck", "head"), ("right_hand", "right_elbow"), ("right_elbow", "right_shoulder"),
+                   ("right_shoulder", "neck")]
+
+    def __init__(self, player_keypoints: list):
+        self.player_keypoints = player_keypoints
+        self.keypoints_by_name = {k.name: k for k in player_keypoints}
+
+    @classmethod
+    def from_json(cls, x: dict):
+        return cls([PlayerKeypoint.from_json(k) for k in x["player_keypoints"]])
+
+    def serialize(self) -> dict:
+        return {"player_keypoints": [k.serialize() for k in self.player_keypoints]}
+
+    def __len__(self) -> int: return len(self.player_keypoints)
+
+    def __iter__(self): return iter(self.player_keypoints)
+
+    def __getitem__(self, name: str) -> PlayerKeypoint:
+        assert name in self.KEYPOINTS_NAMES
+        return self.keypoints_by_name[name]
+
+    def draw(self, frame: np.ndarray) -> np.ndarray: return frame
+
+
+class PlayersKeypoints(Object):
+    def __init__(self, players_keypoints: list) -> None:
+        super().__init__()
+        self.players_keypoints = players_keypoints
+
+    @classmethod
+    def from_json(cls, x) -> "PlayersKeypoints":
+        return cls([PlayerKeypoints.from_json(p) for p in x])
+
+    def serialize(self) -> list:
+        return [p.serialize() for p in self.players_keypoints]
+
+    def __len__(self) -> int: return len(self.players_keypoints)
+
+    def __iter__(self): return iter(self.players_keypoints)
+
+    def __getitem__(self, i: int) -> PlayerKeypoints: return self.players_keypoints[i]
+
+
+class PlayerKeypointsTracker(Tracker):
+    CONF = 0.25
+    IOU = 0.7
+
+    def __init__(self, model_path: str, train_image_size: int, batch_size: int,
+                 load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None):
+        super().__init__(load_path=load_path, save_path=save_path)
+        self.model = YOLO(model_path)
+        assert train_image_size in (640, 1280)
+        self.train_image_size = train_image_size
+        self.batch_size = batch_size
+
+    def video_info_post_init(self, video_info) -> "PlayerKeypointsTracker": return self
+
+    def object(self) -> Type[Object]: return PlayersKeypoints
+
+    def draw_kwargs(self) -> dict: return {}
+
+    def __str__(self) -> str: return "players_keypoints_tracker"
+
+    def restart(self) -> None: self.results.restart()
+
+    def processor(self, frame: np.ndarray):
+        """BGR2RGB + ``Image.resize((S, S))`` (Pillow default bicubic), reference :260-266; API parity only —
+        the hot path does this on the device."""
+        from PIL import Image
+        return Image.fromarray(np.ascontiguousarray(frame[..., ::-1])).resize((self.train_image_size,) * 2)
+
+    def to(self, device: str) -> None:
+        self.model.to(device)
+
+    def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> list:
+        sample = list(sample)
+        h_frame, w_frame = sample[0].shape[:2]
+        ratio_x = w_frame / self.train_image_size
+        ratio_y = h_frame / self.train_image_size
+        results = self.model.predict_frames(sample, self.CONF, self.IOU, self.train_image_size, classes=[0],
+                                            channel_reverse=True, pil_stretch=True)
+        names = PlayerKeypoints.KEYPOINTS_NAMES
+        predictions = []
+        for result in results:
+            players = []
+            for person in result.keypoints.xy:                 # (K, 2)
+                players.append(PlayerKeypoints([
+                    PlayerKeypoint(id=i, name=names[i] if i < len(names) else str(i),
+                                   xy=(float(kp[0]) * ratio_x, float(kp[1]) * ratio_y))
+                    for i, kp in enumerate(person)]))
+            predictions.append(PlayersKeypoints(players))
+        return predictions
+
+    def predict_frames(self, frame_generator, **kwargs):
+        raise NoPredictFrames()

@@ -1,0 +1,161 @@
+"""Tracker plugin API — the outer drop-in boundary.
+
+Mirrors the abstractions of the reference's ``trackers/tracker.py`` (``Object`` :30-63,
+``TrackingResults`` :66-119, ``Tracker`` :122-330) with the same names, signatures, printed messages
+and error conventions, so ``TrackingRunner`` and user code keep working unchanged:
+
+* a tracker that works on batches raises ``NoPredictFrames`` from ``predict_frames`` and is fed lists of
+  ``batch_size`` frames (last one short) by ``predict_and_update`` (reference :290-326);
+* a tracker that works on the whole stream raises ``NoPredictSample`` from ``predict_sample``;
+* predictions are cached as JSON through ``save_predictions`` / ``load_predictions`` (:200-241).
+
+Written from scratch; host logic only (the numeric engines live behind ``padel_analytics_amd.engine``).
+"""
+from __future__ import annotations
+
+import json
+from abc import ABC, abstractmethod
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Iterable, Iterator, Optional, Type
+
+import numpy as np
+
+
+class NoPredictSample(Exception):
+    """The tracker predicts from the frame generator, not from samples (reference tracker.py:15-20)."""
+
+
+class NoPredictFrames(Exception):
+    """The tracker predicts from samples, not from a frame generator (reference tracker.py:22-27)."""
+
+
+class Object(ABC):
+    """One frame's worth of tracked objects (players, keypoints, ball)."""
+
+    @classmethod
+    def from_json(cls, x):
+        raise NotImplementedError
+
+    def serialize(self):
+        raise NotImplementedError
+
+    def draw(self, frame: np.ndarray, **kwargs) -> np.ndarray:
+        """Annotation is outside the hot path (OUT OF SCOPE); frames pass through."""
+        return frame
+
+
+@dataclass
+class TrackingResults:
+    predictions: list = field(default_factory=list)
+    sample_predictions: list = field(default_factory=list)
+    counter: int = 0
+
+    def load(self, predictions: list) -> None:
+        self.predictions = predictions
+        self.sample_predictions = []
+        self.counter = 0
+
+    def update(self, predictions: list) -> None:
+        self.predictions += predictions
+        self.sample_predictions = predictions
+        self.counter += 1
+
+    def restart(self) -> None:
+        self.predictions = []
+        self.sample_predictions = []
+        self.counter = 0
+
+    def __len__(self) -> int:
+        return len(self.predictions)
+
+    def __getitem__(self, i: int):
+        return self.predictions[i]
+
+    def __iter__(self) -> Iterator:
+        return iter(self.predictions)
+
+
+def _sampler(generator: Iterable[np.ndarray], sequence_length: int) -> Iterator[list]:
+    """Chop a frame stream into lists of ``sequence_length`` frames; the last one may be short."""
+    w: list = []
+    for x in generator:
+        w.append(x)
+        if len(w) == sequence_length:
+            yield w
+            w = []
+    if w:
+        yield w
+
+
+class Tracker(ABC):
+    batch_size: int
+
+    def __init__(self, load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None) -> None:
+        self.results = TrackingResults()
+        self.load_path = load_path
+        self.save_path = save_path
+        self.load_predictions()
+
+    @abstractmethod
+    def video_info_post_init(self, video_info) -> "Tracker": ...
+
+    @abstractmethod
+    def object(self) -> Type[Object]: ...
+
+    @abstractmethod
+    def draw_kwargs(self) -> dict: ...
+
+    @property
+    def DEVICE(self) -> str:
+        """"cuda" when the HIP engine sees a GPU (ROCm devices are "cuda" to callers), else "cpu".
+        There is no CPU execution path: on "cpu" the numeric calls raise EngineUnavailable."""
+        from .. import engine
+        try:
+            return "cuda" if engine.load_library().pa_device_count() > 0 else "cpu"
+        except engine.EngineUnavailable:
+            return "cpu"
+
+    @abstractmethod
+    def restart(self) -> None: ...
+
+    def __len__(self) -> int:
+        return len(self.results)
+
+    @abstractmethod
+    def __str__(self) -> str: ...
+
+    def save_predictions(self) -> None:
+        if self.save_path:
+            print(f"{self.__str__()}: Saving predictions ...")
+            parsable = [obj.serialize() for obj in self.results.predictions]
+            with open(self.save_path, "w") as f:
+                json.dump(parsable, f)
+            print(f"{self.__str__()}: {self.__len__()} predictions saved.")
+
+    def load_predictions(self) -> None:
+        if self.load_path:
+            print(f"{self.__str__()}: Loading predictions ...")
+            with open(self.load_path, "r") as f:
+                parsable = json.load(f)
+            self.results.load([self.object().from_json(o) for o in parsable])
+        print(f"{self.__str__()}: {self.__len__()} predictions loaded.")
+
+    def to(self, device: str) -> None:
+        """Move the tracker's model(s) to ``device`` (weights go to HBM on "cuda")."""
+
+    @abstractmethod
+    def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> Optional[list]: ...
+
+    @abstractmethod
+    def predict_frames(self, frame_generator: Iterable[np.ndarray], **kwargs) -> Optional[list]: ...
+
+    def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:
+        try:
+            predictions = self.predict_frames(frame_generator, **kwargs)
+            self.results.predictions = predictions
+        except NoPredictFrames:
+            for sample in _sampler(frame_generator, self.batch_size):
+                self.results.update(self.predict_sample(sample, **kwargs))
+        print(f"{self.__str__()}: {len(self.results)} predictions.")
+        return self.results
