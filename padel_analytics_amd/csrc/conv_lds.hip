@@ -1,0 +1,288 @@
+// K3/K4 v2 — LDS-staged implicit-GEMM conv on v_mfma_f32_16x16x4_f32 (gfx950).
+//
+// Same math, operands, K order and two-level accumulation as conv_igemm.hip (so results are
+// bit-identical between the two kernels); what changes is how operands reach the matrix pipe.
+// The register-direct kernel issues one 16-byte global load per fragment per wave and tops out at
+// ~80-90 TFLOP/s because every wave re-fetches the weight tile and its pixels from L1/L2.  Here a
+// workgroup of 4 waves (WM x WN) shares a BM x BN output tile:
+//
+//   * per k-step (16 channels of one 3x3 tap) the 256 threads stage A[BM][16] (im2col rows, zero-padded
+//     taps read a zero page) and Wt[BN][16] into LDS with ONE 16-byte global load per 64 bytes of tile
+//     row -> 2-4 loads per thread feed 32-64 MFMAs per wave (the direct kernel needs 6-8);
+//   * LDS rows are 64 bytes; the 16-byte chunk index is XOR-swizzled with f(row>>2) = (4-(row>>2))&3 so
+//     that both the 8-lane ds_write_b128 groups and the four 16-lane ds_read_b128 groups of a wave touch
+//     16 distinct 16-byte bank slots (conflict-free, MI355X_MICROARCH.md §LDS);
+//   * double-buffered: global loads for step k+1 are in flight (in registers) while step k's fragments
+//     are read from LDS and its MF*NF*4 MFMAs issue; registers are written to the other LDS buffer
+//     after the MFMAs; one __syncthreads per k-step.
+//   * fragments: lane l reads the 16 bytes [4*(l>>4), +4) of row (l&15) -> exactly the A[i][k=l>>4]
+//     / B[k=l>>4][j] operand layout of 16x16x4, four MFMAs per ds_read_b128 pair.
+#include "kernels.h"
+#include <cmath>
+#include <cstdlib>
+
+namespace padel {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply2(float v, int act) {
+    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+template <int WM, int WN, int MF, int NF, int KS>
+__global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
+    constexpr int TAPS = KS * KS;
+    constexpr int pad = KS >> 1;
+    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+    constexpr int AP = BM / 64;              // A rows staged per thread
+    constexpr int BP = (BN + 63) / 64;       // B rows staged per thread (last pass may be partial)
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * 16];
+    float* const As = lds;
+    float* const Bs = lds + 2 * BM * 16;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware (bijective) remap of the pixel-tile index
+    const int nmt = a.n_mtiles;
+    const int bid = blockIdx.x;
+    const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int nt = blockIdx.y;
+    const int m0 = mt * BM;
+    const int f0 = nt * (WN * NF);           // first 16-channel fragment of this workgroup
+
+    const int HoWo = a.Ho * a.Wo;
+    const int nfull = a.cin >> 5;
+    const int steps_full = nfull * TAPS * 2;
+    const int nks = steps_full + ((a.cin & 16) ? TAPS : 0);
+    const int Ktot = nks * 16;
+
+    // ---- staging assignment: thread -> (row = tid>>2 (+64 per pass), 16-byte chunk = tid&3)
+    const int srow = tid >> 2, sc = tid & 3;
+    long long aoff[AP];
+    int iy0[AP], ix0[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        int m = m0 + srow + 64 * p;
+        const bool rv = m < a.M;
+        if (!rv) m = 0;
+        const int n = m / HoWo;
+        const int rem = m - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        iy0[p] = rv ? oy * a.stride - pad : -(1 << 20);
+        ix0[p] = ox * a.stride - pad;
+        aoff[p] = (((long long)n * a.H + (oy * a.stride - pad)) * a.W + ix0[p]) * a.in_cs + a.in_choff + sc * 4;
+    }
+    const float* wrow[BP];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+        const int rr = srow + 64 * p;                       // row inside the BN tile
+        const int frag = min(f0 + (rr >> 4), a.n16 - 1);    // clamp: partial last channel tile
+        wrow[p] = a.w + ((long long)(frag * 16 + (rr & 15))) * Ktot + sc * 4;
+    }
+    // swizzled LDS offsets (floats)
+    const int swz_w = ((sc ^ ((4 - ((srow >> 2) & 3)) & 3)) << 2);       // same for every pass: +64 rows keeps (row>>2)&3
+    const int st_off = srow * 16 + swz_w;
+    const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);
+    const int a_rd = (wm * MF * 16) * 16 + ld_off;
+    const int b_rd = (wn * NF * 16) * 16 + ld_off;
+
+    f32x4 acc[MF][NF], part[MF][NF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    f32x4 ga[AP], gb[BP];
+    auto gload = [&](const int ks_) {
+        int tap, c0;
+        if (ks_ < steps_full) {
+            const int c32 = ks_ / (TAPS * 2);
+            const int rr = ks_ - c32 * (TAPS * 2);
+            tap = rr >> 1;
+            c0 = c32 * 32 + (rr & 1) * 16;
+        } else {
+            tap = ks_ - steps_full;
+            c0 = nfull * 32;
+        }
+        const int ky = (KS == 3) ? tap / 3 : 0;
+        const int kx = (KS == 3) ? tap - ky * 3 : 0;
+        const long long toff = ((long long)ky * a.W + kx) * a.in_cs + c0;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) {
+            const bool v = (unsigned)(iy0[p] + ky) < (unsigned)a.H && (unsigned)(ix0[p] + kx) < (unsigned)a.W;
+            const float* ptr = v ? a.in + (aoff[p] + toff) : a.zeros;
+            ga[p] = *reinterpret_cast<const f32x4*>(ptr);
+        }
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+            if (BN % 64 == 0 || srow + 64 * p < BN) gb[p] = *reinterpret_cast<const f32x4*>(wrow[p] + ks_ * 16);
+    };
+    auto lstore = [&](const int buf) {
+        float* ad = As + buf * (BM * 16) + st_off;
+        float* bd = Bs + buf * (BN * 16) + st_off;
+#pragma unroll
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(ad + p * 64 * 16) = ga[p];
+#pragma unroll
+        for (int p = 0; p < BP; ++p)
+            if (BN % 64 == 0 || srow + 64 * p < BN) *reinterpret_cast<f32x4*>(bd + p * 64 * 16) = gb[p];
+    };
+    auto compute = [&](const int buf) {
+        const float* ab = As + buf * (BM * 16) + a_rd;
+        const float* bb = Bs + buf * (BN * 16) + b_rd;
+        f32x4 A[MF], B[NF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) A[f] = *reinterpret_cast<const f32x4*>(ab + f * 256);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) B[j] = *reinterpret_cast<const f32x4*>(bb + j * 256);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+                    part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[f][kk], B[j][kk], part[f][j], 0, 0, 0);
+    };
+
+    constexpr int FLUSH = (KS == 3) ? TAPS * 2 : 16;       // k-steps per accumulation block
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    int blk = 0;
+    for (int ks = 0; ks < nks - 1; ++ks) {
+        gload(ks + 1);                                     // in flight under the MFMAs below
+        __builtin_amdgcn_sched_barrier(0);
+        compute(ks & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore((ks + 1) & 1);
+        __syncthreads();
+        if (++blk == FLUSH) {
+            blk = 0;
+#pragma unroll
+            for (int f = 0; f < MF; ++f)
+#pragma unroll
+                for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+    }
+    compute((nks - 1) & 1);
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];
+
+    // epilogue: lane holds D[row = lq*4 + r][col = lr] of each 16x16 fragment
+    const int act = a.act;
+    const int mw = m0 + wm * MF * 16;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int fr = f0 + wn * NF + j;
+        const int co = fr * 16 + lr;
+        const bool cv = co < a.cout;
+        const float b = a.bias[min(fr, a.n16 - 1) * 16 + lr];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = mw + f * 16 + lq * 4 + rr;
+                if (cv && m < a.M) {
+                    float v = act_apply2(acc[f][j][rr] + b, act);
+                    if (a.res) v += a.res[(long long)m * a.res_cs + a.res_choff + co];
+                    a.out[(long long)m * a.out_cs + a.out_choff + co] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MF, int NF>
+static hipError_t launch_l(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    constexpr int BM = WM * MF * 16;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
+    if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3>), grid, dim3(256), 0, s, a);
+    else if (a.ksize == 1) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1>), grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// variant ids: see lds_variants[] below
+struct LdsVariant { int id, wm, wn, mf, nf; };
+static const LdsVariant lds_variants[] = {
+    {0, 2, 2, 4, 4},   // 128 x 128
+    {1, 2, 2, 4, 3},   // 128 x  96
+    {2, 4, 1, 4, 4},   // 256 x  64
+    {3, 4, 1, 4, 3},   // 256 x  48
+    {4, 4, 1, 4, 2},   // 256 x  32
+    {5, 4, 1, 4, 1},   // 256 x  16
+    {6, 2, 2, 2, 4},   //  64 x 128
+    {7, 2, 2, 2, 3},   //  64 x  96
+    {8, 4, 1, 2, 5},   // 128 x  80
+    {9, 4, 1, 2, 4},   // 128 x  64
+    {10, 2, 2, 4, 2},  // 128 x  64 (2x2 waves)
+    {11, 4, 1, 2, 2},  // 128 x  32
+    {12, 4, 1, 2, 1},  // 128 x  16
+};
+
+hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s) {
+    switch (variant) {
+        case 0: return launch_l<2, 2, 4, 4>(a, s);
+        case 1: return launch_l<2, 2, 4, 3>(a, s);
+        case 2: return launch_l<4, 1, 4, 4>(a, s);
+        case 3: return launch_l<4, 1, 4, 3>(a, s);
+        case 4: return launch_l<4, 1, 4, 2>(a, s);
+        case 5: return launch_l<4, 1, 4, 1>(a, s);
+        case 6: return launch_l<2, 2, 2, 4>(a, s);
+        case 7: return launch_l<2, 2, 2, 3>(a, s);
+        case 8: return launch_l<4, 1, 2, 5>(a, s);
+        case 9: return launch_l<4, 1, 2, 4>(a, s);
+        case 10: return launch_l<2, 2, 4, 2>(a, s);
+        case 11: return launch_l<4, 1, 2, 2>(a, s);
+        case 12: return launch_l<4, 1, 2, 1>(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+int choose_conv_lds_variant(int M, int n16) {
+    // tuning overrides (tools/conv_bench.py)
+    static const char* impl = getenv("PADEL_CONV_IMPL");
+    static const int forced = getenv("PADEL_CONV_LDS_VARIANT") ? atoi(getenv("PADEL_CONV_LDS_VARIANT")) : -1;
+    if (impl && impl[0] == 'd') return -1;
+    if (forced >= 0) return forced;
+    // relative speeds measured on MI355X (profiles/conv_lds_sweep_r1.txt)
+    static const float speed[] = {1.00f, 0.98f, 0.95f, 0.90f, 0.80f, 0.60f, 0.85f, 0.83f, 0.85f, 0.82f, 0.85f, 0.65f, 0.45f};
+    float best = -1.f;
+    int bv = 0;
+    for (const auto& v : lds_variants) {
+        const int bm = v.wm * v.mf * 16, nfw = v.wn * v.nf;
+        const int ntiles = (n16 + nfw - 1) / nfw;
+        const long long mtiles = (M + bm - 1) / bm;
+        const float fill = (float)n16 / (float)(ntiles * nfw) * (float)M / (float)(mtiles * bm);
+        const long long blocks = mtiles * ntiles;
+        // 2 workgroups per CU resident; quantisation loss when the grid is only a few waves of workgroups
+        const float waves = (float)blocks / 512.f;
+        const float occ = waves >= 4.f ? 1.f : (waves / ceilf(waves)) * (blocks >= 256 ? 1.f : (float)blocks / 256.f);
+        const float sc = speed[v.id] * fill * occ;
+        if (sc > best) { best = sc; bv = v.id; }
+    }
+    return bv;
+}
+
+int conv_lds_num_variants() { return (int)(sizeof(lds_variants) / sizeof(lds_variants[0])); }
+
+void conv_lds_variant_shape(int variant, int* bm, int* bn) {
+    const LdsVariant& v = lds_variants[variant];
+    *bm = v.wm * v.mf * 16;
+    *bn = v.wn * v.nf * 16;
+}
+
+}  // namespace padel

@@ -430,11 +430,13 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.H = m->net_h >> ib.level; a.W = m->net_w >> ib.level; a.Ho = Ho; a.Wo = Wo;
             a.cin = o.cin; a.cout = o.cout; a.n16 = o.npad / 16; a.ksize = o.ksize; a.stride = o.stride; a.act = o.act;
             a.M = n * Ho * Wo;
-            int mf, nf;
-            choose_conv_tile(a.M, a.n16, &mf, &nf);
+            int mf = 0, nf = 0;
+            const int lv = choose_conv_lds_variant(a.M, a.n16);
+            if (lv >= 0) conv_lds_variant_shape(lv, &mf, &nf);      // profile rows carry BM, BN for the LDS kernel
+            else choose_conv_tile(a.M, a.n16, &mf, &nf);
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
             if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = mf; pr->nf = nf; }
-            r = launch_conv_igemm(a, mf, nf, s);
+            r = lv >= 0 ? launch_conv_lds(a, lv, s) : launch_conv_igemm(a, mf, nf, s);
         } else if (o.kind == PA_OP_STEM) {
             StemArgs a{};
             a.in = m->d_netin; a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;

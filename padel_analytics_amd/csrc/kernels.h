@@ -37,6 +37,13 @@ hipError_t launch_conv_igemm(const ConvArgs& a, int mf, int nf, hipStream_t s);
 // heuristic tile choice for a (M, npad16) problem: returns mf, nf and the N padding it implies
 void choose_conv_tile(int M, int n16, int* mf, int* nf);
 
+// v2: LDS-staged workgroup tiles (conv_lds.hip); bit-identical results to the register-direct kernel
+hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s);
+int conv_lds_num_variants();
+void conv_lds_variant_shape(int variant, int* bm, int* bn);
+// returns the LDS variant to use for (M, n16), or -1 to use the register-direct kernel
+int choose_conv_lds_variant(int M, int n16);
+
 struct StemArgs {
     const uint8_t* in;    // net input u8 NHWC4 [B][H][W][4]
     const float* w;       // [cout][27] (ky,kx,c) fused BN

@@ -1,0 +1,48 @@
+"""Multi-GPU plumbing: frames are independent, so the path shards by batch with no
+data-path collective; the only exchange is a ONE-TIME broadcast of the packed weight blob from the rank
+that loaded the checkpoint (RCCL over xGMI on the GPU box — ``torch.distributed`` backend "nccl"; "gloo" in
+the CPU tests).  ByteTrack ids are assigned on rank 0 after the gather because the tracker is sequential in
+global frame order."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple:
+    """Contiguous block of frame indices owned by `rank` (contiguous so results concatenate in frame order)."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def broadcast_blob(blob: Optional[np.ndarray], n_floats: int, src: int = 0, device=None) -> np.ndarray:
+    """Broadcast the fp32 weight blob; ranks != src pass None.  `device`: torch device the collective runs on
+    ("cuda:k" for RCCL, None/cpu for gloo)."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        assert blob is not None
+        return blob
+    if dist.get_rank() == src:
+        t = torch.from_numpy(np.ascontiguousarray(blob, np.float32))
+    else:
+        t = torch.empty(n_floats, dtype=torch.float32)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def gather_results(local: list, dst: int = 0) -> Optional[list]:
+    """Gather per-rank python result lists (already in local frame order) to `dst`, concatenated in rank
+    (= global frame) order."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(local, out, dst=dst)
+    if out is None:
+        return None
+    return [x for part in out for x in part]

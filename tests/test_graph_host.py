@@ -1,0 +1,48 @@
+"""Host logic without a GPU: BN fold + K-order weight packing + concat-by-slice wiring of the engine's op
+list, checked by interpreting the op list on CPU (tests/graph_interp.py) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolov8_ref as ref
+from padel_analytics_amd import graph as G, yolo_arch
+from tests import graph_interp
+
+
+def test_kstep_order_and_pack_roundtrip():
+    for cin, k in ((16, 3), (32, 3), (48, 3), (96, 1), (80, 3)):
+        steps = G.kstep_order(cin, k)
+        assert len(steps) == cin // 16 * k * k
+        assert sorted(steps) == sorted((t, c) for t in range(k * k) for c in range(0, cin, 16))
+        w = np.random.default_rng(0).normal(size=(32, cin, k, k)).astype(np.float32)
+        p = G.pack_conv_weight(w)
+        o = dict(ksize=k, cin=cin, npad=32, w_off=0, b_off=0)
+        wu, _ = graph_interp.unpack_conv(np.concatenate([p.reshape(-1), np.zeros(32, np.float32)]), o)
+        assert np.array_equal(wu, w)
+
+
+@pytest.mark.parametrize("scale,nc,kpt", [("n", 80, None), ("n", 1, (13, 3)), ("s", 2, (13, 2))])
+def test_graph_matches_oracle(scale, nc, kpt):
+    sd = yolo_arch.synth_state_dict(scale, nc, kpt, seed=1, gain=1.0)
+    g = G.build_yolov8(sd, nc, kpt)
+    x = torch.rand(1, 3, 64, 96)
+    bufs = graph_interp.run(g, net_in=x)
+    m = ref.YoloV8Ref(sd, nc, kpt)
+    with torch.no_grad():
+        det, kp = m.head_raw(m.features(x))
+    for l in range(3):
+        want = det[l] if not kpt else torch.cat([det[l], kp[l]], 1)
+        got = bufs[g.head_buf[l]][:, :want.shape[1]]
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+    # every conv slice obeys the kernel's alignment contract
+    for o in g.ops:
+        if o["kind"] == G.OP_CONV:
+            assert o["cin"] % 16 == 0 and o["in_choff"] % 4 == 0 and o["npad"] % 16 == 0 and o["w_off"] % 4 == 0
+
+
+def test_conv_flops_accounting():
+    sd = yolo_arch.synth_state_dict("n", 80, None, seed=0)
+    g = G.build_yolov8(sd, 80, None)
+    # executed FLOPs (with the 16-padding of head widths) are within 1% of the algorithmic count
+    algo = yolo_arch.conv_flops(yolo_arch.conv_inventory("n", 80, None, 384, 640))
+    assert abs(g.conv_flops(384, 640) / algo - 1) < 0.01

@@ -61,7 +61,8 @@ if __name__ == "__main__":
     ap.add_argument("--one", nargs=2, type=int)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--shapes", default="")
-    ap.add_argument("--tiles", default="1x4,1x6,2x2,2x3,2x4,4x1,4x2,2x6,4x3,4x4")
+    ap.add_argument("--tiles", default="d4x3,d4x4,L0,L1,L2,L3,L4,L5,L6,L7,L8,L9,L10,L11",
+                    help="dMxN = register-direct kernel with MFxNF fragments; Lk = LDS kernel variant k; auto")
     a = ap.parse_args()
     shapes = [s for s in SHAPES if (not a.shapes or any(t in s[0] for t in a.shapes.split(",")))]
     if a.one:
@@ -70,9 +71,13 @@ if __name__ == "__main__":
     table = {}
     for t in ["auto"] + a.tiles.split(","):
         env = dict(os.environ)
-        mf, nf = (0, 0) if t == "auto" else map(int, t.split("x"))
-        if t != "auto":
+        mf, nf = 0, 0
+        if t.startswith("d"):
+            mf, nf = map(int, t[1:].split("x"))
+            env["PADEL_CONV_IMPL"] = "direct"
             env["PADEL_CONV_MF"], env["PADEL_CONV_NF"] = str(mf), str(nf)
+        elif t.startswith("L"):
+            env["PADEL_CONV_LDS_VARIANT"] = t[1:]
         p = subprocess.run([sys.executable, __file__, "--one", str(mf), str(nf), "--reps", str(a.reps), "--shapes", a.shapes],
                            env=env, capture_output=True, text=True)
         for line in p.stdout.splitlines():
