@@ -223,8 +223,8 @@ hipError_t launch_conv_igemm(const ConvArgs& a_in, int mf, int nf, hipStream_t s
 
 void choose_conv_tile(int M, int n16, int* mf_out, int* nf_out) {
     // tuning override (tools/conv_bench.py): PADEL_CONV_MF / PADEL_CONV_NF
-    static const int env_mf = getenv("PADEL_CONV_MF") ? atoi(getenv("PADEL_CONV_MF")) : 0;
-    static const int env_nf = getenv("PADEL_CONV_NF") ? atoi(getenv("PADEL_CONV_NF")) : 0;
+    const int env_mf = getenv("PADEL_CONV_MF") ? atoi(getenv("PADEL_CONV_MF")) : 0;
+    const int env_nf = getenv("PADEL_CONV_NF") ? atoi(getenv("PADEL_CONV_NF")) : 0;
     if (env_mf > 0 && env_nf > 0) { *mf_out = env_mf; *nf_out = env_nf; return; }
     // measured on MI355X (tools/conv_bench.py, profiles/conv_tile_sweep_r1.txt): throughput rises with
     // fragments per wave (fewer operand loads per MFMA) even at 1-2 waves/SIMD, so score each legal

@@ -254,8 +254,8 @@ hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s) {
 
 int choose_conv_lds_variant(int M, int n16) {
     // tuning overrides (tools/conv_bench.py)
-    static const char* impl = getenv("PADEL_CONV_IMPL");
-    static const int forced = getenv("PADEL_CONV_LDS_VARIANT") ? atoi(getenv("PADEL_CONV_LDS_VARIANT")) : -1;
+    const char* impl = getenv("PADEL_CONV_IMPL");
+    const int forced = getenv("PADEL_CONV_LDS_VARIANT") ? atoi(getenv("PADEL_CONV_LDS_VARIANT")) : -1;
     if (impl && impl[0] == 'd') return -1;
     if (forced >= 0) return forced;
     // relative speeds measured on MI355X (profiles/conv_lds_sweep_r1.txt)

@@ -82,6 +82,7 @@ class Graph:
     n_floats: int = 0
     head_buf: tuple = (-1, -1, -1)
     in_channels: int = 0
+    out_channels: int = 0
 
     # ---- construction helpers
     def buf(self, level: int, channels: int) -> int:
@@ -248,4 +249,79 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None) -> Graph:
             g.conv((h1, 0, pw), (hd, hoff), w, b, 1, 1, ACT_NONE)
         heads.append(hd)
     g.head_buf = tuple(heads)
+    return g
+
+
+TRACKNET_BN_EPS = 1e-5      # nn.BatchNorm2d default (reference models.py:9)
+
+
+def build_tracknet(sd) -> Graph:
+    """TrackNetV3 U-Net (reference ``trackers/ball_tracker/models.py:45-74``) over the engine's op set.
+
+    Buffer 0 is the fp32 NHWC input with the 27 channels (background + 8 frames x RGB) zero-padded to 32.
+    ``torch.cat([Upsample(x), skip])`` (:66,:68,:70) is a concat buffer whose first slice is written by the
+    upsample op and whose second slice is written directly by the encoder block that produces the skip."""
+    g = Graph(task=TASK_TRACKNET)
+    in_dim = int(np.asarray(sd["down_block_1.conv_1.conv.weight"]).shape[1])
+    out_dim = int(np.asarray(sd["predictor.weight"]).shape[0])
+    cin0 = pad16(in_dim)
+    g.in_channels = cin0
+
+    def block(prefix, src, dst):
+        w, b = fold_bn(sd, prefix, TRACKNET_BN_EPS)
+        g.conv(src, dst, w, b, 3, 1, ACT_RELU)
+
+    def pool(src, dst):
+        g.ops.append(dict(kind=OP_MAXPOOL2, in_buf=src[0], in_choff=src[1], cin=src[2], out_buf=dst[0], out_choff=dst[1],
+                          cout=src[2], ksize=2, stride=2, act=0, res_buf=-1, res_choff=0, npad=0, w_off=0, b_off=0))
+
+    def up(src, dst):
+        g.ops.append(dict(kind=OP_UPSAMPLE2X, in_buf=src[0], in_choff=src[1], cin=src[2], out_buf=dst[0],
+                          out_choff=dst[1], cout=src[2], ksize=0, stride=0, act=0, res_buf=-1, res_choff=0, npad=0,
+                          w_off=0, b_off=0))
+
+    x0 = g.buf(0, cin0)
+    cat3 = g.buf(0, 128 + 64)        # [up(up_block_2) | x1]
+    cat2 = g.buf(1, 256 + 128)       # [up(up_block_1) | x2]
+    cat1 = g.buf(2, 512 + 256)       # [up(bottleneck) | x3]
+    t = g.buf(0, 64)
+    block("down_block_1.conv_1", (x0, 0, cin0), (t, 0))
+    block("down_block_1.conv_2", (t, 0, 64), (cat3, 128))
+    p1 = g.buf(1, 64)
+    pool((cat3, 128, 64), (p1, 0))
+    t = g.buf(1, 128)
+    block("down_block_2.conv_1", (p1, 0, 64), (t, 0))
+    block("down_block_2.conv_2", (t, 0, 128), (cat2, 256))
+    p2 = g.buf(2, 128)
+    pool((cat2, 256, 128), (p2, 0))
+    ta, tb = g.buf(2, 256), g.buf(2, 256)
+    block("down_block_3.conv_1", (p2, 0, 128), (ta, 0))
+    block("down_block_3.conv_2", (ta, 0, 256), (tb, 0))
+    block("down_block_3.conv_3", (tb, 0, 256), (cat1, 512))
+    p3 = g.buf(3, 256)
+    pool((cat1, 512, 256), (p3, 0))
+    ba, bb, bc = g.buf(3, 512), g.buf(3, 512), g.buf(3, 512)
+    block("bottleneck.conv_1", (p3, 0, 256), (ba, 0))
+    block("bottleneck.conv_2", (ba, 0, 512), (bb, 0))
+    block("bottleneck.conv_3", (bb, 0, 512), (bc, 0))
+    up((bc, 0, 512), (cat1, 0))
+    block("up_block_1.conv_1", (cat1, 0, 768), (ta, 0))
+    block("up_block_1.conv_2", (ta, 0, 256), (tb, 0))
+    u1 = g.buf(2, 256)
+    block("up_block_1.conv_3", (tb, 0, 256), (u1, 0))
+    up((u1, 0, 256), (cat2, 0))
+    t = g.buf(1, 128)
+    u2 = g.buf(1, 128)
+    block("up_block_2.conv_1", (cat2, 0, 384), (t, 0))
+    block("up_block_2.conv_2", (t, 0, 128), (u2, 0))
+    up((u2, 0, 128), (cat3, 0))
+    t = g.buf(0, 64)
+    u3 = g.buf(0, 64)
+    block("up_block_3.conv_1", (cat3, 0, 192), (t, 0))
+    block("up_block_3.conv_2", (t, 0, 64), (u3, 0))
+    out = g.buf(0, out_dim if out_dim % 4 == 0 else pad16(out_dim))
+    g.conv((u3, 0, 64), (out, 0), np.asarray(sd["predictor.weight"], np.float32),
+           np.asarray(sd["predictor.bias"], np.float32), 1, 1, ACT_SIGMOID)
+    g.head_buf = (out, -1, -1)
+    g.out_channels = out_dim
     return g
