@@ -258,8 +258,10 @@ int choose_conv_lds_variant(int M, int n16) {
     const int forced = getenv("PADEL_CONV_LDS_VARIANT") ? atoi(getenv("PADEL_CONV_LDS_VARIANT")) : -1;
     if (impl && impl[0] == 'd') return -1;
     if (forced >= 0) return forced;
-    // relative speeds measured on MI355X (profiles/conv_lds_sweep_r1.txt)
-    static const float speed[] = {1.00f, 0.98f, 0.95f, 0.90f, 0.80f, 0.60f, 0.85f, 0.83f, 0.85f, 0.82f, 0.85f, 0.65f, 0.45f};
+    if (impl && impl[0] == 'l') {} else if (n16 == 3) return -1;   // 48 channels: direct 4x3 measured faster
+    // relative speeds measured on MI355X (profiles/conv_lds_sweep_r1.txt): mid-size tiles at 3-4 waves/SIMD
+    // beat the 128x128 tile (1 wave/SIMD cannot hide its own barriers)
+    static const float speed[] = {0.60f, 0.92f, 0.70f, 0.85f, 0.88f, 0.62f, 0.95f, 1.00f, 0.75f, 0.97f, 0.98f, 0.90f, 0.50f};
     float best = -1.f;
     int bv = 0;
     for (const auto& v : lds_variants) {
@@ -268,9 +270,9 @@ int choose_conv_lds_variant(int M, int n16) {
         const long long mtiles = (M + bm - 1) / bm;
         const float fill = (float)n16 / (float)(ntiles * nfw) * (float)M / (float)(mtiles * bm);
         const long long blocks = mtiles * ntiles;
-        // 2 workgroups per CU resident; quantisation loss when the grid is only a few waves of workgroups
-        const float waves = (float)blocks / 512.f;
-        const float occ = waves >= 4.f ? 1.f : (waves / ceilf(waves)) * (blocks >= 256 ? 1.f : (float)blocks / 256.f);
+        // MFMA-bound: a CU's throughput is shared by its resident workgroups, so time ~ max workgroups per CU
+        const long long per_cu = (blocks + 255) / 256;
+        const float occ = (float)blocks / (256.f * (float)per_cu);
         const float sc = speed[v.id] * fill * occ;
         if (sc > best) { best = sc; bv = v.id; }
     }
