@@ -147,19 +147,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs a) {
     load(0, A0, B0);
     int ks = 0;
     constexpr int FLUSH = (KS == 3) ? TAPS * 2 : 16;      // k-steps per accumulation block (even)
-    int blk = 0;
-    for (; ks + 2 < nks; ks += 2) {
-        load(ks + 1, A1, B1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(A0, B0);
-        __builtin_amdgcn_sched_barrier(0);
-        load(ks + 2, A0, B0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(A1, B1);
-        __builtin_amdgcn_sched_barrier(0);
-        blk += 2;
-        if (blk == FLUSH) {
-            blk = 0;
+    // nested loops: the part -> acc flush sits BETWEEN inner loops (as a branch inside the k-loop it made
+    // hipcc shuffle every accumulator AGPR<->VGPR each iteration)
+    while (ks + 2 < nks) {
+        int pairs = 0;
+        for (; pairs < FLUSH / 2 && ks + 2 < nks; ++pairs, ks += 2) {
+            load(ks + 1, A1, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A0, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            load(ks + 2, A0, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(A1, B1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (pairs == FLUSH / 2) {
 #pragma unroll
             for (int f = 0; f < MF; ++f)
 #pragma unroll

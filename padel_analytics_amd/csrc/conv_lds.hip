@@ -102,19 +102,13 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
+    constexpr int FLUSH = (KS == 3) ? TAPS * 2 : 16;       // k-steps per accumulation block
     f32x4 ga[AP], gb[BP];
-    auto gload = [&](const int ks_) {
-        int tap, c0;
-        if (ks_ < steps_full) {
-            const int c32 = ks_ / (TAPS * 2);
-            const int rr = ks_ - c32 * (TAPS * 2);
-            tap = rr >> 1;
-            c0 = c32 * 32 + (rr & 1) * 16;
-        } else {
-            tap = ks_ - steps_full;
-            c0 = nfull * 32;
-        }
-        const int ky = (KS == 3) ? tap / 3 : 0;
+    // k-position of the step being PREFETCHED, kept incrementally in scalar registers: (pf_c0 = first
+    // channel of the 16-wide slice, pf_tap); `gload` is called for steps 0,1,2,... in order.
+    int pf_tap = 0, pf_half = 0, pf_c32 = 0;
+    auto gload = [&](const int ks_, const int tap, const int c0) {
+        const int ky = (KS == 3) ? (tap * 11) >> 5 : 0;          // tap / 3 for tap in [0, 9)
         const int kx = (KS == 3) ? tap - ky * 3 : 0;
         const long long toff = ((long long)ky * a.W + kx) * a.in_cs + c0;
 #pragma unroll
@@ -127,6 +121,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
         for (int p = 0; p < BP; ++p)
             if (BN % 64 == 0 || srow + 64 * p < BN) gb[p] = *reinterpret_cast<const f32x4*>(wrow[p] + ks_ * 16);
     };
+    (void)steps_full;
     auto lstore = [&](const int buf) {
         float* ad = As + buf * (BM * 16) + st_off;
         float* bd = Bs + buf * (BN * 16) + st_off;
@@ -153,20 +148,32 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
                     part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[f][kk], B[j][kk], part[f][j], 0, 0, 0);
     };
 
-    constexpr int FLUSH = (KS == 3) ? TAPS * 2 : 16;       // k-steps per accumulation block
-    gload(0);
+    // Nested loops: the inner loop (one accumulation block of FLUSH k-steps) contains nothing but
+    // loads / LDS traffic / MFMAs on `part`; the part -> acc flush sits between inner loops.  With the flush
+    // as a branch INSIDE the k-loop hipcc moved every accumulator AGPR<->VGPR on every k-step
+    // (48 v_accvgpr moves per 24 MFMAs in the 64x96 variant).
+#define PADEL_PF_ADVANCE()                                                              \
+    do {                                                                               \
+        if (pf_c32 >= nfull) { ++pf_tap; }                                             \
+        else { pf_half ^= 1; if (!pf_half) { if (++pf_tap == TAPS) { pf_tap = 0; ++pf_c32; } } } \
+    } while (0)
+    gload(0, 0, 0);
+    PADEL_PF_ADVANCE();
     lstore(0);
     __syncthreads();
-    int blk = 0;
-    for (int ks = 0; ks < nks - 1; ++ks) {
-        gload(ks + 1);                                     // in flight under the MFMAs below
-        __builtin_amdgcn_sched_barrier(0);
-        compute(ks & 1);
-        __builtin_amdgcn_sched_barrier(0);
-        lstore((ks + 1) & 1);
-        __syncthreads();
-        if (++blk == FLUSH) {
-            blk = 0;
+    int ks = 0;
+    while (ks < nks - 1) {
+        const int nb = min(FLUSH, nks - 1 - ks);
+        for (int i = 0; i < nb; ++i, ++ks) {
+            gload(ks + 1, pf_tap, pf_c32 * 32 + pf_half * 16);   // in flight under the MFMAs below
+            PADEL_PF_ADVANCE();
+            __builtin_amdgcn_sched_barrier(0);
+            compute(ks & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            lstore((ks + 1) & 1);
+            __syncthreads();
+        }
+        if (nb == FLUSH) {
 #pragma unroll
             for (int f = 0; f < MF; ++f)
 #pragma unroll
