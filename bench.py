@@ -104,7 +104,8 @@ def main():
     from padel_analytics_amd import engine as E, graph as G, synth, yolo_arch
 
     dist = None
-    if world > 1:
+    use_dist = "RANK" in os.environ            # launched by torch.distributed.run (also with 1 rank: exercises RCCL)
+    if use_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
@@ -130,8 +131,8 @@ def main():
         else:
             g = G.build_yolov8(yolo_arch.synth_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], 0), cfg["nc"], cfg["kpt"])
             blob = np.empty(g.n_floats, np.float32)
-        if world > 1:
-            t = torch.from_numpy(blob).cuda(local)
+        if use_dist:
+            t = torch.from_numpy(blob).cuda(local)           # one-time weight broadcast (RCCL)
             dist.broadcast(t, src=0)
             blob = t.cpu().numpy()
             del t
@@ -160,7 +161,7 @@ def main():
 
     def fence():
         eng.synchronize()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -174,7 +175,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local}")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -256,7 +257,7 @@ def main():
         print(json.dumps(out), flush=True)
     for m in models.values():
         m.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

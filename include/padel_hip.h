@@ -130,6 +130,24 @@ int pa_yolo_read_head(pa_model* m, int level, int n, float* out);
 int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on_device, float* out,
                       int out_on_device);
 
+/* ---- ball path: streaming TrackNet session (trackers/ball_tracker/ball_tracker.py:373-523) ----
+ * Frames are fed in stream order; every frame is Pillow-bicubic-resized to 512x288 on the device once
+ * (iterable.py:188), windows of 8 consecutive frames + the background are run through the TrackNet
+ * model, the 8 overlapping window outputs of each frame are ensembled (ball_tracker.py:449-509) and
+ * thresholded at 0.5 (predict.py:184).  The caller gets one 288x512 uint8 mask (255/0) per frame, in
+ * frame order, and turns it into coordinates (predict.py:7-39) on the host.                          */
+typedef struct pa_ball pa_ball;
+int pa_ball_create(pa_model* tracknet, int src_h, int src_w, pa_ball** out);
+void pa_ball_destroy(pa_ball* b);
+/* background: src_h x src_w x 3 uint8 RGB (np.median(...).astype(uint8), iterable.py:70-78); also resets
+ * the stream state                                                                                     */
+int pa_ball_set_background(pa_ball* b, const uint8_t* median_rgb);
+/* frames: n x src_h x src_w x 3 uint8 BGR (n <= the model's max_batch).  flush != 0 after the last
+ * frames of the clip emits the 7 tail frames.  out_masks capacity: (n + 7) x 288 x 512 bytes;
+ * out_heat (optional, may be NULL): (n + 7) x 288 x 512 fp32 ensembled heat maps.                      */
+int pa_ball_feed(pa_ball* b, const uint8_t* frames_bgr, int n, int frames_on_device, int flush,
+                 uint8_t* out_masks, float* out_heat, int* out_count);
+
 /* ---- profiling (bench.py roofline): per-op device times of the LAST inference, HIP events on the
  * engine's stream.  kinds/ms/flops are host arrays of capacity cap; returns the number of records. */
 int pa_engine_set_profiling(pa_engine* eng, int enable);

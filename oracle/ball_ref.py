@@ -1,0 +1,123 @@
+"""ORACLE — test infrastructure only.  CPU restatement of the reference's ball path around TrackNet:
+
+* ``trackers/ball_tracker/iterable.py``: background median of the first ``median_range`` RGB frames
+  (:59-81: ``np.median`` -> ``astype('uint8')`` truncation -> Pillow bicubic resize to 512x288), 8-frame
+  windows sliding by 1 (:153-165), per-frame Pillow resize + CHW stacking + ``/255`` in float64 (:167-199);
+* ``trackers/ball_tracker/ball_tracker.py:421-523``: temporal ensemble of the 8 overlapping window outputs
+  (``get_ensemble_weight`` :68-97 -> [1,2,3,4,4,3,2,1]/20; incomplete head: plain mean of the available
+  windows; tail: plain means);
+* ``trackers/ball_tracker/predict.py``: ``predict_modified`` :149-221 / ``predict_location`` :7-39 / ``to_img``
+  :42-54: threshold 0.5 -> external contours -> bounding rects -> first rect of maximal w*h ->
+  ``int(x+w/2), int(y+h/2)`` -> ``int(c*scaler)``; visibility 0 iff both coordinates are 0.
+
+The window stream is the *intended* contiguous one (the reference drops the 7
+windows that straddle the median boundary for clips longer than ``median_range``).
+
+PINNED: TrackNet itself against the reference's own models.py (tracknet_ref.py goldens); the Pillow resize
+bit-exactly against Pillow; the ensemble against a literal transcription of the reference's buffer algebra
+(tests/test_ball_ref.py).  UNPINNED: ``cv2.findContours`` ordering (ties between equal-area rectangles) —
+restated as 8-connected components in reverse raster-discovery order; cv2 is not installable here.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from PIL import Image
+from scipy import ndimage
+
+HEIGHT, WIDTH, SEQ = 288, 512, 8
+
+
+def ensemble_weight(seq_len: int = SEQ) -> np.ndarray:
+    w = np.ones(seq_len, np.float32)
+    for i in range(math.ceil(seq_len / 2)):
+        w[i] = i + 1
+        w[seq_len - i - 1] = i + 1
+    return (torch.from_numpy(w) / torch.from_numpy(w).sum()).numpy()
+
+
+def median_background(frames_bgr) -> np.ndarray:
+    """-> (3, 288, 512) uint8 (iterable.py:59-81)."""
+    rgb = np.array([f[..., ::-1] for f in frames_bgr])
+    med = np.median(rgb, 0).astype("uint8")
+    return np.moveaxis(np.array(Image.fromarray(med).resize((WIDTH, HEIGHT))), -1, 0)
+
+
+def resize_frame(frame_bgr: np.ndarray) -> np.ndarray:
+    """BGR frame -> (3, 288, 512) uint8 RGB, Pillow bicubic (iterable.py:160,188-189)."""
+    return np.moveaxis(np.array(Image.fromarray(np.ascontiguousarray(frame_bgr[..., ::-1])).resize((WIDTH, HEIGHT))), -1, 0)
+
+
+def window_input(median_chw: np.ndarray, frames_chw) -> np.ndarray:
+    """(27, 288, 512) float32 exactly as ``x.float()`` of the float64 ``frames /= 255.`` (ball_tracker.py:440)."""
+    x = np.concatenate([median_chw.astype(np.float64)] + [f.astype(np.float64) for f in frames_chw], 0)
+    x /= 255.0
+    return x.astype(np.float32)
+
+
+def ensemble(y: np.ndarray) -> np.ndarray:
+    """y: (Nw, 8, H, W) fp32 window outputs -> (Nw + 7, H, W) fp32 per-frame heat maps.
+    Literal index algebra of ball_tracker.py:421-509 (buffer rows = windows, slot = 7 - k)."""
+    nw = y.shape[0]
+    w = torch.from_numpy(ensemble_weight())
+    yt = torch.from_numpy(y)
+    zero = torch.zeros((7,) + tuple(y.shape[1:]), dtype=torch.float32)
+    buf = torch.cat([zero, yt, zero], 0)             # row r <-> window r - 7
+    si = torch.arange(8)
+    fi = torch.arange(7, -1, -1)
+    out = []
+    for g in range(nw):                               # frame g = first frame of window g
+        rows = buf[si + g, fi]
+        out.append(rows.sum(0) / (g + 1) if g < 7 else (rows * w[:, None, None]).sum(0))
+    for frame_i in range(1, 8):                       # the 7 tail frames
+        rows = buf[si + (nw - 1) + frame_i, fi]
+        out.append(rows.sum(0) / (8 - frame_i))
+    return torch.stack(out).numpy()
+
+
+def predict_location(mask_u8: np.ndarray):
+    """Largest bounding rectangle among the 8-connected foreground components (predict.py:7-39)."""
+    if mask_u8.max() == 0:
+        return 0, 0, 0, 0
+    lab, n = ndimage.label(mask_u8 > 0, structure=np.ones((3, 3)))
+    rects = []
+    for sl in ndimage.find_objects(lab):
+        rects.append((sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start))
+    rects = rects[::-1]                               # cv2 returns the last-discovered contour first
+    best = 0
+    for i in range(1, len(rects)):
+        if rects[i][2] * rects[i][3] > rects[best][2] * rects[best][3]:
+            best = i
+    return rects[best]
+
+
+def decode_heat(heat: np.ndarray, img_scaler, threshold: float = 0.5):
+    """(T, H, W) fp32 -> lists x, y, visibility (predict_modified)."""
+    xs, ys, vs = [], [], []
+    for h in heat:
+        m = ((h > threshold) * 255).astype("uint8")
+        x, y, w, hh = predict_location(m)
+        cx, cy = int(x + w / 2), int(y + hh / 2)
+        cx, cy = int(cx * img_scaler[0]), int(cy * img_scaler[1])
+        xs.append(cx); ys.append(cy); vs.append(0 if (cx == 0 and cy == 0) else 1)
+    return xs, ys, vs
+
+
+def track(frames_bgr, tracknet, median_chw=None, batch: int = 4):
+    """Whole-clip oracle: frames -> (x, y, visibility) per frame + the per-frame heat maps.
+    ``tracknet``: callable (N,27,288,512) fp32 tensor -> (N,8,288,512)."""
+    frames_bgr = list(frames_bgr)
+    T = len(frames_bgr)
+    if median_chw is None:
+        median_chw = median_background(frames_bgr)
+    small = [resize_frame(f) for f in frames_bgr]
+    ys = []
+    for g0 in range(0, T - 7, batch):
+        xb = np.stack([window_input(median_chw, small[g:g + 8]) for g in range(g0, min(g0 + batch, T - 7))])
+        ys.append(tracknet(torch.from_numpy(xb)).numpy())
+    heat = ensemble(np.concatenate(ys))
+    h0, w0 = frames_bgr[0].shape[:2]
+    x, y, v = decode_heat(heat, (w0 / WIDTH, h0 / HEIGHT))
+    return x, y, v, heat

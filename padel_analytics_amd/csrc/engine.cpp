@@ -633,6 +633,204 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------- ball session
+struct pa_ball {
+    pa_model* m = nullptr;
+    int h = 0, w = 0;            // source frame size
+    int B = 0;                   // max frames per feed == model max_batch
+    int ring = 0;                // resized-frame ring slots (B + 7)
+    long long fed = 0;           // frames fed since the last set_background
+    bool have_bg = false;
+    uint8_t *d_src = nullptr, *d_tmp = nullptr, *d_small = nullptr, *d_med_src = nullptr, *d_med = nullptr;
+    uint8_t* d_mask = nullptr; float* d_heat = nullptr;
+    float* d_Y = nullptr;        // [7 + B + 7][288][512][cs] window outputs (7 carry rows first)
+    float* d_lut = nullptr;
+    int32_t *d_hb = nullptr, *d_hk = nullptr, *d_vb = nullptr, *d_vk = nullptr;
+    int hks = 0, vks = 0;
+    int32_t *d_row0 = nullptr, *d_mode = nullptr; float* d_div = nullptr;
+    int cs = 0;
+};
+
+static const int BALL_H = 288, BALL_W = 512;
+
+int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
+    if (!m || !out) return 1;
+    pa_engine* e = m->e;
+    if (m->d.task != PA_TASK_TRACKNET) PA_FAIL(e, "pa_ball_create: not a TrackNet model");
+    if (m->bufs[0].channels != 32) PA_FAIL(e, "pa_ball_create: TrackNet input buffer must have 32 channels (27 + pad)");
+    PA_HIP(e, hipSetDevice(e->dev));
+    pa_ball* b = new pa_ball();
+    b->m = m; b->h = src_h; b->w = src_w; b->B = m->max_batch; b->ring = b->B + 7;
+    b->cs = m->bufs[m->d.head_buf[0]].channels;
+    if (b->cs < 8) { delete b; PA_FAIL(e, "pa_ball_create: TrackNet output has %d channels (< 8)", b->cs); }
+    const size_t HW = (size_t)BALL_H * BALL_W;
+    PA_HIP(e, hipMalloc((void**)&b->d_src, (size_t)b->B * src_h * src_w * 3));
+    PA_HIP(e, hipMalloc((void**)&b->d_tmp, (size_t)b->B * src_h * BALL_W * 3));
+    PA_HIP(e, hipMalloc((void**)&b->d_small, (size_t)b->ring * HW * 3));
+    PA_HIP(e, hipMalloc((void**)&b->d_med_src, (size_t)src_h * src_w * 3));
+    PA_HIP(e, hipMalloc((void**)&b->d_med, HW * 3));
+    PA_HIP(e, hipMalloc((void**)&b->d_mask, (size_t)(b->B + 7) * HW));
+    PA_HIP(e, hipMalloc((void**)&b->d_heat, (size_t)(b->B + 7) * HW * sizeof(float)));
+    PA_HIP(e, hipMalloc((void**)&b->d_Y, (size_t)(b->B + 14) * HW * b->cs * sizeof(float)));
+    PA_HIP(e, hipMalloc((void**)&b->d_row0, (b->B + 7) * sizeof(int32_t)));
+    PA_HIP(e, hipMalloc((void**)&b->d_mode, (b->B + 7) * sizeof(int32_t)));
+    PA_HIP(e, hipMalloc((void**)&b->d_div, (b->B + 7) * sizeof(float)));
+    std::vector<float> lut(256);
+    for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);     // float64 division, then .float()
+    PA_HIP(e, hipMalloc((void**)&b->d_lut, 256 * sizeof(float)));
+    PA_HIP(e, hipMemcpyAsync(b->d_lut, lut.data(), 256 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    std::vector<int32_t> bb, kk;
+    if (src_w != BALL_W) { b->hks = pil_coeffs(src_w, BALL_W, bb, kk); PA_HIP(e, upload(e, &b->d_hb, bb)); PA_HIP(e, upload(e, &b->d_hk, kk)); }
+    if (src_h != BALL_H) { b->vks = pil_coeffs(src_h, BALL_H, bb, kk); PA_HIP(e, upload(e, &b->d_vb, bb)); PA_HIP(e, upload(e, &b->d_vk, kk)); }
+    *out = b;
+    return 0;
+}
+
+void pa_ball_destroy(pa_ball* b) {
+    if (!b) return;
+    hipSetDevice(b->m->e->dev);
+    hipStreamSynchronize(b->m->e->stream);
+    void* ptrs[] = {b->d_src, b->d_tmp, b->d_small, b->d_med_src, b->d_med, b->d_mask, b->d_heat, b->d_Y, b->d_lut,
+                    b->d_hb, b->d_hk, b->d_vb, b->d_vk, b->d_row0, b->d_mode, b->d_div};
+    for (void* p : ptrs) if (p) hipFree(p);
+    delete b;
+}
+
+// Pillow bicubic resize of n u8 HWC images (h x w x 3) to 288 x 512 x 3, optional channel reversal
+static int ball_resize(pa_ball* b, const uint8_t* src, int n, uint8_t* dst, int reverse) {
+    pa_engine* e = b->m->e;
+    hipStream_t s = e->stream;
+    const uint8_t* cur = src;
+    int cw = b->w;
+    hipError_t r = hipSuccess;
+    if (b->w == BALL_W && b->h == BALL_H) PA_FAIL(e, "ball path: a source that is already 512x288 is not supported yet");
+    if (b->w != BALL_W) {
+        ResamplePassArgs a{};
+        const bool last = (b->h == BALL_H);
+        a.in = cur; a.out = last ? dst : b->d_tmp; a.B = n; a.in_h = b->h; a.in_w = b->w; a.in_c = 3;
+        a.out_h = b->h; a.out_w = BALL_W; a.out_c = 3; a.vertical = 0; a.bounds = b->d_hb; a.coefs = b->d_hk; a.ksize = b->hks;
+        a.reverse = last ? reverse : 0;
+        r = launch_resample_pass(a, s);
+        cur = b->d_tmp; cw = BALL_W;
+    }
+    if (r == hipSuccess && b->h != BALL_H) {
+        ResamplePassArgs a{};
+        a.in = cur; a.out = dst; a.B = n; a.in_h = b->h; a.in_w = cw; a.in_c = 3;
+        a.out_h = BALL_H; a.out_w = cw; a.out_c = 3; a.vertical = 1; a.bounds = b->d_vb; a.coefs = b->d_vk; a.ksize = b->vks;
+        a.reverse = reverse;
+        r = launch_resample_pass(a, s);
+    }
+    if (r != hipSuccess) PA_FAIL(e, "ball resize launch failed: %s", hipGetErrorString(r));
+    return 0;
+}
+
+int pa_ball_set_background(pa_ball* b, const uint8_t* median_rgb) {
+    if (!b || !median_rgb) return 1;
+    pa_engine* e = b->m->e;
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipMemcpyAsync(b->d_med_src, median_rgb, (size_t)b->h * b->w * 3, hipMemcpyHostToDevice, e->stream));
+    if (ball_resize(b, b->d_med_src, 1, b->d_med, 0)) return 1;
+    PA_HIP(e, hipMemsetAsync(b->d_Y, 0, (size_t)(b->B + 14) * BALL_H * BALL_W * b->cs * sizeof(float), e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    b->fed = 0;
+    b->have_bg = true;
+    return 0;
+}
+
+int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int flush, uint8_t* out_masks,
+                 float* out_heat, int* out_count) {
+    if (!b || !out_masks || !out_count) return 1;
+    pa_model* m = b->m;
+    pa_engine* e = m->e;
+    if (!b->have_bg) PA_FAIL(e, "pa_ball_feed: set the background first");
+    if (n < 0 || n > b->B || (n > 0 && !frames)) PA_FAIL(e, "pa_ball_feed: n = %d (max %d)", n, b->B);
+    PA_HIP(e, hipSetDevice(e->dev));
+    hipStream_t s = e->stream;
+    const size_t HW = (size_t)BALL_H * BALL_W;
+    if (!m->planned || m->net_h != BALL_H || m->net_w != BALL_W || m->p_batch != m->max_batch) {
+        PA_HIP(e, hipStreamSynchronize(s));
+        free_plan(m);
+        m->net_h = BALL_H; m->net_w = BALL_W;
+        if (plan_buffers(m, m->max_batch)) return 1;
+        m->planned = true;
+    }
+    int nout = 0;
+    std::vector<int32_t> row0, mode;
+    std::vector<float> div;
+    int nw = 0;
+    if (n > 0) {
+        // 1. resize the new frames (BGR -> RGB) into the ring; a feed never wraps more than once
+        const uint8_t* src = frames;
+        if (!on_device) {
+            PA_HIP(e, hipMemcpyAsync(b->d_src, frames, (size_t)n * b->h * b->w * 3, hipMemcpyHostToDevice, s));
+            src = b->d_src;
+        }
+        const int slot0 = (int)(b->fed % b->ring);
+        const int first = std::min(n, b->ring - slot0);
+        if (ball_resize(b, src, first, b->d_small + (size_t)slot0 * HW * 3, 1)) return 1;
+        if (first < n && ball_resize(b, src + (size_t)first * b->h * b->w * 3, n - first, b->d_small, 1)) return 1;
+        const long long f_old = b->fed, f_new = b->fed + n;
+        // 2. new complete windows g in [g_lo, g_hi]
+        const long long g_lo = std::max(0ll, f_old - 7), g_hi = f_new - 8;
+        nw = g_hi >= g_lo ? (int)(g_hi - g_lo + 1) : 0;
+        if (nw > 0) {
+            BallAssembleArgs aa{};
+            aa.median = b->d_med; aa.frames = b->d_small; aa.lut = b->d_lut; aa.out = m->bptr[0];
+            aa.B = nw; aa.H = BALL_H; aa.W = BALL_W; aa.ring = b->ring; aa.first_slot = (int)(g_lo % b->ring);
+            hipError_t r = launch_ball_assemble(aa, s);
+            if (r != hipSuccess) PA_FAIL(e, "ball assemble launch failed: %s", hipGetErrorString(r));
+            size_t pi = 0;
+            if (run_ops(m, nw, &pi)) return 1;
+            finish_profile(m, pi);
+            PA_HIP(e, hipMemcpyAsync(b->d_Y + (size_t)7 * HW * b->cs, m->bptr[m->d.head_buf[0]],
+                                     (size_t)nw * HW * b->cs * sizeof(float), hipMemcpyDeviceToDevice, s));
+            for (int i = 0; i < nw; ++i) {             // frame g = g_lo + i: rows i .. i+7 (row r <-> window g_lo - 7 + r)
+                const long long g = g_lo + i;
+                row0.push_back(i);
+                mode.push_back(g < 7 ? 1 : 0);
+                div.push_back((float)(g + 1));
+            }
+        }
+        b->fed = f_new;
+    }
+    if (flush && b->fed >= 8) {
+        // tail: rows after the last window are zero (ball_tracker.py:486-509)
+        PA_HIP(e, hipMemsetAsync(b->d_Y + (size_t)(7 + nw) * HW * b->cs, 0, (size_t)7 * HW * b->cs * sizeof(float), s));
+        for (int fi = 1; fi < 8; ++fi) {
+            row0.push_back(nw - 1 + fi);               // window index of the last sample is row (nw - 1) + 7
+            mode.push_back(1);
+            div.push_back((float)(8 - fi));
+        }
+    }
+    nout = (int)row0.size();
+    if (nout > 0) {
+        PA_HIP(e, hipMemcpyAsync(b->d_row0, row0.data(), nout * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        PA_HIP(e, hipMemcpyAsync(b->d_mode, mode.data(), nout * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        PA_HIP(e, hipMemcpyAsync(b->d_div, div.data(), nout * sizeof(float), hipMemcpyHostToDevice, s));
+        BallEnsembleArgs ea{};
+        ea.Y = b->d_Y; ea.cs = b->cs; ea.H = BALL_H; ea.W = BALL_W; ea.row0 = b->d_row0; ea.mode = b->d_mode; ea.div = b->d_div;
+        static const float w8[8] = {1.f, 2.f, 3.f, 4.f, 4.f, 3.f, 2.f, 1.f};
+        for (int k = 0; k < 8; ++k) ea.w[k] = w8[k] / 20.0f;
+        ea.threshold = 0.5f; ea.heat = out_heat ? b->d_heat : nullptr; ea.mask = b->d_mask;
+        hipError_t r = launch_ball_ensemble(ea, nout, s);
+        if (r != hipSuccess) PA_FAIL(e, "ball ensemble launch failed: %s", hipGetErrorString(r));
+        PA_HIP(e, hipMemcpyAsync(out_masks, b->d_mask, (size_t)nout * HW, hipMemcpyDeviceToHost, s));
+        if (out_heat) PA_HIP(e, hipMemcpyAsync(out_heat, b->d_heat, (size_t)nout * HW * sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    // 3. carry the last 7 window rows to the front for the next feed: rows [nw, nw+7) -> [0, 7).  The ranges
+    // overlap when nw < 7; copying row by row in ascending order is safe because dst row < src row.
+    if (nw > 0) {
+        for (int r7 = 0; r7 < 7; ++r7)
+            PA_HIP(e, hipMemcpyAsync(b->d_Y + (size_t)r7 * HW * b->cs, b->d_Y + (size_t)(nw + r7) * HW * b->cs,
+                                     HW * b->cs * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    PA_HIP(e, hipStreamSynchronize(s));
+    *out_count = nout;
+    return 0;
+}
+
 int pa_model_profile_text(pa_model* m, char* buf, size_t cap) {
     size_t off = 0;
     for (size_t i = 0; i < m->n_prof && i < m->prof.size(); ++i) {

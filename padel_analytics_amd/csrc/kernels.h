@@ -126,4 +126,27 @@ struct NmsArgs {
 };
 hipError_t launch_nms(const NmsArgs& a, hipStream_t s);
 
+// ---- ball path (TrackNet) ---------------------------------------------------------------
+struct BallAssembleArgs {
+    const uint8_t* median;   // [H][W][3] RGB, resized background
+    const uint8_t* frames;   // ring [ring][H][W][3] RGB, resized frames
+    const float* lut;        // [256] u8 -> float(double(u)/255)
+    float* out;              // [B][H][W][32] fp32
+    int B, H, W, ring, first_slot;
+};
+hipError_t launch_ball_assemble(const BallAssembleArgs& a, hipStream_t s);
+
+struct BallEnsembleArgs {
+    const float* Y;          // [rows][H][W][cs] window outputs (sigmoid heat maps), slot = channel
+    int cs, H, W;
+    const int32_t* row0;     // [nout] first buffer row of each output frame
+    const int32_t* mode;     // [nout] 0 weighted, 1 mean
+    const float* div;        // [nout] divisor for mode 1
+    float w[8];              // ensemble weights
+    float threshold;
+    float* heat;             // [nout][H][W] or nullptr
+    uint8_t* mask;           // [nout][H][W] 255 / 0
+};
+hipError_t launch_ball_ensemble(const BallEnsembleArgs& a, int nout, hipStream_t s);
+
 }  // namespace padel

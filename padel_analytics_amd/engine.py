@@ -61,7 +61,7 @@ ABI_SYMBOLS = [
     "pa_engine_synchronize", "pa_device_malloc", "pa_device_free", "pa_memcpy_h2d", "pa_memcpy_d2h",
     "pa_model_create", "pa_model_destroy", "pa_model_set_max_batch", "pa_yolo_infer", "pa_yolo_head_shape",
     "pa_yolo_read_head", "pa_tracknet_infer", "pa_engine_set_profiling", "pa_model_last_profile",
-    "pa_model_profile_text",
+    "pa_model_profile_text", "pa_ball_create", "pa_ball_destroy", "pa_ball_set_background", "pa_ball_feed",
 ]
 
 
@@ -104,6 +104,11 @@ def load_library():
     lib.pa_engine_set_profiling.argtypes = [vp, i32]
     lib.pa_model_last_profile.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.pa_model_profile_text.argtypes = [vp, C.c_char_p, sz]
+    lib.pa_ball_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    lib.pa_ball_destroy.argtypes = [vp]
+    lib.pa_ball_destroy.restype = None
+    lib.pa_ball_set_background.argtypes = [vp, vp]
+    lib.pa_ball_feed.argtypes = [vp, vp, i32, i32, i32, vp, vp, C.POINTER(i32)]
     if lib.pa_abi_version() != 1:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
@@ -278,4 +283,45 @@ class Model:
     def close(self):
         if self.handle:
             self.engine.lib.pa_model_destroy(self.handle)
+            self.handle = None
+
+
+class BallSession:
+    """Streaming TrackNet session on one engine (``pa_ball_*``): resize + windows + network + temporal
+    ensemble + threshold on the GPU; yields one 288x512 uint8 mask (and optionally the fp32 heat map) per frame."""
+
+    H, W = 288, 512
+
+    def __init__(self, model: Model, src_h: int, src_w: int):
+        self.model, self.src_h, self.src_w = model, src_h, src_w
+        h = C.c_void_p()
+        model.engine._check(model.engine.lib.pa_ball_create(model.handle, src_h, src_w, C.byref(h)))
+        self.handle = h
+        self.max_feed = model.max_batch
+
+    def set_background(self, median_rgb: np.ndarray):
+        m = np.ascontiguousarray(median_rgb, np.uint8)
+        assert m.shape == (self.src_h, self.src_w, 3), m.shape
+        self.model.engine._check(self.model.engine.lib.pa_ball_set_background(self.handle, m.ctypes.data))
+
+    def feed(self, frames_bgr: Optional[np.ndarray], flush: bool = False, want_heat: bool = False):
+        """frames_bgr: (n, h, w, 3) uint8 with n <= max_feed (or None with flush=True).
+        Returns (masks (k,288,512) uint8, heat (k,288,512) fp32 | None): outputs for the next k frames in order."""
+        n = 0 if frames_bgr is None else len(frames_bgr)
+        ptr = None
+        if n:
+            frames_bgr = np.ascontiguousarray(frames_bgr, np.uint8)
+            assert frames_bgr.shape == (n, self.src_h, self.src_w, 3) and n <= self.max_feed
+            ptr = frames_bgr.ctypes.data
+        masks = np.empty((n + 7, self.H, self.W), np.uint8)
+        heat = np.empty((n + 7, self.H, self.W), np.float32) if want_heat else None
+        cnt = C.c_int(0)
+        self.model.engine._check(self.model.engine.lib.pa_ball_feed(
+            self.handle, ptr, n, 0, int(flush), masks.ctypes.data, heat.ctypes.data if want_heat else None, C.byref(cnt)))
+        k = cnt.value
+        return masks[:k], (heat[:k] if want_heat else None)
+
+    def close(self):
+        if self.handle:
+            self.model.engine.lib.pa_ball_destroy(self.handle)
             self.handle = None

@@ -2,4 +2,5 @@
 from .tracker import NoPredictFrames, NoPredictSample, Object, Tracker, TrackingResults
 from .players_tracker import Player, Players, PlayerTracker
 from .players_keypoints_tracker import PlayerKeypoint, PlayerKeypoints, PlayersKeypoints, PlayerKeypointsTracker
+from .ball_tracker import Ball, BallTracker
 from .runner import TrackingRunner

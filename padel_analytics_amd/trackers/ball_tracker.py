@@ -1,0 +1,169 @@
+"""Ball tracker — drop-in for the reference's ``trackers/ball_tracker/ball_tracker.py`` (``Ball`` :139-205,
+``BallTracker`` :208-708), TrackNet stage.
+
+Hot path (``predict_frames`` :373-523): background median of the first ``median_max_sample_num`` frames ->
+every frame Pillow-resized to 512x288 -> 8-frame sliding windows (+ background = 27 channels) -> TrackNet ->
+temporal ensemble of the 8 overlapping outputs -> threshold .5 -> largest bounding rectangle of the connected
+components -> centre scaled to source pixels.  On the GPU (``pa_ball_*``): resize, window assembly, network,
+ensemble, threshold.  On the host: the median (numpy, like the reference; device histogram median is "next",
+SURVEY.md §2.1 K11) and the connected-component rectangle pick (scipy.ndimage; the reference uses cv2 on the
+host too, ``predict.py:21-26``).
+
+Deliberate differences: the window stream is contiguous across the median boundary
+(#10: the reference drops 7 windows for clips longer than ``median_range``); the tracker completes without an
+InpaintNet (#3: the reference raises KeyError); nothing hard-codes ``.cuda()``.  The InpaintNet stage
+(:525-673) is not implemented yet — ``inpainting_model_path`` is accepted and ignored with a message.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Iterable, Optional, Type
+
+import numpy as np
+from scipy import ndimage
+
+from .. import checkpoint, engine as E, graph as G
+from .tracker import NoPredictSample, Object, Tracker
+
+
+class Ball(Object):
+    def __init__(self, frame: int, xy: tuple, visibility: int, projection: Optional[tuple] = None):
+        super().__init__()
+        self.frame = frame
+        self.xy = xy
+        self.visibility = visibility
+        self.projection = projection
+
+    @classmethod
+    def from_json(cls, x: dict): return cls(**x)
+
+    def serialize(self) -> dict:
+        return {"frame": self.frame, "xy": self.xy, "visibility": self.visibility, "projection": self.projection}
+
+    def asint(self) -> tuple: return tuple(int(v) for v in self.xy)
+
+
+def predict_location(mask_u8: np.ndarray) -> tuple:
+    """predict.py:7-39: bounding rectangle of maximal w*h among the 8-connected foreground components; on ties
+    the first one in cv2.findContours order (taken as reverse raster-discovery order — cv2 is unavailable)."""
+    if mask_u8.max() == 0:
+        return 0, 0, 0, 0
+    lab, _ = ndimage.label(mask_u8 > 0, structure=np.ones((3, 3)))
+    rects = [(sl[1].start, sl[0].start, sl[1].stop - sl[1].start, sl[0].stop - sl[0].start)
+             for sl in ndimage.find_objects(lab)][::-1]
+    best = 0
+    for i in range(1, len(rects)):
+        if rects[i][2] * rects[i][3] > rects[best][2] * rects[best][3]:
+            best = i
+    return rects[best]
+
+
+class BallTracker(Tracker):
+    EVAL_MODE = "weight"
+    TRAJECTORY_LENGTH = 8
+    HEIGHT = 288
+    WIDTH = 512
+
+    def __init__(self, tracking_model_path: str, inpainting_model_path: Optional[str], batch_size: int,
+                 median_max_sample_num: int = 1800, median: Optional[np.ndarray] = None,
+                 load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None):
+        super().__init__(load_path=load_path, save_path=save_path)
+        ck = checkpoint.load_checkpoint(tracking_model_path)
+        if ck.task != "tracknet":
+            raise ValueError(f"{tracking_model_path}: not a TrackNet checkpoint")
+        self.tracknet_seq_len = int(ck.param_dict.get("seq_len", 8))
+        assert self.tracknet_seq_len == self.TRAJECTORY_LENGTH
+        self.bg_mode = ck.param_dict.get("bg_mode", "concat")
+        assert self.bg_mode == "concat", "only bg_mode='concat' (27 input channels) is wired, like the reference (:402,:443)"
+        self.graph = G.build_tracknet(ck.state_dict)
+        if inpainting_model_path:
+            print(f"{self}: InpaintNet trajectory repair is not implemented in this build; using TrackNet output")
+        self.batch_size = batch_size
+        self.median_max_sample_num = median_max_sample_num
+        self.median = median
+        self.video_info = None
+        self._model: Optional[E.Model] = None
+        self._engine: Optional[E.Engine] = None
+
+    def video_info_post_init(self, video_info) -> "BallTracker":
+        self.video_info = video_info
+        return self
+
+    def object(self) -> Type[Object]: return Ball
+
+    def draw_kwargs(self) -> dict: return {}
+
+    def __str__(self) -> str: return "ball_tracker"
+
+    def restart(self) -> None: self.results.restart()
+
+    def to(self, device: str) -> None:
+        if str(device).startswith("cuda"):
+            if self._model is None:
+                self._model = E.Model(self._engine or E.default_engine(), self.graph)
+                self._model.set_max_batch(max(1, self.batch_size))
+        elif self._model is not None:
+            self._model.close()
+            self._model = None
+
+    def predict_sample(self, sample: Iterable[np.ndarray], **kwargs):
+        raise NoPredictSample()
+
+    def predict_frames(self, frame_generator: Iterable[np.ndarray], total_frames: int = None, **kwargs) -> list:
+        self.to("cuda")
+        it = iter(frame_generator)
+        head = []
+        median = self.median
+        if median is None:                       # iterable.py:59-74 (RGB frames, np.median, uint8 truncation)
+            for f in it:
+                head.append(f)
+                if len(head) == self.median_max_sample_num:
+                    break
+            if not head:
+                return []
+            median = np.median(np.array([f[..., ::-1] for f in head]), 0).astype("uint8")
+        first = head[0] if head else next(it)
+        if not head:
+            head = [first]
+        h0, w0 = first.shape[:2]
+        w_scaler, h_scaler = w0 / self.WIDTH, h0 / self.HEIGHT
+        sess = E.BallSession(self._model, h0, w0)
+        sess.set_background(median)
+        xs, ys, vs = [], [], []
+
+        def consume(masks):
+            for m in masks:
+                x, y, w, h = predict_location(m)
+                cx, cy = int(x + w / 2), int(y + h / 2)
+                cx, cy = int(cx * w_scaler), int(cy * h_scaler)
+                xs.append(cx); ys.append(cy); vs.append(0 if (cx == 0 and cy == 0) else 1)
+
+        def chunks():
+            buf = []
+            for f in head:
+                buf.append(f)
+                if len(buf) == sess.max_feed:
+                    yield buf
+                    buf = []
+            for f in it:
+                buf.append(f)
+                if len(buf) == sess.max_feed:
+                    yield buf
+                    buf = []
+            if buf:
+                yield buf
+
+        n_total = 0
+        for c in chunks():
+            n_total += len(c)
+            consume(sess.feed(np.stack(c))[0])
+        consume(sess.feed(None, flush=True)[0])
+        sess.close()
+        out = []
+        for i in range(n_total):
+            if i < len(xs):
+                out.append(Ball(frame=i, xy=(xs[i], ys[i]), visibility=vs[i]))
+            else:                                  # clips shorter than one window (reference :688-696)
+                print(f"{self}: missing detection frame {i}")
+                out.append(Ball(frame=i, xy=(0.0, 0.0), visibility=0))
+        return out

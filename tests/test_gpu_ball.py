@@ -1,0 +1,83 @@
+"""GPU: the streaming ball session (pa_ball_*: Pillow resize, window assembly, TrackNet, temporal ensemble,
+threshold) and the BallTracker plugin against the oracle (oracle/ball_ref.py + oracle/tracknet_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ball_ref as br, tracknet_ref as tr
+from padel_analytics_amd import checkpoint, engine as E, graph as G, synth, video
+from padel_analytics_amd.trackers import BallTracker
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip(T, h, w, seed):
+    frames = synth.synthetic_frames(T, h, w, seed=seed)
+    # a bright moving blob so the clip is not static
+    for t in range(T):
+        cy, cx = h // 3 + 5 * t, w // 4 + 17 * t
+        frames[t, cy:cy + 14, cx:cx + 14] = (255, 255, 255)
+    return frames
+
+
+def _calibrated_tracknet(frames):
+    """TrackNet weights whose sigmoid output crosses 0.5 on a small fraction of pixels of `frames`."""
+    sd = tr.synth_tracknet_state_dict(5)
+    med = br.median_background(frames)
+    small = [br.resize_frame(f) for f in frames[:8]]
+    x = torch.from_numpy(br.window_input(med, small))[None]
+    net = tr.TrackNetRef(sd)
+    # pre-sigmoid logits of the predictor: shift the bias so ~1 % of pixels are above threshold
+    sd["predictor.bias"] = np.zeros(8, np.float32)
+    y = net.forward(x)
+    logit = torch.log(y / (1 - y))
+    sd["predictor.bias"] = (-torch.quantile(logit.flatten(), 0.99)).repeat(8).numpy().astype(np.float32)
+    return sd
+
+
+@pytest.mark.parametrize("T,feed", [(19, 4), (12, 8)])
+def test_ball_session_matches_oracle(gpu_engine, T, feed):
+    frames = _clip(T, 360, 640, seed=21)
+    sd = _calibrated_tracknet(frames)
+    net = tr.TrackNetRef(sd)
+    x_ref, y_ref, v_ref, heat_ref = br.track(frames, net.forward, batch=4)
+    m = E.Model(gpu_engine, G.build_tracknet(sd))
+    m.set_max_batch(feed)
+    sess = E.BallSession(m, 360, 640)
+    sess.set_background(np.median(np.array([f[..., ::-1] for f in frames]), 0).astype("uint8"))
+    masks, heats = [], []
+    for i in range(0, T, feed):
+        mk, ht = sess.feed(frames[i:i + feed], want_heat=True)
+        masks.append(mk); heats.append(ht)
+    mk, ht = sess.feed(None, flush=True, want_heat=True)
+    masks.append(mk); heats.append(ht)
+    masks, heat = np.concatenate(masks), np.concatenate(heats)
+    assert heat.shape == heat_ref.shape == (T, 288, 512)
+    err = np.abs(heat - heat_ref).max()
+    assert err < 2e-5, f"ensembled heat map max abs err {err:.2e}"
+    want_mask = (heat_ref > 0.5)
+    near = np.abs(heat_ref - 0.5) < 1e-4                       # threshold-adjacent pixels may flip
+    assert np.array_equal((masks > 0)[~near], want_mask[~near])
+    assert want_mask.any(), "calibration produced empty masks"
+    sess.close()
+    m.close()
+
+
+def test_ball_tracker_plugin(gpu_engine, tmp_path):
+    T = 20
+    frames = _clip(T, 360, 640, seed=33)
+    sd = _calibrated_tracknet(frames)
+    ck = tmp_path / "TrackNet_synth.pt"
+    checkpoint.save_checkpoint(ck, sd, "tracknet", param_dict={"seq_len": 8, "bg_mode": "concat"})
+    x_ref, y_ref, v_ref, heat_ref = br.track(frames, tr.TrackNetRef(sd).forward, batch=4)
+    t = BallTracker(str(ck), None, batch_size=6, median_max_sample_num=T)
+    t.video_info_post_init(video.VideoInfo(640, 360, 30, T))
+    balls = t.predict_and_update(iter(frames), total_frames=T)
+    assert len(balls) == T
+    near = [bool((np.abs(h - 0.5) < 1e-4).any()) for h in heat_ref]
+    for i, b in enumerate(balls):
+        assert b.frame == i
+        if not near[i]:
+            assert (b.xy[0], b.xy[1], b.visibility) == (x_ref[i], y_ref[i], v_ref[i]), i
+    assert sum(v_ref) > 0
+    t.to("cpu")
