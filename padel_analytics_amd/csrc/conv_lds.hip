@@ -32,7 +32,7 @@ __device__ __forceinline__ float act_apply2(float v, int act) {
     return v;
 }
 
-template <int WM, int WN, int MF, int NF, int KS>
+template <int WM, int WN, int MF, int NF, int KS, int KB>
 __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
     constexpr int TAPS = KS * KS;
     constexpr int pad = KS >> 1;
@@ -40,9 +40,10 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
     constexpr int AP = BM / 64;              // A rows staged per thread
     constexpr int BP = (BN + 63) / 64;       // B rows staged per thread (last pass may be partial)
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float lds[2 * (BM + BN) * 16];
+    // KB k-steps (16 channels each) are staged per barrier interval
+    __shared__ __attribute__((aligned(16))) float lds[2 * KB * (BM + BN) * 16];
     float* const As = lds;
-    float* const Bs = lds + 2 * BM * 16;
+    float* const Bs = lds + 2 * KB * BM * 16;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -103,37 +104,39 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
         for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
     constexpr int FLUSH = (KS == 3) ? TAPS * 2 : 16;       // k-steps per accumulation block
-    f32x4 ga[AP], gb[BP];
+    f32x4 ga[KB][AP], gb[KB][BP];
     // k-position of the step being PREFETCHED, kept incrementally in scalar registers: (pf_c0 = first
     // channel of the 16-wide slice, pf_tap); `gload` is called for steps 0,1,2,... in order.
     int pf_tap = 0, pf_half = 0, pf_c32 = 0;
-    auto gload = [&](const int ks_, const int tap, const int c0) {
+    auto gload = [&](const int u, const int ks_, const int tap, const int c0) {
+        const bool live = ks_ < nks;                              // odd tail of a KB=2 pair: all-zero operands
         const int ky = (KS == 3) ? (tap * 11) >> 5 : 0;          // tap / 3 for tap in [0, 9)
         const int kx = (KS == 3) ? tap - ky * 3 : 0;
         const long long toff = ((long long)ky * a.W + kx) * a.in_cs + c0;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const bool v = (unsigned)(iy0[p] + ky) < (unsigned)a.H && (unsigned)(ix0[p] + kx) < (unsigned)a.W;
+            const bool v = live && (unsigned)(iy0[p] + ky) < (unsigned)a.H && (unsigned)(ix0[p] + kx) < (unsigned)a.W;
             const float* ptr = v ? a.in + (aoff[p] + toff) : a.zeros;
-            ga[p] = *reinterpret_cast<const f32x4*>(ptr);
+            ga[u][p] = *reinterpret_cast<const f32x4*>(ptr);
         }
 #pragma unroll
         for (int p = 0; p < BP; ++p)
-            if (BN % 64 == 0 || srow + 64 * p < BN) gb[p] = *reinterpret_cast<const f32x4*>(wrow[p] + ks_ * 16);
+            if (BN % 64 == 0 || srow + 64 * p < BN)
+                gb[u][p] = *reinterpret_cast<const f32x4*>(live ? wrow[p] + ks_ * 16 : a.zeros);
     };
     (void)steps_full;
-    auto lstore = [&](const int buf) {
-        float* ad = As + buf * (BM * 16) + st_off;
-        float* bd = Bs + buf * (BN * 16) + st_off;
+    auto lstore = [&](const int u, const int buf) {
+        float* ad = As + (buf * KB + u) * (BM * 16) + st_off;
+        float* bd = Bs + (buf * KB + u) * (BN * 16) + st_off;
 #pragma unroll
-        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(ad + p * 64 * 16) = ga[p];
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<f32x4*>(ad + p * 64 * 16) = ga[u][p];
 #pragma unroll
         for (int p = 0; p < BP; ++p)
-            if (BN % 64 == 0 || srow + 64 * p < BN) *reinterpret_cast<f32x4*>(bd + p * 64 * 16) = gb[p];
+            if (BN % 64 == 0 || srow + 64 * p < BN) *reinterpret_cast<f32x4*>(bd + p * 64 * 16) = gb[u][p];
     };
-    auto compute = [&](const int buf) {
-        const float* ab = As + buf * (BM * 16) + a_rd;
-        const float* bb = Bs + buf * (BN * 16) + b_rd;
+    auto compute = [&](const int u, const int buf) {
+        const float* ab = As + (buf * KB + u) * (BM * 16) + a_rd;
+        const float* bb = Bs + (buf * KB + u) * (BN * 16) + b_rd;
         f32x4 A[MF], B[NF];
 #pragma unroll
         for (int f = 0; f < MF; ++f) A[f] = *reinterpret_cast<const f32x4*>(ab + f * 256);
@@ -157,30 +160,40 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
         if (pf_c32 >= nfull) { ++pf_tap; }                                             \
         else { pf_half ^= 1; if (!pf_half) { if (++pf_tap == TAPS) { pf_tap = 0; ++pf_c32; } } } \
     } while (0)
-    gload(0, 0, 0);
-    PADEL_PF_ADVANCE();
-    lstore(0);
+    // super-step = KB consecutive k-steps between two barriers
+    const int nss = (nks + KB - 1) / KB;
+    constexpr int FLUSH_SS = FLUSH / KB;                    // FLUSH is even
+#pragma unroll
+    for (int u = 0; u < KB; ++u) { gload(u, u, pf_tap, pf_c32 * 32 + pf_half * 16); PADEL_PF_ADVANCE(); }
+#pragma unroll
+    for (int u = 0; u < KB; ++u) lstore(u, 0);
     __syncthreads();
-    int ks = 0;
-    while (ks < nks - 1) {
-        const int nb = min(FLUSH, nks - 1 - ks);
-        for (int i = 0; i < nb; ++i, ++ks) {
-            gload(ks + 1, pf_tap, pf_c32 * 32 + pf_half * 16);   // in flight under the MFMAs below
-            PADEL_PF_ADVANCE();
+    int ss = 0;
+    while (ss < nss - 1) {
+        const int nb = min(FLUSH_SS, nss - 1 - ss);
+        for (int i = 0; i < nb; ++i, ++ss) {
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {                 // in flight under the MFMAs below
+                gload(u, (ss + 1) * KB + u, pf_tap, pf_c32 * 32 + pf_half * 16);
+                PADEL_PF_ADVANCE();
+            }
             __builtin_amdgcn_sched_barrier(0);
-            compute(ks & 1);
+#pragma unroll
+            for (int u = 0; u < KB; ++u) compute(u, ss & 1);
             __builtin_amdgcn_sched_barrier(0);
-            lstore((ks + 1) & 1);
+#pragma unroll
+            for (int u = 0; u < KB; ++u) lstore(u, (ss + 1) & 1);
             __syncthreads();
         }
-        if (nb == FLUSH) {
+        if (nb == FLUSH_SS) {
 #pragma unroll
             for (int f = 0; f < MF; ++f)
 #pragma unroll
                 for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         }
     }
-    compute((nks - 1) & 1);
+#pragma unroll
+    for (int u = 0; u < KB; ++u) compute(u, (nss - 1) & 1);
 #pragma unroll
     for (int f = 0; f < MF; ++f)
 #pragma unroll
@@ -210,14 +223,22 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
     }
 }
 
+static int lds_kb() {
+    const char* e = getenv("PADEL_CONV_KB");
+    return e ? atoi(e) : 1;
+}
+
 template <int WM, int WN, int MF, int NF>
 static hipError_t launch_l(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
     dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
-    if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3>), grid, dim3(256), 0, s, a);
-    else if (a.ksize == 1) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1>), grid, dim3(256), 0, s, a);
+    const int kb = lds_kb();
+    if (a.ksize == 3 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 2>), grid, dim3(256), 0, s, a);
+    else if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 1>), grid, dim3(256), 0, s, a);
+    else if (a.ksize == 1 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 2>), grid, dim3(256), 0, s, a);
+    else if (a.ksize == 1) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 1>), grid, dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -268,7 +289,7 @@ int choose_conv_lds_variant(int M, int n16) {
     if (impl && impl[0] == 'l') {} else if (n16 == 3) return -1;   // 48 channels: direct 4x3 measured faster
     // relative speeds measured on MI355X (profiles/conv_lds_sweep_r1.txt): mid-size tiles at 3-4 waves/SIMD
     // beat the 128x128 tile (1 wave/SIMD cannot hide its own barriers)
-    static const float speed[] = {0.60f, 0.92f, 0.70f, 0.85f, 0.88f, 0.62f, 0.95f, 1.00f, 0.75f, 0.97f, 0.98f, 0.90f, 0.50f};
+    static const float speed[] = {0.60f, 0.92f, 0.70f, 0.85f, 0.88f, 0.62f, 0.99f, 1.00f, 0.75f, 1.05f, 1.03f, 0.92f, 0.50f};
     float best = -1.f;
     int bv = 0;
     for (const auto& v : lds_variants) {

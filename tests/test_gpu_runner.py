@@ -1,0 +1,58 @@
+"""GPU end-to-end: TrackingRunner drives PlayerTracker + PlayerKeypointsTracker + BallTracker over a synthetic
+clip exactly like the reference's main.py/runner.py (sequential trackers, batch sampler, JSON caches), and the
+returned objects match the oracle run through the same host glue."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import synth_weights, tracknet_ref as tr, yolov8_ref as ref
+from padel_analytics_amd import checkpoint, detections as D, video
+from padel_analytics_amd.trackers import (BallTracker, PlayerKeypointsTracker, PlayerTracker, Players, PlayersKeypoints,
+                                          TrackingRunner)
+from tests import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def test_runner_end_to_end(gpu_engine, tmp_path):
+    src = "synthetic://?n=20&h=360&w=640&fps=30&seed=5"
+    frames = list(video.get_video_frames_generator(src))
+    # checkpoints (synthetic, calibrated on the clip)
+    srcs = [f[..., ::-1] for f in frames[:4]]
+    sd_p = synth_weights.calibrated_state_dict("n", 80, None, ref.preprocess(srcs, 640), 0.5, seed=3)
+    checkpoint.save_checkpoint(tmp_path / "players.pt", sd_p, "detect", 80, None, "n", {0: "person"})
+    from PIL import Image
+    pil = [np.asarray(Image.fromarray(f[..., ::-1].copy()).resize((640, 640)))[..., ::-1] for f in frames[:4]]
+    sd_k = synth_weights.calibrated_state_dict("n", 1, (13, 3), ref.preprocess(pil, 640), 0.25, seed=4)
+    checkpoint.save_checkpoint(tmp_path / "pose.pt", sd_k, "pose", 1, (13, 3), "n", {0: "person"})
+    checkpoint.save_checkpoint(tmp_path / "tracknet.pt", tr.synth_tracknet_state_dict(9), "tracknet",
+                               param_dict={"seq_len": 8, "bg_mode": "concat"})
+    zone = D.PolygonZone(np.array([[40, 40], [600, 40], [600, 340], [40, 340]]), frame_resolution_wh=(640, 360))
+    players = PlayerTracker(str(tmp_path / "players.pt"), zone, batch_size=8, save_path=tmp_path / "players.json")
+    pose = PlayerKeypointsTracker(str(tmp_path / "pose.pt"), 640, batch_size=8, load_path=None, save_path=tmp_path / "pose.json")
+    ball = BallTracker(str(tmp_path / "tracknet.pt"), None, batch_size=8, median_max_sample_num=20, save_path=tmp_path / "ball.json")
+    runner = TrackingRunner([players, pose, ball], src, tmp_path / "out.mp4")
+    runner.run()
+    assert set(runner.timings) == {"players_tracker", "players_keypoints_tracker", "ball_tracker"}
+    assert len(players) == len(pose) == len(ball) == 20
+    # JSON caches round-trip through the reference wire format
+    for name, cls in (("players.json", Players), ("pose.json", PlayersKeypoints)):
+        data = json.loads((tmp_path / name).read_text())
+        assert len(data) == 20 and len(cls.from_json(data[0])) == len(data[0])
+    # a second runner with load_path set skips inference (runner.py:187-191)
+    players2 = PlayerTracker(str(tmp_path / "players.pt"), zone, batch_size=8, load_path=tmp_path / "players.json")
+    assert len(players2) == 20
+    # detections (before zone / ByteTrack) agree with the oracle on the first batch
+    res = players.model.predict_frames(np.stack(frames[:8]), 0.5, 0.7, 640, classes=[0], channel_reverse=False)
+    r32 = ref.predict(ref.YoloV8Ref(sd_p, 80, None), [f[..., ::-1] for f in frames[:8]], 0.5, 0.7, 640, classes=[0])
+    n = len(res)
+    boxes = np.zeros((n, 300, 6), np.float32); counts = np.zeros(n, np.int32)
+    for i, r in enumerate(res):
+        counts[i] = len(r.boxes); boxes[i, :counts[i]] = r.boxes.data
+    rep = parity.compare_batch(r32, boxes, None, counts, 0.5, 0.7)
+    assert rep["worst_px"] < 0.1 and rep["n"] > 0
+    # every kept player is inside the zone and carries a ByteTrack id after the first frames
+    ids = [p.id for pl in players.results.predictions[3:] for p in pl]
+    assert all(i is not None for i in ids)

@@ -30,7 +30,7 @@ SHAPES = [
 ]
 
 
-def run_one(mf, nf, shapes, reps):
+def run_one(mf, nf, shapes, reps, act=1):
     from padel_analytics_amd import engine as E, graph as G
     eng = E.default_engine(0)
     eng.set_profiling(True)
@@ -41,7 +41,7 @@ def run_one(mf, nf, shapes, reps):
         b0 = g.buf(0, cin)
         b1 = g.buf(1 if s == 2 else 0, G.pad16(cout))
         w = rng.normal(0, (2.0 / (cin * k * k)) ** 0.5, (cout, cin, k, k)).astype(np.float32)
-        g.conv((b0, 0, cin), (b1, 0), w, np.zeros(cout, np.float32), k, s, G.ACT_SILU)
+        g.conv((b0, 0, cin), (b1, 0), w, np.zeros(cout, np.float32), k, s, act)
         g.head_buf = (b1, -1, -1)
         m = E.Model(eng, g)
         m.set_max_batch(B)
@@ -61,12 +61,13 @@ if __name__ == "__main__":
     ap.add_argument("--one", nargs=2, type=int)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--act", type=int, default=1, help="0 none, 1 SiLU, 2 ReLU (epilogue cost probe)")
     ap.add_argument("--tiles", default="d4x3,d4x4,L0,L1,L2,L3,L4,L5,L6,L7,L8,L9,L10,L11",
                     help="dMxN = register-direct kernel with MFxNF fragments; Lk = LDS kernel variant k; auto")
     a = ap.parse_args()
     shapes = [s for s in SHAPES if (not a.shapes or any(t in s[0] for t in a.shapes.split(",")))]
     if a.one:
-        print("RESULT " + json.dumps(run_one(a.one[0], a.one[1], shapes, a.reps)))
+        print("RESULT " + json.dumps(run_one(a.one[0], a.one[1], shapes, a.reps, a.act)))
         sys.exit(0)
     table = {}
     for t in ["auto"] + a.tiles.split(","):
@@ -77,8 +78,11 @@ if __name__ == "__main__":
             env["PADEL_CONV_IMPL"] = "direct"
             env["PADEL_CONV_MF"], env["PADEL_CONV_NF"] = str(mf), str(nf)
         elif t.startswith("L"):
-            env["PADEL_CONV_LDS_VARIANT"] = t[1:]
-        p = subprocess.run([sys.executable, __file__, "--one", str(mf), str(nf), "--reps", str(a.reps), "--shapes", a.shapes],
+            v, _, kb = t[1:].partition("k")
+            env["PADEL_CONV_LDS_VARIANT"] = v
+            if kb:
+                env["PADEL_CONV_KB"] = kb
+        p = subprocess.run([sys.executable, __file__, "--one", str(mf), str(nf), "--reps", str(a.reps), "--shapes", a.shapes, "--act", str(a.act)],
                            env=env, capture_output=True, text=True)
         for line in p.stdout.splitlines():
             if line.startswith("RESULT "):
