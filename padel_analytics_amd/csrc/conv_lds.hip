@@ -60,6 +60,15 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
     const int m0 = mt * BM;
     const int f0 = nt * (WN * NF);           // first 16-channel fragment of this workgroup
 
+    const bool prio = (a.tune & 1) != 0;
+    if (a.tune & 2) {
+        // co-resident workgroups start together and run at the same rate: without an offset their
+        // non-MFMA phases (barrier, LDS refill) coincide and the matrix pipe idles
+        const int ph = (bid >> 3) & 3;
+        if (ph == 1) __builtin_amdgcn_s_sleep(4);
+        else if (ph == 2) __builtin_amdgcn_s_sleep(8);
+        else if (ph == 3) __builtin_amdgcn_s_sleep(12);
+    }
     const int HoWo = a.Ho * a.Wo;
     const int nfull = a.cin >> 5;
     const int steps_full = nfull * TAPS * 2;
@@ -142,6 +151,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
         for (int f = 0; f < MF; ++f) A[f] = *reinterpret_cast<const f32x4*>(ab + f * 256);
 #pragma unroll
         for (int j = 0; j < NF; ++j) B[j] = *reinterpret_cast<const f32x4*>(bb + j * 256);
+        if (prio) __builtin_amdgcn_s_setprio(1);          // keep the matrix pipe fed ahead of waves in their load phase
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -149,6 +159,7 @@ __global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NF; ++j)
                     part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[f][kk], B[j][kk], part[f][j], 0, 0, 0);
+        if (prio) __builtin_amdgcn_s_setprio(0);
     };
 
     // Nested loops: the inner loop (one accumulation block of FLUSH k-steps) contains nothing but

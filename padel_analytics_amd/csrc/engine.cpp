@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -430,6 +431,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.H = m->net_h >> ib.level; a.W = m->net_w >> ib.level; a.Ho = Ho; a.Wo = Wo;
             a.cin = o.cin; a.cout = o.cout; a.n16 = o.npad / 16; a.ksize = o.ksize; a.stride = o.stride; a.act = o.act;
             a.M = n * Ho * Wo;
+            a.tune = getenv("PADEL_CONV_TUNE") ? atoi(getenv("PADEL_CONV_TUNE")) : 1;   // default: s_setprio around MFMA clusters
             int mf = 0, nf = 0;
             const int lv = choose_conv_lds_variant(a.M, a.n16);
             if (lv >= 0) conv_lds_variant_shape(lv, &mf, &nf);      // profile rows carry BM, BN for the LDS kernel

@@ -30,6 +30,7 @@ struct ConvArgs {
     int act;
     int M;                // batch * Ho * Wo
     int n_mtiles;         // ceil(M / (4 * MF * 16))
+    int tune;             // bit 0: s_setprio(1) around MFMA clusters; bit 1: staggered workgroup start
 };
 
 // implicit-GEMM conv on v_mfma_f32_16x16x4_f32; MF in {1,2,4}, NF in {1..6}

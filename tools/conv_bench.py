@@ -78,10 +78,13 @@ if __name__ == "__main__":
             env["PADEL_CONV_IMPL"] = "direct"
             env["PADEL_CONV_MF"], env["PADEL_CONV_NF"] = str(mf), str(nf)
         elif t.startswith("L"):
-            v, _, kb = t[1:].partition("k")
+            body, _, tune = t[1:].partition("t")
+            v, _, kb = body.partition("k")
             env["PADEL_CONV_LDS_VARIANT"] = v
             if kb:
                 env["PADEL_CONV_KB"] = kb
+            if tune:
+                env["PADEL_CONV_TUNE"] = tune
         p = subprocess.run([sys.executable, __file__, "--one", str(mf), str(nf), "--reps", str(a.reps), "--shapes", a.shapes, "--act", str(a.act)],
                            env=env, capture_output=True, text=True)
         for line in p.stdout.splitlines():
