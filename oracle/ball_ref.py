@@ -121,3 +121,94 @@ def track(frames_bgr, tracknet, median_chw=None, batch: int = 4):
     h0, w0 = frames_bgr[0].shape[:2]
     x, y, v = decode_heat(heat, (w0 / WIDTH, h0 / HEIGHT))
     return x, y, v, heat
+
+
+# ------------------------------------------------------------------------------------------------
+# InpaintNet stage (ball_tracker.py:100-136, :525-673; dataset.py:387-429,493-503; predict.py:91-146)
+
+def generate_inpaint_mask_ref(y, vis_pred, th_h: float):
+    """Transcription of the control flow of ball_tracker.py:112-136."""
+    y = np.array(y)
+    vis_pred = np.array(vis_pred)
+    inpaint_mask = np.zeros_like(y)
+    i = j = 0
+    while j < len(vis_pred):
+        while i < len(vis_pred) - 1 and vis_pred[i] == 1:
+            i += 1
+        j = i
+        while j < len(vis_pred) - 1 and vis_pred[j] == 0:
+            j += 1
+        if j == i:
+            break
+        elif i == 0 and y[j] > th_h:
+            inpaint_mask[:j] = 1
+        elif (i > 1 and y[i - 1] > th_h) and (j < len(vis_pred) and y[j] > th_h):
+            inpaint_mask[i:j] = 1
+        i = j
+    return inpaint_mask.tolist()
+
+
+def inpaint_stage_ref(xs, ys, vs, img_w, img_h, inpaint_net, seq_len, batch_size=4):
+    """Streaming transcription of ball_tracker.py:525-673 with torch; returns {frame: (x, y, vis)} plus the
+    pre-truncation pixel values (for tolerance-aware comparison)."""
+    coor_th = 50.0 / math.sqrt(HEIGHT ** 2 + WIDTH ** 2)
+    img_scaler = (img_w / WIDTH, img_h / HEIGHT)
+    inpaint = generate_inpaint_mask_ref(ys, vs, th_h=img_h * 0.05)
+    T = len(xs)
+    ids, coors, masks = [], [], []
+    for i in range(T):
+        if i + seq_len <= T:
+            ids.append([(0, i + f) for f in range(seq_len)])
+            c = np.array([(xs[i + f], ys[i + f]) for f in range(seq_len)], np.float32)
+            c[:, 0] = c[:, 0] / img_w
+            c[:, 1] = c[:, 1] / img_h
+            coors.append(c)
+            masks.append(np.array([inpaint[i + f] for f in range(seq_len)], np.float32).reshape(-1, 1))
+    weight = torch.from_numpy(inpaint_ensemble_weight(seq_len))
+    num_sample, sample_count = len(ids), 0
+    buffer_size = seq_len - 1
+    si, fi = torch.arange(seq_len), torch.arange(seq_len - 1, -1, -1)
+    buf = torch.zeros((buffer_size, seq_len, 2), dtype=torch.float32)
+    out, raw = {}, {}
+    for b0 in range(0, num_sample, batch_size):
+        i_b = torch.tensor(ids[b0:b0 + batch_size])
+        coor_pred = torch.from_numpy(np.stack(coors[b0:b0 + batch_size])).float()
+        m = torch.from_numpy(np.stack(masks[b0:b0 + batch_size])).float()
+        ci = inpaint_net(coor_pred, m)
+        ci = ci * m + coor_pred * (1 - m)
+        th = (ci[:, :, 0] < coor_th) & (ci[:, :, 1] < coor_th)
+        ci[th] = 0.0
+        buf = torch.cat((buf, ci), 0)
+        e_i, e_c = [], []
+        for s in range(i_b.shape[0]):
+            if sample_count < buffer_size:
+                c = buf[si + s, fi].sum(0)
+                c /= (sample_count + 1)
+            else:
+                c = (buf[si + s, fi] * weight[:, None]).sum(0)
+            e_i.append(int(i_b[s][0][1])); e_c.append(c)
+            sample_count += 1
+            if sample_count == num_sample:
+                buf = torch.cat((buf, torch.zeros((buffer_size, seq_len, 2))), 0)
+                for frame_i in range(1, seq_len):
+                    c = buf[si + s + frame_i, fi].sum(0)
+                    c /= (seq_len - frame_i)
+                    e_i.append(int(i_b[-1][frame_i][1])); e_c.append(c)
+        e_c = torch.stack(e_c)
+        th = (e_c[:, 0] < coor_th) & (e_c[:, 1] < coor_th)
+        e_c[th] = 0.0
+        for f_i, c in zip(e_i, e_c.numpy()):
+            fx, fy = c[0] * WIDTH * img_scaler[0], c[1] * HEIGHT * img_scaler[1]
+            px, py = int(fx), int(fy)
+            out[f_i] = (px, py, 0 if (px == 0 and py == 0) else 1)
+            raw[f_i] = (float(fx), float(fy))
+        buf = buf[-buffer_size:]
+    return out, raw
+
+
+def inpaint_ensemble_weight(seq_len):
+    w = np.ones(seq_len, np.float32)
+    for i in range(math.ceil(seq_len / 2)):
+        w[i] = i + 1
+        w[seq_len - i - 1] = i + 1
+    return (torch.from_numpy(w) / torch.from_numpy(w).sum()).numpy()

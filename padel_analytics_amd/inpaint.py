@@ -1,0 +1,139 @@
+"""InpaintNet trajectory repair on the host (0.52 M parameters over length-16
+coordinate sequences — negligible FLOPs, kept on the CPU in numpy fp32).
+
+Restates, from the reference's ball tracker:
+* ``generate_inpaint_mask`` (``ball_tracker.py:100-136``): runs of invisible frames that are bounded by
+  visible frames lower than ``th_h`` pixels from the top get mask 1 (with the reference's edge rules: a run
+  starting at frame 0 only needs the closing frame; a run starting at frame 1 is never masked; a run reaching
+  the end of the clip is never masked);
+* the coordinate windows of ``BallTrajectoryDataset`` (``dataset.py:387-429,493-503``): length-L windows
+  sliding by 1, x / w and y / h normalisation in fp32;
+* ``InpaintNet`` (``models.py:101-130``): Conv1d(k=3, same) + LeakyReLU U-Net, sigmoid output;
+* blend / threshold / temporal ensemble / ``predict`` (``ball_tracker.py:572-657``, ``predict.py:91-146``).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+
+def generate_inpaint_mask(y, vis, th_h: float) -> np.ndarray:
+    y = np.asarray(y)
+    vis = np.asarray(vis)
+    n = len(vis)
+    mask = np.zeros(n, dtype=y.dtype if y.dtype.kind == "f" else np.int64)
+    i = 0
+    while i < n:
+        while i < n - 1 and vis[i] == 1:      # first invisible frame (stops at n-1 regardless)
+            i += 1
+        j = i
+        while j < n - 1 and vis[j] == 0:      # first visible frame after the run (or n-1)
+            j += 1
+        if j == i:
+            break
+        if i == 0:
+            if y[j] > th_h:
+                mask[:j] = 1
+        elif i > 1 and y[i - 1] > th_h and y[j] > th_h:
+            mask[i:j] = 1
+        i = j
+    return mask
+
+
+def ensemble_weight(seq_len: int) -> np.ndarray:
+    w = np.ones(seq_len, np.float32)
+    for i in range(math.ceil(seq_len / 2)):
+        w[i] = i + 1
+        w[seq_len - i - 1] = i + 1
+    return w / w.sum(dtype=np.float32)
+
+
+def temporal_ensemble(seq: np.ndarray, weight: np.ndarray) -> np.ndarray:
+    """seq: (S, L, ...) per-window predictions (window s covers frames s..s+L-1) -> (S + L - 1, ...):
+    frame g < L-1: mean of the available windows; L-1 <= g < S: sum_k weight[k] * seq[g-(L-1)+k][L-1-k];
+    the L-1 tail frames: means of the remaining windows (ball_tracker.py:449-509 / :600-650)."""
+    S, L = seq.shape[:2]
+    zero = np.zeros((L - 1,) + seq.shape[1:], np.float32)
+    buf = np.concatenate([zero, seq.astype(np.float32), zero], 0)          # row r <-> window r-(L-1)
+    k = np.arange(L)
+    out = []
+    wb = weight.reshape((L,) + (1,) * (seq.ndim - 2))
+    for g in range(S):
+        rows = buf[k + g, L - 1 - k]
+        if g < L - 1:
+            acc = rows[0].copy()
+            for r in rows[1:]:
+                acc = acc + r
+            out.append(acc / np.float32(g + 1))
+        else:
+            prod = rows * wb
+            acc = prod[0].copy()
+            for r in prod[1:]:
+                acc = acc + r
+            out.append(acc)
+    for fi in range(1, L):
+        rows = buf[k + (S - 1) + fi, L - 1 - k]
+        acc = rows[0].copy()
+        for r in rows[1:]:
+            acc = acc + r
+        out.append(acc / np.float32(L - fi))
+    return np.stack(out)
+
+
+class InpaintNetHost:
+    """numpy fp32 forward of the reference's InpaintNet (state_dict keys of models.py)."""
+
+    def __init__(self, state_dict):
+        self.sd = {k: np.asarray(v, np.float32) for k, v in state_dict.items()}
+
+    def _conv(self, x, name, act=True):
+        w, b = self.sd[f"{name}.weight"], self.sd[f"{name}.bias"]
+        xp = np.pad(x, ((0, 0), (0, 0), (1, 1)))
+        L = x.shape[2]
+        cols = np.stack([xp[:, :, t:t + L] for t in range(3)], 2)            # (N, Ci, 3, L)
+        y = np.einsum("oik,nikl->nol", w, cols, optimize=True).astype(np.float32) + b[None, :, None]
+        return np.where(y >= 0, y, np.float32(0.01) * y).astype(np.float32) if act else y
+
+    def forward(self, coor: np.ndarray, mask: np.ndarray) -> np.ndarray:
+        x = np.concatenate([coor, mask], 2).astype(np.float32).transpose(0, 2, 1)   # (N, 3, L)
+        x1 = self._conv(x, "down_1.conv")
+        x2 = self._conv(x1, "down_2.conv")
+        x3 = self._conv(x2, "down_3.conv")
+        x = self._conv(self._conv(x3, "buttleneck.conv_1.conv"), "buttleneck.conv_2.conv")
+        x = self._conv(np.concatenate([x, x3], 1), "up_1.conv")
+        x = self._conv(np.concatenate([x, x2], 1), "up_2.conv")
+        x = self._conv(np.concatenate([x, x1], 1), "up_3.conv")
+        x = self._conv(x, "predictor", act=False)
+        x = (1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.float32)
+        return x.transpose(0, 2, 1)
+
+
+def inpaint_trajectory(xs, ys, vs, img_w: int, img_h: int, net: InpaintNetHost, seq_len: int,
+                       width: int = 512, height: int = 288):
+    """TrackNet coordinates (source pixels, ints) -> repaired (x, y, visibility) per frame.
+    Frames the windows cannot cover (clips shorter than seq_len) come back as None."""
+    T = len(xs)
+    if T < seq_len:
+        return [None] * T
+    coor_th = 50.0 / math.sqrt(height ** 2 + width ** 2)
+    mask = generate_inpaint_mask(np.asarray(ys), np.asarray(vs), th_h=img_h * 0.05).astype(np.float32)
+    cx = np.asarray(xs, np.float32) / np.float32(img_w)
+    cy = np.asarray(ys, np.float32) / np.float32(img_h)
+    S = T - seq_len + 1
+    idx = np.arange(S)[:, None] + np.arange(seq_len)[None, :]
+    coor = np.stack([cx[idx], cy[idx]], 2).astype(np.float32)                # (S, L, 2)
+    m = mask[idx][..., None].astype(np.float32)                              # (S, L, 1)
+    out = net.forward(coor, m)
+    out = out * m + coor * (1 - m)
+    low = (out[:, :, 0] < coor_th) & (out[:, :, 1] < coor_th)
+    out[low] = 0.0
+    ens = temporal_ensemble(out, ensemble_weight(seq_len))                   # (T, 2)
+    low = (ens[:, 0] < coor_th) & (ens[:, 1] < coor_th)
+    ens[low] = 0.0
+    w_scaler, h_scaler = img_w / width, img_h / height
+    res = []
+    for g in range(T):
+        px, py = int(ens[g, 0] * width * w_scaler), int(ens[g, 1] * height * h_scaler)
+        res.append((px, py, 0 if (px == 0 and py == 0) else 1))
+    return res

@@ -12,7 +12,8 @@ host too, ``predict.py:21-26``).
 Deliberate differences: the window stream is contiguous across the median boundary
 (#10: the reference drops 7 windows for clips longer than ``median_range``); the tracker completes without an
 InpaintNet (#3: the reference raises KeyError); nothing hard-codes ``.cuda()``.  The InpaintNet stage
-(:525-673) is not implemented yet — ``inpainting_model_path`` is accepted and ignored with a message.
+(:525-673) runs on the host in numpy (``padel_analytics_amd/inpaint.py``; 0.5 M parameters over 16-long
+coordinate sequences).
 """
 from __future__ import annotations
 
@@ -22,7 +23,7 @@ from typing import Iterable, Optional, Type
 import numpy as np
 from scipy import ndimage
 
-from .. import checkpoint, engine as E, graph as G
+from .. import checkpoint, engine as E, graph as G, inpaint
 from .tracker import NoPredictSample, Object, Tracker
 
 
@@ -76,8 +77,13 @@ class BallTracker(Tracker):
         self.bg_mode = ck.param_dict.get("bg_mode", "concat")
         assert self.bg_mode == "concat", "only bg_mode='concat' (27 input channels) is wired, like the reference (:402,:443)"
         self.graph = G.build_tracknet(ck.state_dict)
+        self.inpaintnet = None
         if inpainting_model_path:
-            print(f"{self}: InpaintNet trajectory repair is not implemented in this build; using TrackNet output")
+            ick = checkpoint.load_checkpoint(inpainting_model_path)
+            if ick.task != "inpaintnet":
+                raise ValueError(f"{inpainting_model_path}: not an InpaintNet checkpoint")
+            self.inpaintnet_seq_len = int(ick.param_dict.get("seq_len", 16))
+            self.inpaintnet = inpaint.InpaintNetHost(ick.state_dict)
         self.batch_size = batch_size
         self.median_max_sample_num = median_max_sample_num
         self.median = median
@@ -159,6 +165,13 @@ class BallTracker(Tracker):
             consume(sess.feed(np.stack(c))[0])
         consume(sess.feed(None, flush=True)[0])
         sess.close()
+        if self.inpaintnet is not None and len(xs) == n_total:
+            fixed = inpaint.inpaint_trajectory(xs, ys, vs, w0, h0, self.inpaintnet, self.inpaintnet_seq_len,
+                                               self.WIDTH, self.HEIGHT)
+            if fixed and fixed[0] is not None:
+                xs, ys, vs = [f[0] for f in fixed], [f[1] for f in fixed], [f[2] for f in fixed]
+            else:                                  # clip shorter than one InpaintNet window: nothing is covered
+                xs, ys, vs = [], [], []
         out = []
         for i in range(n_total):
             if i < len(xs):

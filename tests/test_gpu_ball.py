@@ -81,3 +81,16 @@ def test_ball_tracker_plugin(gpu_engine, tmp_path):
             assert (b.xy[0], b.xy[1], b.visibility) == (x_ref[i], y_ref[i], v_ref[i]), i
     assert sum(v_ref) > 0
     t.to("cpu")
+    # with an InpaintNet checkpoint the trajectory goes through the host repair stage (ball_tracker.py:525-673)
+    from padel_analytics_amd import inpaint as ip
+    sdi = tr.synth_inpaintnet_state_dict(8)
+    ick = tmp_path / "InpaintNet_synth.pt"
+    checkpoint.save_checkpoint(ick, sdi, "inpaintnet", param_dict={"seq_len": 16})
+    t2 = BallTracker(str(ck), str(ick), batch_size=6, median_max_sample_num=T)
+    t2.video_info_post_init(video.VideoInfo(640, 360, 30, T))
+    balls2 = t2.predict_and_update(iter(frames), total_frames=T)
+    base = [(b.xy[0], b.xy[1], b.visibility) for b in balls]
+    want = ip.inpaint_trajectory([b[0] for b in base], [b[1] for b in base], [b[2] for b in base], 640, 360,
+                                 ip.InpaintNetHost(sdi), 16)
+    assert [(b.xy[0], b.xy[1], b.visibility) for b in balls2] == want
+    t2.to("cpu")
