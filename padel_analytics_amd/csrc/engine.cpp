@@ -762,6 +762,7 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
     std::vector<int32_t> row0, mode;
     std::vector<float> div;
     int nw = 0;
+    size_t prof_n = 0;
     if (n > 0) {
         // 1. resize the new frames (BGR -> RGB) into the ring; a feed never wraps more than once
         const uint8_t* src = frames;
@@ -783,9 +784,7 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
             aa.B = nw; aa.H = BALL_H; aa.W = BALL_W; aa.ring = b->ring; aa.first_slot = (int)(g_lo % b->ring);
             hipError_t r = launch_ball_assemble(aa, s);
             if (r != hipSuccess) PA_FAIL(e, "ball assemble launch failed: %s", hipGetErrorString(r));
-            size_t pi = 0;
-            if (run_ops(m, nw, &pi)) return 1;
-            finish_profile(m, pi);
+            if (run_ops(m, nw, &prof_n)) return 1;
             PA_HIP(e, hipMemcpyAsync(b->d_Y + (size_t)7 * HW * b->cs, m->bptr[m->d.head_buf[0]],
                                      (size_t)nw * HW * b->cs * sizeof(float), hipMemcpyDeviceToDevice, s));
             for (int i = 0; i < nw; ++i) {             // frame g = g_lo + i: rows i .. i+7 (row r <-> window g_lo - 7 + r)
@@ -829,6 +828,7 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
                                      HW * b->cs * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     PA_HIP(e, hipStreamSynchronize(s));
+    finish_profile(m, prof_n);
     *out_count = nout;
     return 0;
 }
