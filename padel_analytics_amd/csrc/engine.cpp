@@ -656,17 +656,23 @@ struct pa_ball {
 
 static const int BALL_H = 288, BALL_W = 512;
 
+void pa_ball_destroy(pa_ball* b);
+
 int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
     if (!m || !out) return 1;
     pa_engine* e = m->e;
     if (m->d.task != PA_TASK_TRACKNET) PA_FAIL(e, "pa_ball_create: not a TrackNet model");
     if (m->bufs[0].channels != 32) PA_FAIL(e, "pa_ball_create: TrackNet input buffer must have 32 channels (27 + pad)");
     PA_HIP(e, hipSetDevice(e->dev));
+    if (src_h <= 0 || src_w <= 0 || (src_h == BALL_H && src_w == BALL_W))
+        PA_FAIL(e, "pa_ball_create: unsupported source size %dx%d", src_w, src_h);
+    if (m->bufs[m->d.head_buf[0]].channels < 8)
+        PA_FAIL(e, "pa_ball_create: TrackNet output has %d channels (< 8)", m->bufs[m->d.head_buf[0]].channels);
     pa_ball* b = new pa_ball();
     b->m = m; b->h = src_h; b->w = src_w; b->B = m->max_batch; b->ring = b->B + 7;
     b->cs = m->bufs[m->d.head_buf[0]].channels;
-    if (b->cs < 8) { delete b; PA_FAIL(e, "pa_ball_create: TrackNet output has %d channels (< 8)", b->cs); }
     const size_t HW = (size_t)BALL_H * BALL_W;
+    struct Guard { pa_ball* b; bool ok = false; ~Guard() { if (!ok) pa_ball_destroy(b); } } guard{b};
     PA_HIP(e, hipMalloc((void**)&b->d_src, (size_t)b->B * src_h * src_w * 3));
     PA_HIP(e, hipMalloc((void**)&b->d_tmp, (size_t)b->B * src_h * BALL_W * 3));
     PA_HIP(e, hipMalloc((void**)&b->d_small, (size_t)b->ring * HW * 3));
@@ -686,6 +692,7 @@ int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
     std::vector<int32_t> bb, kk;
     if (src_w != BALL_W) { b->hks = pil_coeffs(src_w, BALL_W, bb, kk); PA_HIP(e, upload(e, &b->d_hb, bb)); PA_HIP(e, upload(e, &b->d_hk, kk)); }
     if (src_h != BALL_H) { b->vks = pil_coeffs(src_h, BALL_H, bb, kk); PA_HIP(e, upload(e, &b->d_vb, bb)); PA_HIP(e, upload(e, &b->d_vk, kk)); }
+    guard.ok = true;
     *out = b;
     return 0;
 }
@@ -707,7 +714,6 @@ static int ball_resize(pa_ball* b, const uint8_t* src, int n, uint8_t* dst, int 
     const uint8_t* cur = src;
     int cw = b->w;
     hipError_t r = hipSuccess;
-    if (b->w == BALL_W && b->h == BALL_H) PA_FAIL(e, "ball path: a source that is already 512x288 is not supported yet");
     if (b->w != BALL_W) {
         ResamplePassArgs a{};
         const bool last = (b->h == BALL_H);

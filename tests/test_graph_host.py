@@ -46,3 +46,13 @@ def test_conv_flops_accounting():
     # executed FLOPs (with the 16-padding of head widths) are within 1% of the algorithmic count
     algo = yolo_arch.conv_flops(yolo_arch.conv_inventory("n", 80, None, 384, 640))
     assert abs(g.conv_flops(384, 640) / algo - 1) < 0.01
+
+
+def test_graph_layout_is_weight_independent():
+    """bench.py / dist: ranks != 0 build the op list from uncalibrated weights and receive rank 0's blob over
+    RCCL — the layout (ops, buffers, offsets, blob length) must depend on shapes only."""
+    for scale, nc, kpt in (("n", 1, None), ("n", 1, (13, 3))):
+        a = G.build_yolov8(yolo_arch.synth_state_dict(scale, nc, kpt, seed=0), nc, kpt)
+        b = G.build_yolov8(yolo_arch.synth_state_dict(scale, nc, kpt, seed=9, cls_bias=1.5, gain=0.7), nc, kpt)
+        assert a.n_floats == b.n_floats and a.bufs == b.bufs and a.ops == b.ops and a.head_buf == b.head_buf
+        assert not np.array_equal(a.blob(), b.blob())
