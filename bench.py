@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile (CSV) of the roofline pass here")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="also time the same steps with the frames in pageable host memory (PCIe-inclusive rate)")
     return ap.parse_args()
 
 
@@ -195,6 +197,21 @@ def main():
             "detections_per_step_rank0": ndet,
         },
     }
+
+    if a.host_frames:
+        def step_host():
+            for name in names:
+                cfg = TRACKERS[name]
+                models[name].yolo_infer(frames, B, H, W, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7,
+                                        classes=cfg["classes"], pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX,
+                                        channel_reverse=cfg["rev"])
+        step_host()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            step_host()
+        fence()
+        out["config"]["host_frames_frames_per_s_rank0"] = round(B * a.steps / (time.perf_counter() - t1), 2)
 
     if rank == 0 and not a.no_roofline:
         # ---- roofline of the dominant kernel (conv3x3 implicit GEMM, fp32 MFMA): HIP events recorded on
