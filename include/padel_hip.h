@@ -143,10 +143,16 @@ void pa_ball_destroy(pa_ball* b);
  * the stream state                                                                                     */
 int pa_ball_set_background(pa_ball* b, const uint8_t* median_rgb);
 /* frames: n x src_h x src_w x 3 uint8 BGR (n <= the model's max_batch).  flush != 0 after the last
- * frames of the clip emits the 7 tail frames.  out_masks capacity: (n + 7) x 288 x 512 bytes;
- * out_heat (optional, may be NULL): (n + 7) x 288 x 512 fp32 ensembled heat maps.                      */
+ * frames of the clip emits the 7 tail frames.  Outputs, each optional (NULL) but at least one of
+ * masks / rects: out_masks (n + 7) x 288 x 512 bytes; out_heat (n + 7) x 288 x 512 fp32 ensembled heat
+ * maps; out_rects (n + 7) x 4 int32 {x, y, w, h} = predict_location (predict.py:7-39) of each mask
+ * (largest bounding rectangle among the 8-connected components; all zero: empty mask; w = -1: too many
+ * foreground pixels for the device list, use the mask).                                               */
 int pa_ball_feed(pa_ball* b, const uint8_t* frames_bgr, int n, int frames_on_device, int flush,
-                 uint8_t* out_masks, float* out_heat, int* out_count);
+                 uint8_t* out_masks, float* out_heat, int32_t* out_rects, int* out_count);
+
+/* predict_location on caller-supplied masks (n x 288 x 512 uint8, n <= max_batch + 7) -> n x 4 {x, y, w, h} */
+int pa_ball_locate(pa_ball* b, const uint8_t* masks, int n, int32_t* out_rects);
 
 /* ---- profiling (bench.py roofline): per-op device times of the LAST inference, HIP events on the
  * engine's stream.  kinds/ms/flops are host arrays of capacity cap; returns the number of records. */

@@ -651,6 +651,7 @@ struct pa_ball {
     int32_t *d_hb = nullptr, *d_hk = nullptr, *d_vb = nullptr, *d_vk = nullptr;
     int hks = 0, vks = 0;
     int32_t *d_row0 = nullptr, *d_mode = nullptr; float* d_div = nullptr;
+    int32_t *d_label = nullptr, *d_bbox = nullptr, *d_rect = nullptr;
     int cs = 0;
 };
 
@@ -684,6 +685,9 @@ int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
     PA_HIP(e, hipMalloc((void**)&b->d_row0, (b->B + 7) * sizeof(int32_t)));
     PA_HIP(e, hipMalloc((void**)&b->d_mode, (b->B + 7) * sizeof(int32_t)));
     PA_HIP(e, hipMalloc((void**)&b->d_div, (b->B + 7) * sizeof(float)));
+    PA_HIP(e, hipMalloc((void**)&b->d_label, (size_t)(b->B + 7) * HW * sizeof(int32_t)));
+    PA_HIP(e, hipMalloc((void**)&b->d_bbox, (size_t)(b->B + 7) * 4 * HW * sizeof(int32_t)));
+    PA_HIP(e, hipMalloc((void**)&b->d_rect, (size_t)(b->B + 7) * 4 * sizeof(int32_t)));
     std::vector<float> lut(256);
     for (int i = 0; i < 256; ++i) lut[i] = (float)((double)i / 255.0);     // float64 division, then .float()
     PA_HIP(e, hipMalloc((void**)&b->d_lut, 256 * sizeof(float)));
@@ -702,7 +706,7 @@ void pa_ball_destroy(pa_ball* b) {
     hipSetDevice(b->m->e->dev);
     hipStreamSynchronize(b->m->e->stream);
     void* ptrs[] = {b->d_src, b->d_tmp, b->d_small, b->d_med_src, b->d_med, b->d_mask, b->d_heat, b->d_Y, b->d_lut,
-                    b->d_hb, b->d_hk, b->d_vb, b->d_vk, b->d_row0, b->d_mode, b->d_div};
+                    b->d_hb, b->d_hk, b->d_vb, b->d_vk, b->d_row0, b->d_mode, b->d_div, b->d_label, b->d_bbox, b->d_rect};
     for (void* p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -748,8 +752,8 @@ int pa_ball_set_background(pa_ball* b, const uint8_t* median_rgb) {
 }
 
 int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int flush, uint8_t* out_masks,
-                 float* out_heat, int* out_count) {
-    if (!b || !out_masks || !out_count) return 1;
+                 float* out_heat, int32_t* out_rects, int* out_count) {
+    if (!b || (!out_masks && !out_rects) || !out_count) return 1;
     pa_model* m = b->m;
     pa_engine* e = m->e;
     if (!b->have_bg) PA_FAIL(e, "pa_ball_feed: set the background first");
@@ -823,7 +827,14 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
         ea.threshold = 0.5f; ea.heat = out_heat ? b->d_heat : nullptr; ea.mask = b->d_mask;
         hipError_t r = launch_ball_ensemble(ea, nout, s);
         if (r != hipSuccess) PA_FAIL(e, "ball ensemble launch failed: %s", hipGetErrorString(r));
-        PA_HIP(e, hipMemcpyAsync(out_masks, b->d_mask, (size_t)nout * HW, hipMemcpyDeviceToHost, s));
+        if (out_rects) {
+            BallLocateArgs la{};
+            la.mask = b->d_mask; la.label = b->d_label; la.bbox = b->d_bbox; la.rect = b->d_rect; la.H = BALL_H; la.W = BALL_W;
+            r = launch_ball_locate(la, nout, s);
+            if (r != hipSuccess) PA_FAIL(e, "ball locate launch failed: %s", hipGetErrorString(r));
+            PA_HIP(e, hipMemcpyAsync(out_rects, b->d_rect, (size_t)nout * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        }
+        if (out_masks) PA_HIP(e, hipMemcpyAsync(out_masks, b->d_mask, (size_t)nout * HW, hipMemcpyDeviceToHost, s));
         if (out_heat) PA_HIP(e, hipMemcpyAsync(out_heat, b->d_heat, (size_t)nout * HW * sizeof(float), hipMemcpyDeviceToHost, s));
     }
     // 3. carry the last 7 window rows to the front for the next feed: rows [nw, nw+7) -> [0, 7).  The ranges
@@ -836,6 +847,23 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
     PA_HIP(e, hipStreamSynchronize(s));
     finish_profile(m, prof_n);
     *out_count = nout;
+    return 0;
+}
+
+int pa_ball_locate(pa_ball* b, const uint8_t* masks, int n, int32_t* out_rects) {
+    if (!b || !masks || !out_rects) return 1;
+    pa_engine* e = b->m->e;
+    if (n < 1 || n > b->B + 7) PA_FAIL(e, "pa_ball_locate: n = %d (max %d)", n, b->B + 7);
+    PA_HIP(e, hipSetDevice(e->dev));
+    hipStream_t s = e->stream;
+    const size_t HW = (size_t)BALL_H * BALL_W;
+    PA_HIP(e, hipMemcpyAsync(b->d_mask, masks, (size_t)n * HW, hipMemcpyHostToDevice, s));
+    BallLocateArgs la{};
+    la.mask = b->d_mask; la.label = b->d_label; la.bbox = b->d_bbox; la.rect = b->d_rect; la.H = BALL_H; la.W = BALL_W;
+    hipError_t r = launch_ball_locate(la, n, s);
+    if (r != hipSuccess) PA_FAIL(e, "ball locate launch failed: %s", hipGetErrorString(r));
+    PA_HIP(e, hipMemcpyAsync(out_rects, b->d_rect, (size_t)n * 4 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PA_HIP(e, hipStreamSynchronize(s));
     return 0;
 }
 

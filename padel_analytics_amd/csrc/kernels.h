@@ -150,4 +150,13 @@ struct BallEnsembleArgs {
 };
 hipError_t launch_ball_ensemble(const BallEnsembleArgs& a, int nout, hipStream_t s);
 
+struct BallLocateArgs {
+    const uint8_t* mask;     // [nout][H][W] 255 / 0
+    int32_t* label;          // scratch [nout][H][W]
+    int32_t* bbox;           // scratch [nout][4][H][W]
+    int32_t* rect;           // out [nout][4] = x, y, w, h  (w = -1: foreground list overflow)
+    int H, W;
+};
+hipError_t launch_ball_locate(const BallLocateArgs& a, int nout, hipStream_t s);
+
 }  // namespace padel

@@ -71,3 +71,106 @@ hipError_t launch_ball_ensemble(const BallEnsembleArgs& a, int nout, hipStream_t
 }
 
 }  // namespace padel
+
+// ------------------------------------------------------------------------------------------------
+// ball_locate_kernel — predict_location (reference predict.py:7-39) on the device: 8-connected components of
+// the thresholded heat map, bounding rectangle of each, the one of maximal w*h wins; ties go to the component
+// discovered LAST in raster order (cv2.findContours returns contours in reverse discovery order and the
+// reference keeps the first maximum with a strict '>').
+//
+// Masks are almost empty (a ball is ~100 pixels), so the kernel works on a sparse list: (a) compact the
+// foreground pixel indices into LDS, (b) label[p] = p+1, (c) iterate "min over the 8 neighbours" + one pointer
+// jump until nothing changes (labels converge to the smallest raster index of the component = the pixel a raster
+// scan discovers first), (d) per-root bounding boxes with atomics, (e) arg-max of (area, root index).
+// One 1024-thread workgroup per frame; rect = {x, y, w, h}, all zero when the mask is empty, w = -1 when the
+// foreground does not fit the LDS list (caller falls back to the mask).
+#define LOC_THREADS 1024
+#define LOC_CAP 12288
+
+namespace padel {
+
+__global__ void __launch_bounds__(LOC_THREADS) ball_locate_kernel(const BallLocateArgs a) {
+    __shared__ int fg[LOC_CAP];
+    __shared__ int n_fg;
+    __shared__ int changed;
+    __shared__ unsigned long long best;
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    const uint8_t* mask = a.mask + (long long)o * HW;
+    int* label = a.label + (long long)o * HW;
+    int* bx0 = a.bbox + (long long)o * 4 * HW;
+    int* bx1 = bx0 + HW; int* by0 = bx1 + HW; int* by1 = by0 + HW;
+    if (tid == 0) { n_fg = 0; best = 0ull; }
+    __syncthreads();
+    for (int p4 = tid; p4 < HW / 4; p4 += LOC_THREADS) {
+        const uchar4 m = reinterpret_cast<const uchar4*>(mask)[p4];
+        const uint8_t mm[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (mm[k]) {
+                const int slot = atomicAdd(&n_fg, 1);
+                if (slot < LOC_CAP) fg[slot] = p4 * 4 + k;
+            }
+    }
+    __syncthreads();
+    const int n = n_fg;
+    int* rect = a.rect + o * 4;
+    if (n == 0) { if (tid == 0) { rect[0] = rect[1] = rect[2] = rect[3] = 0; } return; }
+    if (n > LOC_CAP) { if (tid == 0) { rect[0] = rect[1] = rect[3] = 0; rect[2] = -1; } return; }
+    for (int i = tid; i < n; i += LOC_THREADS) label[fg[i]] = fg[i] + 1;
+    __syncthreads();
+    for (int it = 0; it < 4 * (H + W); ++it) {            // upper bound on the geodesic diameter; exits early
+        if (tid == 0) changed = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += LOC_THREADS) {
+            const int p = fg[i];
+            const int y = p / W, x = p - y * W;
+            const int l = label[p];
+            int m = l;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if ((dy | dx) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W && mask[yy * W + xx])
+                        m = min(m, label[yy * W + xx]);
+                }
+            m = min(m, label[m - 1]);                     // pointer jump towards the root
+            if (m < l) { atomicMin(&label[p], m); changed = 1; }
+        }
+        __syncthreads();
+        if (!changed) break;
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += LOC_THREADS) {
+        const int p = fg[i];
+        if (label[p] == p + 1) { const int y = p / W, x = p - y * W; bx0[p] = x; bx1[p] = x; by0[p] = y; by1[p] = y; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += LOC_THREADS) {
+        const int p = fg[i];
+        const int r = label[p] - 1;
+        const int y = p / W, x = p - y * W;
+        atomicMin(&bx0[r], x); atomicMax(&bx1[r], x); atomicMin(&by0[r], y); atomicMax(&by1[r], y);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += LOC_THREADS) {
+        const int p = fg[i];
+        if (label[p] == p + 1) {
+            const unsigned long long area = (unsigned long long)(bx1[p] - bx0[p] + 1) * (unsigned long long)(by1[p] - by0[p] + 1);
+            atomicMax(&best, (area << 32) | (unsigned)(p + 1));
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int p = (int)(best & 0xffffffffull) - 1;
+        rect[0] = bx0[p]; rect[1] = by0[p]; rect[2] = bx1[p] - bx0[p] + 1; rect[3] = by1[p] - by0[p] + 1;
+    }
+}
+
+hipError_t launch_ball_locate(const BallLocateArgs& a, int nout, hipStream_t s) {
+    hipLaunchKernelGGL(ball_locate_kernel, dim3(nout), dim3(LOC_THREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace padel

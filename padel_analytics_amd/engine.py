@@ -62,6 +62,7 @@ ABI_SYMBOLS = [
     "pa_model_create", "pa_model_destroy", "pa_model_set_max_batch", "pa_yolo_infer", "pa_yolo_head_shape",
     "pa_yolo_read_head", "pa_tracknet_infer", "pa_engine_set_profiling", "pa_model_last_profile",
     "pa_model_profile_text", "pa_ball_create", "pa_ball_destroy", "pa_ball_set_background", "pa_ball_feed",
+    "pa_ball_locate",
 ]
 
 
@@ -108,7 +109,8 @@ def load_library():
     lib.pa_ball_destroy.argtypes = [vp]
     lib.pa_ball_destroy.restype = None
     lib.pa_ball_set_background.argtypes = [vp, vp]
-    lib.pa_ball_feed.argtypes = [vp, vp, i32, i32, i32, vp, vp, C.POINTER(i32)]
+    lib.pa_ball_feed.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]
+    lib.pa_ball_locate.argtypes = [vp, vp, i32, vp]
     if lib.pa_abi_version() != 1:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
@@ -304,22 +306,36 @@ class BallSession:
         assert m.shape == (self.src_h, self.src_w, 3), m.shape
         self.model.engine._check(self.model.engine.lib.pa_ball_set_background(self.handle, m.ctypes.data))
 
-    def feed(self, frames_bgr: Optional[np.ndarray], flush: bool = False, want_heat: bool = False):
+    def feed(self, frames_bgr: Optional[np.ndarray], flush: bool = False, want_heat: bool = False,
+             want_rects: bool = False, want_masks: bool = True):
         """frames_bgr: (n, h, w, 3) uint8 with n <= max_feed (or None with flush=True).
-        Returns (masks (k,288,512) uint8, heat (k,288,512) fp32 | None): outputs for the next k frames in order."""
+        Returns (masks (k,288,512) uint8 | None, heat (k,288,512) fp32 | None[, rects (k,4) int32]): outputs for
+        the next k frames in order; rects = predict_location of each mask computed on the device."""
         n = 0 if frames_bgr is None else len(frames_bgr)
         ptr = None
         if n:
             frames_bgr = np.ascontiguousarray(frames_bgr, np.uint8)
             assert frames_bgr.shape == (n, self.src_h, self.src_w, 3) and n <= self.max_feed
             ptr = frames_bgr.ctypes.data
-        masks = np.empty((n + 7, self.H, self.W), np.uint8)
+        masks = np.empty((n + 7, self.H, self.W), np.uint8) if (want_masks or not want_rects) else None
         heat = np.empty((n + 7, self.H, self.W), np.float32) if want_heat else None
+        rects = np.empty((n + 7, 4), np.int32) if want_rects else None
         cnt = C.c_int(0)
         self.model.engine._check(self.model.engine.lib.pa_ball_feed(
-            self.handle, ptr, n, 0, int(flush), masks.ctypes.data, heat.ctypes.data if want_heat else None, C.byref(cnt)))
+            self.handle, ptr, n, 0, int(flush), masks.ctypes.data if masks is not None else None,
+            heat.ctypes.data if want_heat else None, rects.ctypes.data if want_rects else None, C.byref(cnt)))
         k = cnt.value
-        return masks[:k], (heat[:k] if want_heat else None)
+        out = (None if masks is None else masks[:k], heat[:k] if want_heat else None)
+        return out + (rects[:k],) if want_rects else out
+
+    def locate(self, masks: np.ndarray) -> np.ndarray:
+        """predict_location of (n,288,512) uint8 masks on the device -> (n,4) int32 {x, y, w, h}."""
+        masks = np.ascontiguousarray(masks, np.uint8)
+        n = len(masks)
+        assert masks.shape == (n, self.H, self.W)
+        rects = np.empty((n, 4), np.int32)
+        self.model.engine._check(self.model.engine.lib.pa_ball_locate(self.handle, masks.ctypes.data, n, rects.ctypes.data))
+        return rects
 
     def close(self):
         if self.handle:

@@ -5,9 +5,9 @@ Hot path (``predict_frames`` :373-523): background median of the first ``median_
 every frame Pillow-resized to 512x288 -> 8-frame sliding windows (+ background = 27 channels) -> TrackNet ->
 temporal ensemble of the 8 overlapping outputs -> threshold .5 -> largest bounding rectangle of the connected
 components -> centre scaled to source pixels.  On the GPU (``pa_ball_*``): resize, window assembly, network,
-ensemble, threshold.  On the host: the median (numpy, like the reference; device histogram median is "next",
-SURVEY.md §2.1 K11) and the connected-component rectangle pick (scipy.ndimage; the reference uses cv2 on the
-host too, ``predict.py:21-26``).
+ensemble, threshold and the connected-component rectangle pick (``ball_locate_kernel``; the scipy.ndimage
+``predict_location`` below is only the fallback for masks with more than 12 288 foreground pixels).  On the host:
+the median (numpy, like the reference; device histogram median is "next").
 
 Deliberate differences: the window stream is contiguous across the median boundary
 (#10: the reference drops 7 windows for clips longer than ``median_range``); the tracker completes without an
@@ -137,9 +137,11 @@ class BallTracker(Tracker):
         sess.set_background(median)
         xs, ys, vs = [], [], []
 
-        def consume(masks):
-            for m in masks:
-                x, y, w, h = predict_location(m)
+        def consume(res):
+            masks, _, rects = res
+            for i, (x, y, w, h) in enumerate(rects.tolist()):
+                if w < 0:                          # foreground overflowed the device list: host fallback on the mask
+                    x, y, w, h = predict_location(masks[i])
                 cx, cy = int(x + w / 2), int(y + h / 2)
                 cx, cy = int(cx * w_scaler), int(cy * h_scaler)
                 xs.append(cx); ys.append(cy); vs.append(0 if (cx == 0 and cy == 0) else 1)
@@ -162,8 +164,8 @@ class BallTracker(Tracker):
         n_total = 0
         for c in chunks():
             n_total += len(c)
-            consume(sess.feed(np.stack(c))[0])
-        consume(sess.feed(None, flush=True)[0])
+            consume(sess.feed(np.stack(c), want_rects=True))
+        consume(sess.feed(None, flush=True, want_rects=True))
         sess.close()
         if self.inpaintnet is not None and len(xs) == n_total:
             fixed = inpaint.inpaint_trajectory(xs, ys, vs, w0, h0, self.inpaintnet, self.inpaintnet_seq_len,

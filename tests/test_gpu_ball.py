@@ -45,13 +45,16 @@ def test_ball_session_matches_oracle(gpu_engine, T, feed):
     m.set_max_batch(feed)
     sess = E.BallSession(m, 360, 640)
     sess.set_background(np.median(np.array([f[..., ::-1] for f in frames]), 0).astype("uint8"))
-    masks, heats = [], []
+    masks, heats, rects = [], [], []
     for i in range(0, T, feed):
-        mk, ht = sess.feed(frames[i:i + feed], want_heat=True)
-        masks.append(mk); heats.append(ht)
-    mk, ht = sess.feed(None, flush=True, want_heat=True)
-    masks.append(mk); heats.append(ht)
-    masks, heat = np.concatenate(masks), np.concatenate(heats)
+        mk, ht, rc = sess.feed(frames[i:i + feed], want_heat=True, want_rects=True)
+        masks.append(mk); heats.append(ht); rects.append(rc)
+    mk, ht, rc = sess.feed(None, flush=True, want_heat=True, want_rects=True)
+    masks.append(mk); heats.append(ht); rects.append(rc)
+    masks, heat, rects = np.concatenate(masks), np.concatenate(heats), np.concatenate(rects)
+    # device predict_location == the oracle's, on the masks the device actually produced
+    for i in range(T):
+        assert tuple(rects[i]) == tuple(br.predict_location(masks[i])), i
     assert heat.shape == heat_ref.shape == (T, 288, 512)
     err = np.abs(heat - heat_ref).max()
     assert err < 2e-5, f"ensembled heat map max abs err {err:.2e}"
@@ -61,6 +64,41 @@ def test_ball_session_matches_oracle(gpu_engine, T, feed):
     assert want_mask.any(), "calibration produced empty masks"
     sess.close()
     m.close()
+
+
+def test_ball_locate_kernel_synthetic_masks(gpu_engine):
+    """Connected-component pick on crafted masks: empty, single blob, diagonal (8-connectivity) links, equal-area
+    ties (the component discovered last in raster order wins), a snake, blobs touching the borders, random
+    speckle — against the oracle's predict_location."""
+    m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1)))
+    m.set_max_batch(8)
+    sess = E.BallSession(m, 360, 640)
+    rng = np.random.default_rng(0)
+    masks = np.zeros((15, 288, 512), np.uint8)
+    masks[1, 100:110, 200:215] = 255
+    masks[2, 10:14, 20:29] = 255; masks[2, 100:103, 300:303] = 255; masks[2, 103, 303] = 255      # diagonal link
+    masks[3, 5:9, 5:9] = 255; masks[3, 200:204, 400:404] = 255                                     # equal areas: last wins
+    masks[4, 50:54, 60:64] = 255; masks[4, 50:54, 300:304] = 255; masks[4, 250:252, 10:18] = 255   # 16,16,16
+    for i in range(60):                                                                             # snake
+        masks[5, 20 + i, 30 + (i % 7)] = 255
+        masks[5, 20 + i, 30 + ((i + 1) % 7)] = 255
+    masks[6, 0:3, 0:5] = 255; masks[6, 285:288, 507:512] = 255; masks[6, 0:2, 509:512] = 255       # borders
+    masks[7] = (rng.uniform(size=(288, 512)) > 0.97) * 255                                          # speckle (~4400 px)
+    masks[8, 140:150, :] = 255                                                                      # full-width bar
+    masks[9] = 255                                                                                  # overflow -> w = -1
+    masks[10, 287, 511] = 255
+    yy, xx = np.mgrid[0:288, 0:512]
+    masks[11] = (((yy - 144) ** 2 + (xx - 256) ** 2) < 40 ** 2) * 255                              # disc (~5000 px)
+    masks[12] = ((yy + xx) % 37 == 0) * 255                                                         # diagonal stripes
+    masks[13, ::2, 100] = 255                                                                       # disconnected column
+    masks[14, 30:60, 40:45] = 255; masks[14, 30:35, 40:90] = 255                                   # L shape
+    rects = np.concatenate([sess.locate(masks[:8]), sess.locate(masks[8:])])
+    for i in range(len(masks)):
+        if i == 9:
+            assert rects[i][2] == -1
+            continue
+        assert tuple(rects[i]) == tuple(br.predict_location(masks[i])), (i, rects[i], br.predict_location(masks[i]))
+    sess.close(); m.close()
 
 
 def test_ball_tracker_plugin(gpu_engine, tmp_path):
