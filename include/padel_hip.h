@@ -142,6 +142,11 @@ void pa_ball_destroy(pa_ball* b);
 /* background: src_h x src_w x 3 uint8 RGB (np.median(...).astype(uint8), iterable.py:70-78); also resets
  * the stream state                                                                                     */
 int pa_ball_set_background(pa_ball* b, const uint8_t* median_rgb);
+/* background = per-pixel median of the first n BGR frames, computed on the device with np.median + uint8
+ * truncation semantics (iterable.py:59-78); out_median_rgb (optional) receives the src_h x src_w x 3 RGB
+ * median; also resets the stream state                                                                 */
+int pa_ball_background_from_frames(pa_ball* b, const uint8_t* frames_bgr, int n, int frames_on_device,
+                                   uint8_t* out_median_rgb);
 /* frames: n x src_h x src_w x 3 uint8 BGR (n <= the model's max_batch).  flush != 0 after the last
  * frames of the clip emits the 7 tail frames.  Outputs, each optional (NULL) but at least one of
  * masks / rects: out_masks (n + 7) x 288 x 512 bytes; out_heat (n + 7) x 288 x 512 fp32 ensembled heat

@@ -738,17 +738,47 @@ static int ball_resize(pa_ball* b, const uint8_t* src, int n, uint8_t* dst, int 
     return 0;
 }
 
+static int ball_finish_background(pa_ball* b);
+
 int pa_ball_set_background(pa_ball* b, const uint8_t* median_rgb) {
     if (!b || !median_rgb) return 1;
     pa_engine* e = b->m->e;
     PA_HIP(e, hipSetDevice(e->dev));
     PA_HIP(e, hipMemcpyAsync(b->d_med_src, median_rgb, (size_t)b->h * b->w * 3, hipMemcpyHostToDevice, e->stream));
+    return ball_finish_background(b);
+}
+
+static int ball_finish_background(pa_ball* b) {
+    pa_engine* e = b->m->e;
     if (ball_resize(b, b->d_med_src, 1, b->d_med, 0)) return 1;
     PA_HIP(e, hipMemsetAsync(b->d_Y, 0, (size_t)(b->B + 14) * BALL_H * BALL_W * b->cs * sizeof(float), e->stream));
     PA_HIP(e, hipStreamSynchronize(e->stream));
     b->fed = 0;
     b->have_bg = true;
     return 0;
+}
+
+int pa_ball_background_from_frames(pa_ball* b, const uint8_t* frames_bgr, int n, int on_device, uint8_t* out_median_rgb) {
+    if (!b || !frames_bgr) return 1;
+    pa_engine* e = b->m->e;
+    if (n < 1 || n > 65535) PA_FAIL(e, "pa_ball_background_from_frames: n = %d", n);
+    PA_HIP(e, hipSetDevice(e->dev));
+    hipStream_t s = e->stream;
+    const long long fb = (long long)b->h * b->w * 3;
+    const uint8_t* src = frames_bgr;
+    uint8_t* tmp = nullptr;
+    if (!on_device) {
+        PA_HIP(e, hipMalloc((void**)&tmp, (size_t)n * fb));
+        hipError_t r = hipMemcpyAsync(tmp, frames_bgr, (size_t)n * fb, hipMemcpyHostToDevice, s);
+        if (r != hipSuccess) { hipFree(tmp); PA_FAIL(e, "median upload: %s", hipGetErrorString(r)); }
+        src = tmp;
+    }
+    hipError_t r = launch_median(src, n, fb, b->d_med_src, s);
+    if (r == hipSuccess && out_median_rgb) r = hipMemcpyAsync(out_median_rgb, b->d_med_src, (size_t)fb, hipMemcpyDeviceToHost, s);
+    if (r == hipSuccess) r = hipStreamSynchronize(s);
+    if (tmp) hipFree(tmp);
+    if (r != hipSuccess) PA_FAIL(e, "median kernel: %s", hipGetErrorString(r));
+    return ball_finish_background(b);
 }
 
 int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int flush, uint8_t* out_masks,

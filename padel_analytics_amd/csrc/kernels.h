@@ -158,5 +158,7 @@ struct BallLocateArgs {
     int H, W;
 };
 hipError_t launch_ball_locate(const BallLocateArgs& a, int nout, hipStream_t s);
+// K11: per-byte median over N BGR frames -> RGB background (np.median + uint8 truncation)
+hipError_t launch_median(const uint8_t* frames, int N, long long frame_bytes, uint8_t* out_rgb, hipStream_t s);
 
 }  // namespace padel

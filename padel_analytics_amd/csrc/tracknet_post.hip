@@ -174,3 +174,46 @@ hipError_t launch_ball_locate(const BallLocateArgs& a, int nout, hipStream_t s) 
 }
 
 }  // namespace padel
+
+// ------------------------------------------------------------------------------------------------
+// median_kernel — K11: per-pixel, per-channel median over the first N frames of the clip
+// (reference ball_tracker/iterable.py:59-74: np.median(np.array(frames_rgb), 0) then .astype('uint8')).
+// One thread per (pixel, channel) byte; its 256-bin histogram (u16 counts, N <= 65535) lives in LDS laid
+// out [bin][thread] so that neighbouring threads touch neighbouring addresses; frames are read once,
+// coalesced (consecutive threads = consecutive bytes).  np.median semantics: odd N -> the middle element;
+// even N -> mean of the two middle elements computed in float64, and the uint8 cast truncates -> (a+b)>>1.
+// Input frames are BGR, the output is RGB (channel 2-c), like the reference's cvtColor before the median.
+#define MED_THREADS 128
+
+namespace padel {
+
+__global__ void __launch_bounds__(MED_THREADS) median_kernel(const uint8_t* frames, int N, long long frame_bytes,
+                                                              uint8_t* out_rgb) {
+    __shared__ unsigned short hist[256 * MED_THREADS];
+    const int t = threadIdx.x;
+    const long long e = (long long)blockIdx.x * MED_THREADS + t;
+    for (int b = 0; b < 256; ++b) hist[b * MED_THREADS + t] = 0;
+    if (e >= frame_bytes) return;
+    for (int n = 0; n < N; ++n) {
+        const int v = frames[(long long)n * frame_bytes + e];
+        hist[v * MED_THREADS + t] += 1;
+    }
+    const int k_hi = N >> 1, k_lo = (N & 1) ? k_hi : k_hi - 1;       // 0-based ranks of the middle element(s)
+    int cum = 0, lo = -1, hi = -1;
+    for (int b = 0; b < 256; ++b) {
+        cum += hist[b * MED_THREADS + t];
+        if (lo < 0 && cum > k_lo) lo = b;
+        if (cum > k_hi) { hi = b; break; }
+    }
+    const long long pix = e / 3;
+    const int c = (int)(e - pix * 3);
+    out_rgb[pix * 3 + (2 - c)] = (uint8_t)((lo + hi) >> 1);
+}
+
+hipError_t launch_median(const uint8_t* frames, int N, long long frame_bytes, uint8_t* out_rgb, hipStream_t s) {
+    const long long blocks = (frame_bytes + MED_THREADS - 1) / MED_THREADS;
+    hipLaunchKernelGGL(median_kernel, dim3((unsigned)blocks), dim3(MED_THREADS), 0, s, frames, N, frame_bytes, out_rgb);
+    return hipGetLastError();
+}
+
+}  // namespace padel

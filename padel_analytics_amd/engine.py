@@ -62,7 +62,7 @@ ABI_SYMBOLS = [
     "pa_model_create", "pa_model_destroy", "pa_model_set_max_batch", "pa_yolo_infer", "pa_yolo_head_shape",
     "pa_yolo_read_head", "pa_tracknet_infer", "pa_engine_set_profiling", "pa_model_last_profile",
     "pa_model_profile_text", "pa_ball_create", "pa_ball_destroy", "pa_ball_set_background", "pa_ball_feed",
-    "pa_ball_locate",
+    "pa_ball_locate", "pa_ball_background_from_frames",
 ]
 
 
@@ -111,6 +111,7 @@ def load_library():
     lib.pa_ball_set_background.argtypes = [vp, vp]
     lib.pa_ball_feed.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]
     lib.pa_ball_locate.argtypes = [vp, vp, i32, vp]
+    lib.pa_ball_background_from_frames.argtypes = [vp, vp, i32, i32, vp]
     if lib.pa_abi_version() != 1:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
@@ -305,6 +306,16 @@ class BallSession:
         m = np.ascontiguousarray(median_rgb, np.uint8)
         assert m.shape == (self.src_h, self.src_w, 3), m.shape
         self.model.engine._check(self.model.engine.lib.pa_ball_set_background(self.handle, m.ctypes.data))
+
+    def background_from_frames(self, frames_bgr: np.ndarray, want_median: bool = False):
+        """Median background of (n, h, w, 3) uint8 BGR frames on the device (np.median + uint8 truncation)."""
+        f = np.ascontiguousarray(frames_bgr, np.uint8)
+        n = len(f)
+        assert f.shape == (n, self.src_h, self.src_w, 3)
+        med = np.empty((self.src_h, self.src_w, 3), np.uint8) if want_median else None
+        self.model.engine._check(self.model.engine.lib.pa_ball_background_from_frames(
+            self.handle, f.ctypes.data, n, 0, med.ctypes.data if want_median else None))
+        return med
 
     def feed(self, frames_bgr: Optional[np.ndarray], flush: bool = False, want_heat: bool = False,
              want_rects: bool = False, want_masks: bool = True):

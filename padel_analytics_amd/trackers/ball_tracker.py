@@ -7,7 +7,8 @@ temporal ensemble of the 8 overlapping outputs -> threshold .5 -> largest boundi
 components -> centre scaled to source pixels.  On the GPU (``pa_ball_*``): resize, window assembly, network,
 ensemble, threshold and the connected-component rectangle pick (``ball_locate_kernel``; the scipy.ndimage
 ``predict_location`` below is only the fallback for masks with more than 12 288 foreground pixels).  On the host:
-the median (numpy, like the reference; device histogram median is "next").
+nothing numeric: the background median of the first ``median_max_sample_num`` frames is a per-thread LDS
+histogram kernel too (``median_kernel``, K11).
 
 Deliberate differences: the window stream is contiguous across the median boundary
 (#10: the reference drops 7 windows for clips longer than ``median_range``); the tracker completes without an
@@ -127,14 +128,16 @@ class BallTracker(Tracker):
                     break
             if not head:
                 return []
-            median = np.median(np.array([f[..., ::-1] for f in head]), 0).astype("uint8")
         first = head[0] if head else next(it)
         if not head:
             head = [first]
         h0, w0 = first.shape[:2]
         w_scaler, h_scaler = w0 / self.WIDTH, h0 / self.HEIGHT
         sess = E.BallSession(self._model, h0, w0)
-        sess.set_background(median)
+        if median is None:                       # K11: np.median(frames_rgb, 0).astype(uint8) on the device
+            sess.background_from_frames(np.stack(head))
+        else:
+            sess.set_background(median)
         xs, ys, vs = [], [], []
 
         def consume(res):

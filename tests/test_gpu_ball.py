@@ -101,6 +101,20 @@ def test_ball_locate_kernel_synthetic_masks(gpu_engine):
     sess.close(); m.close()
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 16])
+def test_device_median_matches_numpy(gpu_engine, n):
+    m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1)))
+    m.set_max_batch(4)
+    sess = E.BallSession(m, 90, 160)
+    rng = np.random.default_rng(n)
+    frames = rng.integers(0, 256, (n, 90, 160, 3), dtype=np.uint8)
+    frames[:, :10] = rng.integers(100, 104, (n, 10, 160, 3), dtype=np.uint8)      # many ties around the middle
+    got = sess.background_from_frames(frames, want_median=True)
+    want = np.median(np.array([f[..., ::-1] for f in frames]), 0).astype("uint8")
+    assert np.array_equal(got, want)
+    sess.close(); m.close()
+
+
 def test_ball_tracker_plugin(gpu_engine, tmp_path):
     T = 20
     frames = _clip(T, 360, 640, seed=33)
