@@ -56,3 +56,26 @@ def test_runner_end_to_end(gpu_engine, tmp_path):
     # every kept player is inside the zone and carries a ByteTrack id after the first frames
     ids = [p.id for pl in players.results.predictions[3:] for p in pl]
     assert all(i is not None for i in ids)
+
+
+def test_court_keypoints_tracker_yolo(gpu_engine, tmp_path):
+    """model_type='yolo': a 12-keypoint YOLOv8-pose graph with max_det=12 through the same engine."""
+    from PIL import Image
+    from padel_analytics_amd.trackers import KeypointsTracker
+    frames = list(video.get_video_frames_generator("synthetic://?n=4&h=360&w=640&seed=9"))
+    pil = [np.asarray(Image.fromarray(f[..., ::-1].copy()).resize((640, 640)))[..., ::-1] for f in frames]
+    sd = synth_weights.calibrated_state_dict("n", 1, (12, 2), ref.preprocess(pil, 640), 0.5, seed=6, frac=0.02)
+    checkpoint.save_checkpoint(tmp_path / "court.pt", sd, "pose", 1, (12, 2), "n", {0: "court"})
+    t = KeypointsTracker(str(tmp_path / "court.pt"), batch_size=4, model_type="yolo")
+    out = t.predict_and_update(iter(frames))
+    assert len(out) == 4
+    r = ref.predict(ref.YoloV8Ref(sd, 1, (12, 2)), pil, 0.5, 0.7, 640, classes=None, max_det=12)
+    for kp, rr in zip(out, r):
+        if len(rr["boxes"]) == 0:
+            assert len(kp) == 0
+            continue
+        assert sorted(k.id for k in kp) == list(range(12))
+        want = rr["kpts"][0]
+        for i in range(12):
+            k = kp[KeypointsTracker.POINTS_MAPPER[i]]
+            assert abs(k.xy[0] - want[i, 0] * 640 / 640) < 0.1 and abs(k.xy[1] - want[i, 1] * 360 / 640) < 0.1

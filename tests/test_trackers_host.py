@@ -127,3 +127,16 @@ def test_bytetrack_ids_are_stable_and_new_tracks_need_two_frames():
     bt.reset()
     assert bt.update_with_detections(D.Detections(boxes, np.array([0.9, 0.8]), np.zeros(2, int))).tracker_id.tolist() == [1, 2]
     assert len(bt.update_with_detections(D.Detections.empty())) == 0
+
+
+def test_court_keypoints_fixed_short_circuit(tmp_path):
+    from padel_analytics_amd.trackers import Keypoint, Keypoints, KeypointsTracker
+    fixed = Keypoints([Keypoint(id=i, xy=(10.0 * i, 5.0 * i)) for i in (3, 1, 2)])
+    assert [k.id for k in fixed] == [1, 2, 3] and fixed[2].asint() == (20, 10)
+    assert Keypoints.from_json(json.loads(json.dumps(fixed.serialize())))[3].xy == [30.0, 15.0]
+    t = KeypointsTracker("missing.pt", batch_size=4, model_type="yolo", fixed_keypoints_detection=fixed)
+    t.to("cuda")                                            # no model is touched in the shipped configuration
+    out = t.predict_and_update(np.zeros((2, 2, 3), np.uint8) for _ in range(5))
+    assert len(out) == 5 and all(o is fixed for o in out)
+    with pytest.raises(NotImplementedError):
+        KeypointsTracker("x.pt", 4, model_type="resnet").predict_frames(iter([]))
