@@ -19,6 +19,7 @@
 //     / B[k=l>>4][j] operand layout of 16x16x4, four MFMAs per ds_read_b128 pair.
 #include "kernels.h"
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 
 namespace padel {
@@ -32,8 +33,11 @@ __device__ __forceinline__ float act_apply2(float v, int act) {
     return v;
 }
 
+// second launch-bound = minimum waves per SIMD the register allocation must allow: small per-wave tiles are asked
+// to fit 5 resident workgroups per CU (<= 96 registers); measured residency curve of the 64x96 tile: 1 -> 60,
+// 2 -> 81, 3 -> 90, 4 -> 95 TFLOP/s (tools/occ_probe.sh)
 template <int WM, int WN, int MF, int NF, int KS, int KB>
-__global__ void __launch_bounds__(256) conv_lds_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_lds_kernel(const ConvArgs a) {
     constexpr int TAPS = KS * KS;
     constexpr int pad = KS >> 1;
     constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
@@ -246,10 +250,22 @@ static hipError_t launch_l(const ConvArgs& a_in, hipStream_t s) {
     a.n_mtiles = (a.M + BM - 1) / BM;
     dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
     const int kb = lds_kb();
-    if (a.ksize == 3 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 2>), grid, dim3(256), 0, s, a);
-    else if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 1>), grid, dim3(256), 0, s, a);
-    else if (a.ksize == 1 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 2>), grid, dim3(256), 0, s, a);
-    else if (a.ksize == 1) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 1>), grid, dim3(256), 0, s, a);
+    // tuning probes: PADEL_CONV_DYNLDS = extra dynamic LDS bytes per workgroup (caps residency),
+    // PADEL_CONV_OCC = print the runtime's occupancy answer for this instantiation
+    const size_t dyn = getenv("PADEL_CONV_DYNLDS") ? (size_t)atoi(getenv("PADEL_CONV_DYNLDS")) : 0;
+    if (getenv("PADEL_CONV_OCC")) {
+        int nb = -1;
+        if (a.ksize == 3) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<WM, WN, MF, NF, 3, 1>, 256, dyn);
+        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<WM, WN, MF, NF, 1, 1>, 256, dyn);
+        hipFuncAttributes fa{};
+        if (a.ksize == 3) (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(conv_lds_kernel<WM, WN, MF, NF, 3, 1>));
+        fprintf(stderr, "[occ] tile %dx%d ks%d: %d workgroups/CU (dyn LDS %zu), regs %d, static LDS %zu, grid %u x %u\n",
+                BM, WN * NF * 16, a.ksize, nb, dyn, fa.numRegs, fa.sharedSizeBytes, grid.x, grid.y);
+    }
+    if (a.ksize == 3 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 2>), grid, dim3(256), dyn, s, a);
+    else if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 1>), grid, dim3(256), dyn, s, a);
+    else if (a.ksize == 1 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 2>), grid, dim3(256), dyn, s, a);
+    else if (a.ksize == 1) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 1>), grid, dim3(256), dyn, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
