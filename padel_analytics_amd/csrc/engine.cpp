@@ -438,7 +438,13 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             else choose_conv_tile(a.M, a.n16, &mf, &nf);
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
             if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = mf; pr->nf = nf; }
-            r = lv >= 0 ? launch_conv_lds(a, lv, s) : launch_conv_igemm(a, mf, nf, s);
+            const bool use_pipe = getenv("PADEL_CONV_PIPE") && atoi(getenv("PADEL_CONV_PIPE"));
+            if (lv >= 0 && use_pipe) {
+                r = launch_conv_pipe(a, lv, s);
+                if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);
+            } else {
+                r = lv >= 0 ? launch_conv_lds(a, lv, s) : launch_conv_igemm(a, mf, nf, s);
+            }
         } else if (o.kind == PA_OP_STEM) {
             StemArgs a{};
             a.in = m->d_netin; a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;

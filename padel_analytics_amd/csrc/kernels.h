@@ -44,6 +44,8 @@ int conv_lds_num_variants();
 void conv_lds_variant_shape(int variant, int* bm, int* bn);
 // returns the LDS variant to use for (M, n16), or -1 to use the register-direct kernel
 int choose_conv_lds_variant(int M, int n16);
+// v3 (opt-in): 3-stage LDS ring + double-buffered fragments; same variant ids, hipErrorNotSupported if not instantiated
+hipError_t launch_conv_pipe(const ConvArgs& a, int variant, hipStream_t s);
 
 struct StemArgs {
     const uint8_t* in;    // net input u8 NHWC4 [B][H][W][4]

@@ -45,7 +45,7 @@ def _run(eng, case, x, w, b, res):
 
 
 def _setenv(**kw):
-    for k in ("PADEL_CONV_IMPL", "PADEL_CONV_MF", "PADEL_CONV_NF", "PADEL_CONV_LDS_VARIANT", "PADEL_CONV_KB"):
+    for k in ("PADEL_CONV_IMPL", "PADEL_CONV_MF", "PADEL_CONV_NF", "PADEL_CONV_LDS_VARIANT", "PADEL_CONV_KB", "PADEL_CONV_PIPE"):
         os.environ.pop(k, None)
     os.environ.update({k: str(v) for k, v in kw.items()})
 
@@ -74,6 +74,9 @@ def test_conv_variants(gpu_engine, case):
         for v in range(13):
             _setenv(PADEL_CONV_LDS_VARIANT=v)
             outs[f"L{v}"] = _run(gpu_engine, case, x, w, b, None)
+        for v in (0, 1, 6, 7, 9, 10, 11):             # v3: 3-stage LDS ring, double-buffered fragments
+            _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_PIPE=1)
+            outs[f"P{v}"] = _run(gpu_engine, case, x, w, b, None)
         for v in (1, 7, 9, 11):                        # two k-steps per barrier (32-wide LDS stages)
             _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_KB=2)
             outs[f"L{v}k2"] = _run(gpu_engine, case, x, w, b, None)

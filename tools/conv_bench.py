@@ -77,6 +77,9 @@ if __name__ == "__main__":
             mf, nf = map(int, t[1:].split("x"))
             env["PADEL_CONV_IMPL"] = "direct"
             env["PADEL_CONV_MF"], env["PADEL_CONV_NF"] = str(mf), str(nf)
+        elif t.startswith("P"):
+            env["PADEL_CONV_LDS_VARIANT"] = t[1:]
+            env["PADEL_CONV_PIPE"] = "1"
         elif t.startswith("L"):
             body, _, tune = t[1:].partition("t")
             v, _, kb = body.partition("k")
