@@ -139,7 +139,10 @@ def main():
             blob = t.cpu().numpy()
             del t
         m = E.Model(eng, g, blob)
-        chunk = a.chunk or (16 if (cfg["imgsz"] >= 1280 and cfg["scale"] in "mlx") else (32 if cfg["imgsz"] >= 1280 else 64))
+        # frames per graph replay: the whole batch (measured on c3: 16 -> 247, 32 -> 256, 64 -> 264 frames/s; small
+        # replays leave the P5 layers with ~2 rounds of workgroups).  yolov8m-pose @1280^2 x 64 frames ~ 130 GB of
+        # activation buffers, well inside the 288 GB of HBM.
+        chunk = a.chunk or 64
         m.set_max_batch(min(B, chunk))
         models[name] = m
         S = cfg["imgsz"]
