@@ -36,7 +36,9 @@ __device__ __forceinline__ float act_apply2(float v, int act) {
 // second launch-bound = minimum waves per SIMD the register allocation must allow: small per-wave tiles are asked
 // to fit 5 resident workgroups per CU (<= 96 registers); measured residency curve of the 64x96 tile: 1 -> 60,
 // 2 -> 81, 3 -> 90, 4 -> 95 TFLOP/s (tools/occ_probe.sh)
-template <int WM, int WN, int MF, int NF, int KS, int KB>
+// DIAG (tuning probes only, results are WRONG when != 0; PADEL_CONV_DIAG, variant 7 / 3x3 only): bit0 = no global
+// loads in the main loop, bit1 = no LDS stores, bit2 = no barrier, bit3 = no LDS fragment reads.
+template <int WM, int WN, int MF, int NF, int KS, int KB, int DIAG = 0>
 __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_lds_kernel(const ConvArgs a) {
     constexpr int TAPS = KS * KS;
     constexpr int pad = KS >> 1;
@@ -48,12 +50,26 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
     __shared__ __attribute__((aligned(16))) float lds[2 * KB * (BM + BN) * 16];
     float* const As = lds;
     float* const Bs = lds + 2 * KB * BM * 16;
+    // DIAG 16: every wave stamps s_memtime at 5 points of every k-step into an LDS ring (lane 0 writes the real slot,
+    // the other lanes write a per-lane dummy slot: no branch, no bank conflict), dumped to a.dbg at the end
+    __shared__ unsigned long long stamps[(DIAG & 16) ? 4 * kConvDbgSteps * 5 + 4 * 64 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, lq = lane >> 4;
     const int wm = wave / WN, wn = wave % WN;
+    unsigned long long t_begin = 0;
+    if constexpr ((DIAG & 16) != 0) t_begin = __builtin_amdgcn_s_memtime();
+#define PADEL_STAMP(step, slot)                                                                        \
+    do {                                                                                               \
+        if constexpr ((DIAG & 16) != 0) {                                                              \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                \
+            const int real_ = (wave * kConvDbgSteps + ((step) & (kConvDbgSteps - 1))) * 5 + (slot);   \
+            const int dummy_ = 4 * kConvDbgSteps * 5 + wave * 64 + lane;                               \
+            stamps[lane == 0 ? real_ : dummy_] = t_;                                                   \
+        }                                                                                              \
+    } while (0)
 
     // XCD-aware (bijective) remap of the pixel-tile index
     const int nmt = a.n_mtiles;
@@ -64,7 +80,17 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
     const int m0 = mt * BM;
     const int f0 = nt * (WN * NF);           // first 16-channel fragment of this workgroup
 
-    const bool prio = (a.tune & 1) != 0;
+    bool prio = (a.tune & 1) != 0;
+    if (a.tune & 12) {
+        // static per-workgroup priority instead of the toggle: co-resident workgroups that arbitrate MFMA by MFMA
+        // finish their bursts together and then sit in their load/barrier phases together (pipe idle); distinct
+        // priorities let one burst run through while the others wait, which staggers the phases
+        const int pl = (a.tune & 4) ? (idx >> 5) & 3 : idx & 3;
+        if (pl == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pl == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pl == 3) __builtin_amdgcn_s_setprio(3);
+        prio = false;
+    }
     if (a.tune & 2) {
         // co-resident workgroups start together and run at the same rate: without an offset their
         // non-MFMA phases (barrier, LDS refill) coincide and the matrix pipe idles
@@ -147,14 +173,26 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
         for (int p = 0; p < BP; ++p)
             if (BN % 64 == 0 || srow + 64 * p < BN) *reinterpret_cast<f32x4*>(bd + p * 64 * 16) = gb[u][p];
     };
+    int stamp_step = 0;
     auto compute = [&](const int u, const int buf) {
         const float* ab = As + (buf * KB + u) * (BM * 16) + a_rd;
         const float* bb = Bs + (buf * KB + u) * (BN * 16) + b_rd;
         f32x4 A[MF], B[NF];
+        if (DIAG & 8) {
 #pragma unroll
-        for (int f = 0; f < MF; ++f) A[f] = *reinterpret_cast<const f32x4*>(ab + f * 256);
+            for (int f = 0; f < MF; ++f) A[f] = ga[0][f % AP];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) B[j] = *reinterpret_cast<const f32x4*>(bb + j * 256);
+            for (int j = 0; j < NF; ++j) B[j] = gb[0][j % BP];
+        } else {
+#pragma unroll
+            for (int f = 0; f < MF; ++f) A[f] = *reinterpret_cast<const f32x4*>(ab + f * 256);
+#pragma unroll
+            for (int j = 0; j < NF; ++j) B[j] = *reinterpret_cast<const f32x4*>(bb + j * 256);
+        }
+        if constexpr ((DIAG & 16) != 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            PADEL_STAMP(stamp_step, 1);
+        }
         if (prio) __builtin_amdgcn_s_setprio(1);          // keep the matrix pipe fed ahead of waves in their load phase
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -164,6 +202,7 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
                 for (int j = 0; j < NF; ++j)
                     part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[f][kk], B[j][kk], part[f][j], 0, 0, 0);
         if (prio) __builtin_amdgcn_s_setprio(0);
+        PADEL_STAMP(stamp_step, 2);
     };
 
     // Nested loops: the inner loop (one accumulation block of FLUSH k-steps) contains nothing but
@@ -187,18 +226,25 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
     while (ss < nss - 1) {
         const int nb = min(FLUSH_SS, nss - 1 - ss);
         for (int i = 0; i < nb; ++i, ++ss) {
+            PADEL_STAMP(ss, 0);
 #pragma unroll
             for (int u = 0; u < KB; ++u) {                 // in flight under the MFMAs below
-                gload(u, (ss + 1) * KB + u, pf_tap, pf_c32 * 32 + pf_half * 16);
+                if (!(DIAG & 1)) gload(u, (ss + 1) * KB + u, pf_tap, pf_c32 * 32 + pf_half * 16);
                 PADEL_PF_ADVANCE();
             }
             __builtin_amdgcn_sched_barrier(0);
+            stamp_step = ss;
 #pragma unroll
             for (int u = 0; u < KB; ++u) compute(u, ss & 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((DIAG & 16) != 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                PADEL_STAMP(ss, 3);
+            }
 #pragma unroll
-            for (int u = 0; u < KB; ++u) lstore(u, (ss + 1) & 1);
-            __syncthreads();
+            for (int u = 0; u < KB; ++u) if (!(DIAG & 2)) lstore(u, (ss + 1) & 1);
+            if (!(DIAG & 4)) __syncthreads();
+            PADEL_STAMP(ss, 4);
         }
         if (nb == FLUSH_SS) {
 #pragma unroll
@@ -207,6 +253,7 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
                 for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         }
     }
+    stamp_step = nss - 1;
 #pragma unroll
     for (int u = 0; u < KB; ++u) compute(u, (nss - 1) & 1);
 #pragma unroll
@@ -236,6 +283,21 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
             }
         }
     }
+    if constexpr ((DIAG & 16) != 0) {
+        if (a.dbg) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            unsigned long long* d = a.dbg + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * kConvDbgWords;
+            for (int i = tid; i < 4 * kConvDbgSteps * 5; i += 256) d[8 + i] = stamps[i];
+            if (lane == 0) {
+                // HW_REG_HW_ID (4) and HW_REG_XCC_ID (20): which CU / SIMD / XCD this wave ran on
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+                const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+                d[wave] = ((unsigned long long)xcc << 32) | hw;
+                if (wave == 0) { d[4] = t_begin; d[5] = t_end; d[6] = (unsigned long long)nks; d[7] = (unsigned long long)bid; }
+            }
+        }
+    }
 }
 
 static int lds_kb() {
@@ -262,6 +324,20 @@ static hipError_t launch_l(const ConvArgs& a_in, hipStream_t s) {
         fprintf(stderr, "[occ] tile %dx%d ks%d: %d workgroups/CU (dyn LDS %zu), regs %d, static LDS %zu, grid %u x %u\n",
                 BM, WN * NF * 16, a.ksize, nb, dyn, fa.numRegs, fa.sharedSizeBytes, grid.x, grid.y);
     }
+    if constexpr (WM == 2 && WN == 2 && MF == 2 && NF == 3) {
+        const int diag = getenv("PADEL_CONV_DIAG") ? atoi(getenv("PADEL_CONV_DIAG")) : 0;
+        if (diag && a.ksize == 3) {
+            if (diag == 1) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 1>), grid, dim3(256), dyn, s, a);
+            else if (diag == 6) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 6>), grid, dim3(256), dyn, s, a);
+            else if (diag == 7) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 7>), grid, dim3(256), dyn, s, a);
+            else if (diag == 15) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 15>), grid, dim3(256), dyn, s, a);
+            else if (diag == 2) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 2>), grid, dim3(256), dyn, s, a);
+            else if (diag == 14) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 14>), grid, dim3(256), dyn, s, a);
+            else if (diag == 16) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 16>), grid, dim3(256), dyn, s, a);
+            else return hipErrorInvalidValue;
+            return hipGetLastError();
+        }
+    }
     if (a.ksize == 3 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 2>), grid, dim3(256), dyn, s, a);
     else if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 1>), grid, dim3(256), dyn, s, a);
     else if (a.ksize == 1 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 2>), grid, dim3(256), dyn, s, a);
@@ -286,7 +362,16 @@ static const LdsVariant lds_variants[] = {
     {10, 2, 2, 4, 2},  // 128 x  64 (2x2 waves)
     {11, 4, 1, 2, 2},  // 128 x  32
     {12, 4, 1, 2, 1},  // 128 x  16
+    // ring-only (conv_ring.hip): 8 or 16 waves per workgroup
+    {13, 4, 2, 2, 3},  // 128 x  96
+    {14, 4, 2, 2, 4},  // 128 x 128
+    {15, 4, 2, 2, 2},  // 128 x  64
+    {16, 8, 2, 2, 3},  // 256 x  96
+    {17, 4, 4, 2, 3},  // 128 x 192
+    {18, 2, 4, 2, 3},  //  64 x 192
+    {19, 8, 1, 2, 3},  // 256 x  48
 };
+constexpr int kFirstRingOnly = 13;
 
 hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s) {
     switch (variant) {
@@ -304,6 +389,7 @@ hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s) {
         case 11: return launch_l<4, 1, 2, 2>(a, s);
         case 12: return launch_l<4, 1, 2, 1>(a, s);
     }
+    if (variant >= kFirstRingOnly) return launch_conv_ring(a, variant, s);
     return hipErrorInvalidValue;
 }
 
@@ -320,6 +406,7 @@ int choose_conv_lds_variant(int M, int n16) {
     float best = -1.f;
     int bv = 0;
     for (const auto& v : lds_variants) {
+        if (v.id >= kFirstRingOnly) break;                 // not in the heuristic yet
         const int bm = v.wm * v.mf * 16, nfw = v.wn * v.nf;
         const int ntiles = (n16 + nfw - 1) / nfw;
         const long long mtiles = (M + bm - 1) / bm;

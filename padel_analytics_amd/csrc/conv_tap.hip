@@ -1,0 +1,265 @@
+// K3 v5 — tap-unrolled LDS-DMA ring for the 3x3 convs (cin % 32 == 0): the instruction diet.
+//
+// Same tiles, operands, K order, swizzled LDS image, ring and two-level accumulation as conv_ring.hip (results are
+// bit-identical with v1/v2/v4).  Why another kernel: the s_memtime timeline of v2 (tools/timeline_probe.py,
+// profiles/conv_timeline_r1.txt) shows that with 4-5 waves per SIMD a wave spends only ~25 % of a k-step inside its
+// 24-MFMA burst; the other ~2900 cycles go to the ~110 non-MFMA instructions of the k-step (tap decode, 64-bit
+// address arithmetic, bounds tests, zero-page selects, buffer toggles, branches), each of which costs ~26 cycles to
+// issue while the other waves keep the matrix pipe busy.  Here the 18 k-steps of one 32-channel chunk (9 taps x 2
+// halves = one accumulation block) are unrolled, so tap, half and ring stage are compile-time constants, and the
+// loader is rebuilt around buffer addressing:
+//
+//   * per lane and tap ONE precomputed 32-bit byte offset (relative to the workgroup's lowest address); taps that
+//     fall outside the image, and rows past M, hold an out-of-range offset: the raw-buffer range check returns
+//     zeros for them — no compare, no select, no zero page in the loop;
+//   * everything that changes from step to step is wave-uniform and lives in the SGPR offset of
+//     `buffer_load_dwordx4 ... offen lds` (chunk + tap + half: one s_add per request);
+//   * ring stage and fragment offsets are immediates of the ds_read_b128 / of the M0 add.
+//
+// A k-step is: s_waitcnt vmcnt(n) ; s_barrier ; 2-3 LDS-DMA requests (3 SALU each) ; 5 ds_read_b128 ; 24 MFMA.
+// Requests run two steps ahead and read up to 128 bytes past the last chunk of a pixel / weight row (data that is
+// never used); the engine allocates its buffers with that slack.
+#include "kernels.h"
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+namespace padel {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply5(float v, int act) {
+    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    return v;
+}
+
+// raw buffer descriptor (gfx9 family): base, stride 0, num_records = 2 GiB, 32-bit data format
+__device__ __forceinline__ i32x4 make_rsrc(const float* base) {
+    const unsigned long long b = (unsigned long long)(uintptr_t)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xFFFFu));
+    r[2] = (int)0x80000000u;
+    r[3] = 0x00020000;
+    return r;
+}
+constexpr unsigned kOutOfRange = 0xFFFFFFF0u;      // >= num_records: the load returns zeros
+
+// 64 lanes x 16 bytes, buffer (rsrc base + soff + per-lane voff) -> LDS (lds_wave + LDS_IMM + 16 * lane)
+template <int LDS_IMM>
+__device__ __forceinline__ void dma16(unsigned voff, i32x4 rsrc, unsigned soff, unsigned lds_wave) {
+    asm volatile("s_add_u32 m0, %[lb], %[imm]\n\ts_nop 0\n\tbuffer_load_dwordx4 %[vo], %[rs], %[so] offen lds"
+                 :
+                 : [lb] "s"(lds_wave), [imm] "n"(LDS_IMM), [vo] "v"(voff), [rs] "s"(rsrc), [so] "s"(soff)
+                 : "memory", "scc");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+constexpr int tap_min_waves(int nw, int frags) {
+    return nw == 4 ? (frags <= 6 ? 5 : 4) : 4;
+}
+
+template <int WM, int WN, int MF, int NF>
+__global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF)) conv_tap_kernel(const ConvArgs a) {
+    constexpr int NW = WM * WN;              // waves per workgroup (4 or 8)
+    constexpr int RP = NW * 16;              // tile rows staged per pass: one wave-instruction (16 rows) per wave
+    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
+    constexpr int AP = (BM + RP - 1) / RP, BP = (BN + RP - 1) / RP;
+    constexpr int AFULL = BM / RP, BFULL = BN / RP;        // passes every wave takes part in
+    constexpr int NST = 3;
+    constexpr int STAGE = (BM + BN) * 16;    // floats per ring stage: A rows then B rows, 64 bytes each
+    constexpr int STAGE_B = STAGE * 4;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware (bijective) remap of the pixel-tile index
+    const int nmt = a.n_mtiles;
+    const int bid = blockIdx.x;
+    const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int nt = blockIdx.y;
+    const int m0 = mt * BM;
+    const int f0 = nt * (WN * NF);           // first 16-channel fragment of this workgroup
+
+    const int HoWo = a.Ho * a.Wo;
+    const int nchunks = a.cin >> 5;          // cin % 32 == 0 (launcher)
+    const int Ktot = nchunks * 288;
+
+    // ---- A: per lane and tap one byte offset relative to the tap-(0,0) pixel of the workgroup's first row
+    const int srow = tid >> 2;
+    const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);     // source chunk of LDS slot tid&3 (swizzle)
+    const int n0 = m0 / HoWo, rem0 = m0 - n0 * HoWo, oy0 = rem0 / a.Wo, ox0 = rem0 - oy0 * a.Wo;
+    const long long lin0 = ((long long)n0 * a.H + oy0 * a.stride) * a.W + ox0 * a.stride;     // uniform
+    unsigned voffA[AP][9];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        int m = m0 + srow + RP * p;
+        const bool rv = m < a.M;
+        if (!rv) m = m0;
+        const int n = m / HoWo;
+        const int rem = m - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
+        const unsigned off = (unsigned)(((lin - lin0) * a.in_cs + sc * 4) * 4);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int ky = t / 3, kx = t % 3;
+            const bool v = rv && (unsigned)(oy * a.stride - 1 + ky) < (unsigned)a.H && (unsigned)(ox * a.stride - 1 + kx) < (unsigned)a.W;
+            voffA[p][t] = v ? off : kOutOfRange;
+        }
+    }
+    // base of the A descriptor: channel slice of the tap-(0,0) pixel of row m0 (may lie below a.in: never dereferenced there)
+    const float* baseA = a.in + ((lin0 - (a.W + 1)) * a.in_cs + a.in_choff);
+    const i32x4 rsrcA = make_rsrc(baseA);
+    unsigned tapoff[18];                      // SGPRs: byte offset of (tap, half) inside a chunk
+#pragma unroll
+    for (int j = 0; j < 18; ++j) {
+        const int t = j >> 1, ky = t / 3, kx = t % 3;
+        tapoff[j] = __builtin_amdgcn_readfirstlane((unsigned)(((ky * a.W + kx) * a.in_cs + (j & 1) * 16) * 4));
+    }
+    // ---- B: weight rows of this workgroup's channel tile
+    unsigned voffB[BP];
+#pragma unroll
+    for (int p = 0; p < BP; ++p) {
+        const int rr = srow + RP * p;                       // row inside the BN tile
+        const int frag = min(f0 + (rr >> 4), a.n16 - 1);    // clamp: partial last channel tile
+        voffB[p] = (unsigned)((((frag - f0) * 16 + (rr & 15)) * Ktot + sc * 4) * 4);
+    }
+    const i32x4 rsrcB = make_rsrc(a.w + (long long)f0 * 16 * Ktot);
+
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + wave * 1024u);
+    const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);
+    const float* const a_rd = lds + (wm * MF * 16) * 16 + ld_off;
+    const float* const b_rd = lds + BM * 16 + (wn * NF * 16) * 16 + ld_off;
+    const bool a_last = AP > AFULL && (AFULL * RP + wave * 16 < BM);      // this wave takes part in the partial pass
+    const bool b_last = BP > BFULL && (BFULL * RP + wave * 16 < BN);
+
+    f32x4 acc[MF][NF], part[MF][NF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    unsigned s_chunk = 0;                     // byte offset of the current 32-channel chunk inside a pixel
+    unsigned s_kb = 0;                        // byte offset of the current chunk inside a weight row (18 steps x 64 B)
+
+    // request chunk-relative step JR (of the current chunk, or of the next one when WRAP) into ring stage JR % 3
+#define PADEL_TAP_REQUEST(JR, WRAP)                                                                              \
+    do {                                                                                                         \
+        constexpr int SR_ = (JR) % 3;                                                                            \
+        const unsigned sa_ = s_chunk + tapoff[JR] + ((WRAP) ? 128u : 0u);                                        \
+        const unsigned sb_ = s_kb + ((JR) + ((WRAP) ? 18 : 0)) * 64u;                                            \
+        if constexpr (AFULL >= 1) dma16<SR_ * STAGE_B>(voffA[0][(JR) >> 1], rsrcA, sa_, lds_wave);               \
+        if constexpr (AFULL >= 2) dma16<SR_ * STAGE_B + RP * 64>(voffA[1][(JR) >> 1], rsrcA, sa_, lds_wave);     \
+        if constexpr (AP > AFULL) { if (a_last) dma16<SR_ * STAGE_B + AFULL * RP * 64>(voffA[AP - 1][(JR) >> 1], rsrcA, sa_, lds_wave); } \
+        if constexpr (BFULL >= 1) dma16<SR_ * STAGE_B + BM * 64>(voffB[0], rsrcB, sb_, lds_wave);                \
+        if constexpr (BFULL >= 2) dma16<SR_ * STAGE_B + BM * 64 + RP * 64>(voffB[1], rsrcB, sb_, lds_wave);      \
+        if constexpr (BP > BFULL) { if (b_last) dma16<SR_ * STAGE_B + BM * 64 + BFULL * RP * 64>(voffB[BP - 1], rsrcB, sb_, lds_wave); } \
+    } while (0)
+
+    // one k-step: chunk-relative step J is read from ring stage J % 3 while step J + 2 is requested
+#define PADEL_TAP_STEP(J)                                                                                        \
+    do {                                                                                                         \
+        constexpr int ST_ = (J) % 3;                                                                             \
+        wait_vm<AFULL + BFULL>();               /* own requests of step J landed (the younger ones may fly on) */ \
+        __builtin_amdgcn_s_barrier();           /* ... everybody's did; stage (J + 2) % 3 is free again */        \
+        PADEL_TAP_REQUEST(((J) + 2) % 18, (J) + 2 >= 18);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        {                                                                                                        \
+            f32x4 A_[MF], B_[NF];                                                                                \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) A_[f] = *reinterpret_cast<const f32x4*>(a_rd + ST_ * STAGE + f * 256); \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j) B_[j] = *reinterpret_cast<const f32x4*>(b_rd + ST_ * STAGE + j * 256); \
+            __builtin_amdgcn_s_setprio(1);                                                                       \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
+                _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                   \
+                    _Pragma("unroll") for (int j = 0; j < NF; ++j)                                               \
+                        part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[f][kk], B_[j][kk], part[f][j], 0, 0, 0); \
+            __builtin_amdgcn_s_setprio(0);                                                                       \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    } while (0)
+
+    static_assert(AFULL <= 2 && BFULL <= 2, "at most two full passes per operand");
+    PADEL_TAP_REQUEST(0, false);
+    PADEL_TAP_REQUEST(1, false);
+    for (int c = 0; c < nchunks; ++c) {
+        PADEL_TAP_STEP(0);  PADEL_TAP_STEP(1);  PADEL_TAP_STEP(2);  PADEL_TAP_STEP(3);  PADEL_TAP_STEP(4);  PADEL_TAP_STEP(5);
+        PADEL_TAP_STEP(6);  PADEL_TAP_STEP(7);  PADEL_TAP_STEP(8);  PADEL_TAP_STEP(9);  PADEL_TAP_STEP(10); PADEL_TAP_STEP(11);
+        PADEL_TAP_STEP(12); PADEL_TAP_STEP(13); PADEL_TAP_STEP(14); PADEL_TAP_STEP(15); PADEL_TAP_STEP(16); PADEL_TAP_STEP(17);
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        s_chunk += 128u;
+        s_kb += 18u * 64u;
+    }
+    wait_vm<0>();           // the two trailing requests must land before this workgroup's LDS is released
+
+    // epilogue: lane holds D[row = lq*4 + r][col = lr] of each 16x16 fragment
+    const int act = a.act;
+    const int mw = m0 + wm * MF * 16;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int fr = f0 + wn * NF + j;
+        const int co = fr * 16 + lr;
+        const bool cv = co < a.cout;
+        const float b = a.bias[min(fr, a.n16 - 1) * 16 + lr];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = mw + f * 16 + lq * 4 + rr;
+                if (cv && m < a.M) {
+                    float v = act_apply5(acc[f][j][rr] + b, act);
+                    if (a.res) v += a.res[(long long)m * a.res_cs + a.res_choff + co];
+                    a.out[(long long)m * a.out_cs + a.out_choff + co] = v;
+                }
+            }
+        }
+    }
+#undef PADEL_TAP_STEP
+#undef PADEL_TAP_REQUEST
+}
+
+template <int WM, int WN, int MF, int NF>
+static hipError_t launch_t(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    constexpr int BM = WM * MF * 16;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
+    hipLaunchKernelGGL((conv_tap_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+    return hipGetLastError();
+}
+
+// same variant ids as conv_lds.hip / conv_ring.hip; hipErrorNotSupported when the layer or the tile is not covered
+hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s) {
+    if (a.ksize != 3 || (a.cin & 31) || a.cin < 32) return hipErrorNotSupported;
+    switch (variant) {
+        case 6: return launch_t<2, 2, 2, 4>(a, s);    //  64 x 128
+        case 7: return launch_t<2, 2, 2, 3>(a, s);    //  64 x  96
+        case 9: return launch_t<4, 1, 2, 4>(a, s);    // 128 x  64
+        case 10: return launch_t<2, 2, 4, 2>(a, s);   // 128 x  64 (2x2 waves)
+        case 11: return launch_t<4, 1, 2, 2>(a, s);   // 128 x  32
+        case 13: return launch_t<4, 2, 2, 3>(a, s);   // 128 x  96,  8 waves
+        case 14: return launch_t<4, 2, 2, 4>(a, s);   // 128 x 128,  8 waves
+        case 15: return launch_t<4, 2, 2, 2>(a, s);   // 128 x  64,  8 waves
+    }
+    return hipErrorNotSupported;
+}
+
+}  // namespace padel

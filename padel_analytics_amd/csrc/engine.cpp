@@ -206,7 +206,7 @@ int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weight
     m->d.bufs = m->bufs.data();
     m->d.ops = m->ops.data();
     m->n_w = n_floats;
-    hipError_t r = hipMalloc((void**)&m->d_w, n_floats * sizeof(float));
+    hipError_t r = hipMalloc((void**)&m->d_w, n_floats * sizeof(float) + kConvReadSlack);
     if (r == hipSuccess) r = hipMemcpyAsync(m->d_w, weights, n_floats * sizeof(float), hipMemcpyHostToDevice, e->stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
     if (r != hipSuccess) { delete m; PA_FAIL(e, "weights upload: %s", hipGetErrorString(r)); }
@@ -316,8 +316,8 @@ static int plan_buffers(pa_model* m, int batch) {
     for (size_t i = 0; i < m->bufs.size(); ++i) {
         const size_t H = m->net_h >> m->bufs[i].level, W = m->net_w >> m->bufs[i].level;
         const size_t bytes = (size_t)batch * H * W * m->bufs[i].channels * sizeof(float);
-        PA_HIP(e, hipMalloc((void**)&m->bptr[i], bytes));
-        PA_HIP(e, hipMemsetAsync(m->bptr[i], 0, bytes, e->stream));
+        PA_HIP(e, hipMalloc((void**)&m->bptr[i], bytes + kConvReadSlack));
+        PA_HIP(e, hipMemsetAsync(m->bptr[i], 0, bytes + kConvReadSlack, e->stream));
     }
     m->p_batch = batch;
     return 0;
@@ -439,11 +439,37 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
             if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = mf; pr->nf = nf; }
             const bool use_pipe = getenv("PADEL_CONV_PIPE") && atoi(getenv("PADEL_CONV_PIPE"));
-            if (lv >= 0 && use_pipe) {
+            // tuning only: PADEL_CONV_DBG=<file> collects the DIAG-16 timeline of this launch (conv_lds.hip) into <file>
+            unsigned long long* dbg_dev = nullptr;
+            size_t dbg_bytes = 0;
+            if (const char* dbgf = getenv("PADEL_CONV_DBG")) {
+                (void)dbgf;
+                int bm = 64, bn = 96;
+                dbg_bytes = (size_t)((a.M + bm - 1) / bm) * ((o.npad + bn - 1) / bn) * kConvDbgWords * 8;
+                if (hipMalloc(&dbg_dev, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(dbg_dev, 0, dbg_bytes, s);
+                else dbg_dev = nullptr;
+                a.dbg = dbg_dev;
+            }
+            const bool use_ring = getenv("PADEL_CONV_RING") && atoi(getenv("PADEL_CONV_RING"));
+            const bool use_tap = getenv("PADEL_CONV_TAP") && atoi(getenv("PADEL_CONV_TAP"));
+            if (lv >= 0 && use_tap) {
+                r = launch_conv_tap(a, lv, s);
+                if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);
+            } else if (lv >= 0 && use_ring) {
+                r = launch_conv_ring(a, lv, s);
+                if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);
+            } else if (lv >= 0 && use_pipe) {
                 r = launch_conv_pipe(a, lv, s);
                 if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);
             } else {
                 r = lv >= 0 ? launch_conv_lds(a, lv, s) : launch_conv_igemm(a, mf, nf, s);
+            }
+            if (dbg_dev) {
+                (void)hipStreamSynchronize(s);
+                std::vector<unsigned long long> host(dbg_bytes / 8);
+                (void)hipMemcpy(host.data(), dbg_dev, dbg_bytes, hipMemcpyDeviceToHost);
+                if (FILE* f = fopen(getenv("PADEL_CONV_DBG"), "wb")) { fwrite(host.data(), 1, dbg_bytes, f); fclose(f); }
+                (void)hipFree(dbg_dev);
             }
         } else if (o.kind == PA_OP_STEM) {
             StemArgs a{};

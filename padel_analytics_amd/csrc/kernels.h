@@ -31,7 +31,10 @@ struct ConvArgs {
     int M;                // batch * Ho * Wo
     int n_mtiles;         // ceil(M / (4 * MF * 16))
     int tune;             // bit 0: s_setprio(1) around MFMA clusters; bit 1: staggered workgroup start
+    unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_lds.hip DIAG 16
 };
+constexpr int kConvDbgSteps = 64;                       // k-steps kept per wave (ring)
+constexpr int kConvDbgWords = 8 + 4 * kConvDbgSteps * 5;   // u64 words per workgroup: header + 4 waves x steps x 5 stamps
 
 // implicit-GEMM conv on v_mfma_f32_16x16x4_f32; MF in {1,2,4}, NF in {1..6}
 hipError_t launch_conv_igemm(const ConvArgs& a, int mf, int nf, hipStream_t s);
@@ -46,6 +49,12 @@ void conv_lds_variant_shape(int variant, int* bm, int* bn);
 int choose_conv_lds_variant(int M, int n16);
 // v3 (opt-in): 3-stage LDS ring + double-buffered fragments; same variant ids, hipErrorNotSupported if not instantiated
 hipError_t launch_conv_pipe(const ConvArgs& a, int variant, hipStream_t s);
+// v4: LDS-DMA ring (conv_ring.hip); hipErrorNotSupported for tiles it is not instantiated for
+hipError_t launch_conv_ring(const ConvArgs& a, int variant, hipStream_t s);
+// v5: tap-unrolled LDS-DMA ring for 3x3 convs with cin % 32 == 0 (conv_tap.hip); reads up to 128 B past the last
+// chunk of a pixel / weight row, so every buffer a conv reads is allocated with kConvReadSlack extra bytes
+hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s);
+constexpr size_t kConvReadSlack = 512;
 
 struct StemArgs {
     const uint8_t* in;    // net input u8 NHWC4 [B][H][W][4]

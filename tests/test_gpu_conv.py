@@ -23,6 +23,8 @@ CASES = [
     (2, 12, 20, 64, 144, 3, 1, G.ACT_SIGMOID, False),
     (1, 36, 28, 288, 48, 1, 1, G.ACT_SILU, True),
     (1, 8, 12, 576, 192, 3, 1, G.ACT_SILU, False),    # long K: exercises several accumulation blocks
+    (2, 32, 48, 64, 96, 3, 2, G.ACT_SILU, False),     # stride 2 with cin % 32 == 0 (tap-unrolled kernel's stride path)
+    (3, 17, 23, 96, 96, 3, 1, G.ACT_SILU, True),      # odd spatial size: M tail + borders in every tile, residual
 ]
 
 
@@ -45,7 +47,7 @@ def _run(eng, case, x, w, b, res):
 
 
 def _setenv(**kw):
-    for k in ("PADEL_CONV_IMPL", "PADEL_CONV_MF", "PADEL_CONV_NF", "PADEL_CONV_LDS_VARIANT", "PADEL_CONV_KB", "PADEL_CONV_PIPE"):
+    for k in ("PADEL_CONV_IMPL", "PADEL_CONV_MF", "PADEL_CONV_NF", "PADEL_CONV_LDS_VARIANT", "PADEL_CONV_KB", "PADEL_CONV_PIPE", "PADEL_CONV_RING", "PADEL_CONV_TAP"):
         os.environ.pop(k, None)
     os.environ.update({k: str(v) for k, v in kw.items()})
 
@@ -77,6 +79,15 @@ def test_conv_variants(gpu_engine, case):
         for v in (0, 1, 6, 7, 9, 10, 11):             # v3: 3-stage LDS ring, double-buffered fragments
             _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_PIPE=1)
             outs[f"P{v}"] = _run(gpu_engine, case, x, w, b, None)
+        for v in (1, 4, 6, 7, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19):   # v4 (13..19: 8/16-wave workgroups): LDS-DMA ring (global_load_lds, counted vmcnt, raw barrier)
+            _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_RING=1)
+            for rep in range(2):                       # twice: a DMA/barrier race would not be deterministic
+                outs[f"R{v}.{rep}"] = _run(gpu_engine, case, x, w, b, None)
+        if k == 3 and cin % 32 == 0:                   # v5: tap-unrolled DMA ring (buffer addressing, zeros by range check)
+            for v in (6, 7, 9, 10, 11, 13, 14, 15):
+                _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_TAP=1)
+                for rep in range(2):
+                    outs[f"T{v}.{rep}"] = _run(gpu_engine, case, x, w, b, None)
         for v in (1, 7, 9, 11):                        # two k-steps per barrier (32-wide LDS stages)
             _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_KB=2)
             outs[f"L{v}k2"] = _run(gpu_engine, case, x, w, b, None)

@@ -80,6 +80,16 @@ if __name__ == "__main__":
         elif t.startswith("P"):
             env["PADEL_CONV_LDS_VARIANT"] = t[1:]
             env["PADEL_CONV_PIPE"] = "1"
+        elif t.startswith("T"):                       # v5 tap-unrolled DMA ring (3x3, cin % 32 == 0), same variant ids
+            v, _, tune = t[1:].partition("t")
+            env["PADEL_CONV_LDS_VARIANT"] = v
+            env["PADEL_CONV_TAP"] = "1"
+        elif t.startswith("R"):                       # v4 LDS-DMA ring, same variant ids
+            v, _, tune = t[1:].partition("t")
+            env["PADEL_CONV_LDS_VARIANT"] = v
+            env["PADEL_CONV_RING"] = "1"
+            if tune:
+                env["PADEL_CONV_TUNE"] = tune
         elif t.startswith("L"):
             body, _, tune = t[1:].partition("t")
             v, _, kb = body.partition("k")

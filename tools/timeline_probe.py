@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""Per-wave s_memtime timeline of the 64x96 LDS conv tile (tuning tool, GPU only).
+
+Runs the yolov8m P4 bottleneck conv (192->192 3x3, batch 64) through the DIAG-16 instantiation of
+conv_lds_kernel (every wave stamps 5 points of every k-step: loop top / fragments in registers / last MFMA issued /
+prefetch landed / after store+barrier), reads the dump (PADEL_CONV_DBG) and prints where a k-step's cycles go,
+chip-wide and as an ASCII timeline of the waves that shared one SIMD.
+
+    python tools/timeline_probe.py [--out gpurun_out/timeline.txt]
+"""
+import argparse, os, sys
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+STEPS, WORDS = 64, 8 + 4 * 64 * 5
+
+
+def run_conv(dump, B=64, H=48, W=80, cin=192, cout=192):
+    os.environ.update(PADEL_CONV_LDS_VARIANT="7", PADEL_CONV_DIAG="16", PADEL_CONV_DBG=dump)
+    from padel_analytics_amd import engine as E, graph as G
+    eng = E.default_engine(0)
+    eng.set_profiling(True)
+    rng = np.random.default_rng(0)
+    g = G.Graph(task=G.TASK_TRACKNET)
+    b0 = g.buf(0, cin)
+    b1 = g.buf(0, G.pad16(cout))
+    w = rng.normal(0, (2.0 / (cin * 9)) ** 0.5, (cout, cin, 3, 3)).astype(np.float32)
+    g.conv((b0, 0, cin), (b1, 0), w, np.zeros(cout, np.float32), 3, 1, 1)
+    g.head_buf = (b1, -1, -1)
+    m = E.Model(eng, g)
+    m.set_max_batch(B)
+    x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32)
+    for _ in range(2):
+        m.tracknet_infer(x)
+    ms = [p for p in m.profile_rows() if p["kind"] == 2][0]["ms"]
+    m.close()
+    return ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/timeline.txt")
+    ap.add_argument("--dump", default="/tmp/padel_conv_timeline.bin")
+    a = ap.parse_args()
+    ms = run_conv(a.dump)
+    raw = np.fromfile(a.dump, dtype=np.uint64)
+    nblk = raw.size // WORDS
+    raw = raw[: nblk * WORDS].reshape(nblk, WORDS)
+    hdr = raw[:, :8]
+    st = raw[:, 8:].reshape(nblk, 4, STEPS, 5).astype(np.int64)
+    nks = int(hdr[0, 6])
+    out = []
+    P = out.append
+    P(f"conv 192->192 3x3, M = 245760, tile 64x96, {nblk} workgroups, {nks} k-steps, instrumented kernel time {ms:.3f} ms")
+    life = (hdr[:, 5].astype(np.int64) - hdr[:, 4].astype(np.int64))
+    P(f"workgroup lifetime (s_memtime ticks): mean {life.mean():.0f}  p10 {np.percentile(life, 10):.0f}  p90 {np.percentile(life, 90):.0f}"
+      f"  -> {life.mean() / nks:.0f} ticks per k-step incl. prologue/epilogue")
+    # steps whose 5 stamps are all from the same pass of the ring: nks-64 .. nks-3
+    steps = np.arange(max(nks - STEPS + 2, 0), nks - 2)
+    sl = steps & (STEPS - 1)
+    t = st[:, :, sl, :]                                     # (blk, wave, step, 5)
+    nxt = st[:, :, (steps + 1) & (STEPS - 1), 0]
+    seg = {
+        "t0->t1 issue prefetch + wait fragments (ds_read)": t[..., 1] - t[..., 0],
+        "t1->t2 24 MFMAs issued (768 if alone)": t[..., 2] - t[..., 1],
+        "t2->t3 wait prefetch (vmcnt 0)": t[..., 3] - t[..., 2],
+        "t3->t4 ds_write + barrier": t[..., 4] - t[..., 3],
+        "t4->t0' loop back": nxt - t[..., 4],
+        "whole k-step": nxt - t[..., 0],
+    }
+    P("\nper k-step segment, ticks (all workgroups, waves, steps %d..%d):" % (steps[0], steps[-1]))
+    for k, v in seg.items():
+        v = v.reshape(-1)
+        P(f"  {k:52s} mean {v.mean():7.0f}  p10 {np.percentile(v, 10):6.0f}  p50 {np.percentile(v, 50):6.0f}  p90 {np.percentile(v, 90):6.0f}")
+    # prologue / epilogue (ring keeps steps nks-64 ..): epilogue = last MFMA issued -> end stamp
+    first = max(nks - STEPS, 0)
+    t_first = st[:, 0, first & (STEPS - 1), 0]
+    t_lastm = st[:, 0, (nks - 1) & (STEPS - 1), 2]
+    tb, te = hdr[:, 4].astype(np.int64), hdr[:, 5].astype(np.int64)
+    epi = te - t_lastm
+    mainloop = (t_lastm - t_first) / (nks - first)
+    pro = (t_first - tb) - mainloop * first
+    P(f"\nwave 0: epilogue (last MFMA issued -> all stores issued) mean {epi.mean():.0f} p10 {np.percentile(epi, 10):.0f} p90 {np.percentile(epi, 90):.0f} ticks;"
+      f" prologue (estimated) mean {pro.mean():.0f}; main loop {mainloop.mean():.0f} ticks/k-step")
+    # --- one SIMD's view
+    hw = (hdr[:, 0] & 0xFFFFFFFF).astype(np.int64)         # wave 0 of every workgroup
+    xcc = (hdr[:, 0] >> 32).astype(np.int64) & 0xF
+    cu = (hw >> 8) & 0xF
+    sh = (hw >> 12) & 1
+    se = (hw >> 13) & 7
+    key = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    uniq, cnt = np.unique(key, return_counts=True)
+    P(f"\ndistinct (xcc, se, sh, cu) seen: {uniq.size}; workgroups per CU: min {cnt.min()} max {cnt.max()}")
+    pick = uniq[np.argmax(cnt)]
+    blks = np.where(key == pick)[0]
+    blks = blks[np.argsort(hdr[blks, 4])]
+    # take workgroups from the middle of the kernel
+    ref = blks[len(blks) // 2]
+    t_lo = int(st[ref, 0, steps[5] & (STEPS - 1), 0])
+    t_hi = t_lo + 160 * 64
+    rec_lo = st[blks, 0, steps[0] & (STEPS - 1), 0]
+    rec_hi = st[blks, 0, steps[-1] & (STEPS - 1), 0]
+    mid = blks[(rec_lo < t_hi) & (rec_hi > t_lo)]
+    P(f"CU key {pick}: {len(blks)} workgroups; timeline of wave 0 of the workgroups alive around tick {t_lo} (their SIMD ids: "
+      + ", ".join(str(int((hdr[b, 0] >> 4) & 3)) for b in mid) + ")")
+    width, res = 160, 64                                    # 160 columns x 64 ticks
+    for wv in range(4):
+        P(f"  -- wave {wv} of each workgroup (one SIMD per wave index if the 4 waves spread over the 4 SIMDs):")
+        for b in mid:
+            simd = int((hdr[b, wv] >> 4) & 3)
+            row = [" "] * width
+            for s in steps:
+                e = st[b, wv, s & (STEPS - 1)]
+                n0 = st[b, wv, (s + 1) & (STEPS - 1), 0]
+                for (lo, hi, ch) in ((e[0], e[1], "l"), (e[1], e[2], "M"), (e[2], e[3], "w"), (e[3], e[4], "b"), (e[4], n0, ".")):
+                    c0, c1 = int((lo - t_lo) // res), int((hi - t_lo) // res)
+                    for c in range(max(c0, 0), min(c1 + 1, width)):
+                        row[c] = ch
+            P(f"     wg {int(hdr[b, 7]):5d} simd {simd}: " + "".join(row))
+    P("  legend: l = prefetch issue + ds_read wait, M = MFMA burst being issued, w = vmcnt wait, b = ds_write + barrier; "
+      f"1 column = {res} ticks")
+    # compact copy of 16 CUs for offline analysis
+    keep = np.where(np.isin(key, uniq[:16]))[0]
+    np.savez_compressed(str(Path(a.out).with_suffix(".npz")), hdr=hdr[keep], st=(st[keep] - tb[keep, None, None, None]).astype(np.int32),
+                        key=key[keep], tb=tb[keep], te=te[keep])
+    txt = "\n".join(out)
+    print(txt)
+    Path(a.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(a.out).write_text(txt + "\n")
+
+
+if __name__ == "__main__":
+    main()
