@@ -239,7 +239,7 @@ def main():
         ms_all = sum(r["ms"] for r in recs)
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         out["roofline"] = {
-            "kernel": "conv_lds_kernel<...,3> / conv_igemm_kernel<...,3> (3x3 conv+BN+SiLU implicit GEMM, v_mfma_f32_16x16x4_f32)",
+            "kernel": "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)",
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
             "launches": len(c3), "avg_launch_ms": round(ms3 / max(len(c3), 1), 4),

@@ -370,6 +370,7 @@ static const LdsVariant lds_variants[] = {
     {17, 4, 4, 2, 3},  // 128 x 192
     {18, 2, 4, 2, 3},  //  64 x 192
     {19, 8, 1, 2, 3},  // 256 x  48
+    {20, 4, 1, 2, 3},  // 128 x  48
 };
 constexpr int kFirstRingOnly = 13;
 

@@ -287,6 +287,7 @@ hipError_t launch_conv_ring(const ConvArgs& a, int variant, hipStream_t s) {
         case 17: return launch_r<4, 4, 2, 3>(a, s);   // 128 x 192, 16 waves
         case 18: return launch_r<2, 4, 2, 3>(a, s);   //  64 x 192,  8 waves
         case 19: return launch_r<8, 1, 2, 3>(a, s);   // 256 x  48,  8 waves
+        case 20: return launch_r<4, 1, 2, 3>(a, s);   // 128 x  48
     }
     return hipErrorNotSupported;
 }

@@ -1,4 +1,4 @@
-// K3 v5 — tap-unrolled LDS-DMA ring for the 3x3 convs (cin % 32 == 0): the instruction diet.
+// K3/K4 v5 — tap-unrolled LDS-DMA ring for the 3x3 and 1x1 convs: the instruction diet.
 //
 // Same tiles, operands, K order, swizzled LDS image, ring and two-level accumulation as conv_ring.hip (results are
 // bit-identical with v1/v2/v4).  Why another kernel: the s_memtime timeline of v2 (tools/timeline_probe.py,
@@ -19,6 +19,12 @@
 // A k-step is: s_waitcnt vmcnt(n) ; s_barrier ; 2-3 LDS-DMA requests (3 SALU each) ; 5 ds_read_b128 ; 24 MFMA.
 // Requests run two steps ahead and read up to 128 bytes past the last chunk of a pixel / weight row (data that is
 // never used); the engine allocates its buffers with that slack.
+//
+// cin % 32 == 16 (the 16-channel K tail: 9 steps of one half per tap) is a second unrolled block; the two requests
+// that cross from the last full chunk into it take their tap offsets from registers selected once per chunk.
+// The 1x1 kernel (conv_tap1_kernel) is the same machine with one offset per lane, a 4-stage ring (its accumulation
+// block has 16 steps; 16 % 4 == 0 keeps the stage a compile-time constant) and a per-step `J < steps` guard for
+// the last, shorter block.
 #include "kernels.h"
 #include <cmath>
 #include <cstdint>
@@ -67,43 +73,121 @@ constexpr int tap_min_waves(int nw, int frags) {
     return nw == 4 ? (frags <= 6 ? 5 : 4) : 4;
 }
 
+// ---- pieces shared by the 3x3 and the 1x1 kernel (macros: everything must stay in registers of the caller)
+
+// LDS-DMA requests of one k-step into ring stage SR_: A passes with per-pass lane offsets VA0_/VA1_ and SGPR offset
+// SA_, B passes with SGPR offset SB_
+#define PADEL_TAP_DMA(SR_, SA_, SB_, VA0_, VA1_)                                                                  \
+    do {                                                                                                          \
+        const unsigned sa_ = (SA_), sb_ = (SB_);                                                                  \
+        dma16<(SR_) * STAGE_B>((VA0_), rsrcA, sa_, lds_wave);                                                     \
+        if constexpr (AP >= 2) dma16<(SR_) * STAGE_B + RP * 64>((VA1_), rsrcA, sa_, lds_wave);                    \
+        if constexpr (BFULL >= 1) dma16<(SR_) * STAGE_B + BM * 64>(voffB[0], rsrcB, sb_, lds_wave);               \
+        if constexpr (BFULL >= 2) dma16<(SR_) * STAGE_B + BM * 64 + RP * 64>(voffB[1], rsrcB, sb_, lds_wave);     \
+        if constexpr (BP > BFULL) { if (b_last) dma16<(SR_) * STAGE_B + BM * 64 + BFULL * RP * 64>(voffB[BP - 1], rsrcB, sb_, lds_wave); } \
+    } while (0)
+
+// fragments of ring stage ST_ -> MF * NF * 4 MFMAs on `part`
+#define PADEL_TAP_COMPUTE(ST_)                                                                                    \
+    do {                                                                                                          \
+        f32x4 A_[MF], B_[NF];                                                                                     \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) A_[f] = *reinterpret_cast<const f32x4*>(a_rd + (ST_) * STAGE + f * 256); \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) B_[j] = *reinterpret_cast<const f32x4*>(b_rd + (ST_) * STAGE + j * 256); \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
+                _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                    \
+                    part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[f][kk], B_[j][kk], part[f][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+
+#define PADEL_TAP_FLUSH()                                                                                         \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                            \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
+    } while (0)
+
+// epilogue: lane holds D[row = lq*4 + r][col = lr] of each 16x16 fragment
+template <int MF, int NF>
+__device__ __forceinline__ void tap_epilogue(const ConvArgs& a, const f32x4 (&acc)[MF][NF], int mw, int fw, int lr, int lq) {
+    const int act = a.act;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int fr = fw + j;
+        const int co = fr * 16 + lr;
+        const bool cv = co < a.cout;
+        const float b = a.bias[min(fr, a.n16 - 1) * 16 + lr];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int m = mw + f * 16 + lq * 4 + rr;
+                if (cv && m < a.M) {
+                    float v = act_apply5(acc[f][j][rr] + b, act);
+                    if (a.res) v += a.res[(long long)m * a.res_cs + a.res_choff + co];
+                    a.out[(long long)m * a.out_cs + a.out_choff + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// common head of both kernels: tile geometry, wave / lane ids, XCD-aware tile index
+#define PADEL_TAP_GEOMETRY(NST_)                                                                                  \
+    constexpr int NW = WM * WN;              /* waves per workgroup (4 or 8) */                                   \
+    constexpr int RP = NW * 16;              /* tile rows staged per pass: one wave-instruction (16 rows) per wave */ \
+    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;                                                           \
+    constexpr int AP = BM / RP, BP = (BN + RP - 1) / RP, BFULL = BN / RP;                                         \
+    constexpr int NST = (NST_);                                                                                   \
+    constexpr int STAGE = (BM + BN) * 16;    /* floats per ring stage: A rows then B rows, 64 bytes each */       \
+    constexpr int STAGE_B = STAGE * 4;                                                                            \
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");                                              \
+    static_assert(BM % RP == 0 && AP <= 2 && BFULL <= 2, "A in 1-2 full passes, B in at most 2 full + 1 partial"); \
+    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];                                               \
+    const int tid = threadIdx.x;                                                                                  \
+    const int lane = tid & 63;                                                                                    \
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                    \
+    const int lr = lane & 15, lq = lane >> 4;                                                                     \
+    const int wm = wave / WN, wn = wave % WN;                                                                     \
+    const int nmt = a.n_mtiles;                                                                                   \
+    const int bid = blockIdx.x;                                                                                   \
+    const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;                                           \
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                 \
+    const int m0 = mt * BM;                                                                                       \
+    const int f0 = blockIdx.y * (WN * NF);   /* first 16-channel fragment of this workgroup */                    \
+    const int HoWo = a.Ho * a.Wo;                                                                                 \
+    const int srow = tid >> 2;                                                                                    \
+    const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);     /* source chunk of LDS slot tid&3 (swizzle) */  \
+    const int n0 = m0 / HoWo, rem0 = m0 - n0 * HoWo, oy0 = rem0 / a.Wo, ox0 = rem0 - oy0 * a.Wo;                  \
+    const long long lin0 = ((long long)n0 * a.H + oy0 * a.stride) * a.W + ox0 * a.stride;     /* uniform */       \
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + wave * 1024u);            \
+    const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);                                       \
+    const float* const a_rd = lds + (wm * MF * 16) * 16 + ld_off;                                                 \
+    const float* const b_rd = lds + BM * 16 + (wn * NF * 16) * 16 + ld_off;                                       \
+    const bool b_last = BP > BFULL && (BFULL * RP + wave * 16 < BN);   /* this wave takes part in the partial B pass */ \
+    f32x4 acc[MF][NF], part[MF][NF];                                                                              \
+    _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                                \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+// B: weight rows of this workgroup's channel tile (lane offsets relative to the tile's first row)
+#define PADEL_TAP_WEIGHTS()                                                                                       \
+    unsigned voffB[BP];                                                                                           \
+    _Pragma("unroll") for (int p = 0; p < BP; ++p) {                                                              \
+        const int rr = srow + RP * p;                       /* row inside the BN tile */                          \
+        const int frag = min(f0 + (rr >> 4), a.n16 - 1);    /* clamp: partial last channel tile */                \
+        voffB[p] = (unsigned)((((frag - f0) * 16 + (rr & 15)) * Ktot + sc * 4) * 4);                              \
+    }                                                                                                             \
+    const i32x4 rsrcB = make_rsrc(a.w + (long long)f0 * 16 * Ktot);
+
+// =====================================================================================================  3x3
 template <int WM, int WN, int MF, int NF>
 __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF)) conv_tap_kernel(const ConvArgs a) {
-    constexpr int NW = WM * WN;              // waves per workgroup (4 or 8)
-    constexpr int RP = NW * 16;              // tile rows staged per pass: one wave-instruction (16 rows) per wave
-    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;
-    constexpr int AP = (BM + RP - 1) / RP, BP = (BN + RP - 1) / RP;
-    constexpr int AFULL = BM / RP, BFULL = BN / RP;        // passes every wave takes part in
-    constexpr int NST = 3;
-    constexpr int STAGE = (BM + BN) * 16;    // floats per ring stage: A rows then B rows, 64 bytes each
-    constexpr int STAGE_B = STAGE * 4;
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, lq = lane >> 4;
-    const int wm = wave / WN, wn = wave % WN;
-
-    // XCD-aware (bijective) remap of the pixel-tile index
-    const int nmt = a.n_mtiles;
-    const int bid = blockIdx.x;
-    const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;
-    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int nt = blockIdx.y;
-    const int m0 = mt * BM;
-    const int f0 = nt * (WN * NF);           // first 16-channel fragment of this workgroup
-
-    const int HoWo = a.Ho * a.Wo;
-    const int nchunks = a.cin >> 5;          // cin % 32 == 0 (launcher)
-    const int Ktot = nchunks * 288;
+    PADEL_TAP_GEOMETRY(3)
+    const int nfull = a.cin >> 5;            // 32-channel chunks: 18 k-steps each
+    const bool has_tail = (a.cin & 16) != 0; // + 9 k-steps of the last 16 channels
+    const int Ktot = (nfull * 18 + (has_tail ? 9 : 0)) * 16;
 
     // ---- A: per lane and tap one byte offset relative to the tap-(0,0) pixel of the workgroup's first row
-    const int srow = tid >> 2;
-    const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);     // source chunk of LDS slot tid&3 (swizzle)
-    const int n0 = m0 / HoWo, rem0 = m0 - n0 * HoWo, oy0 = rem0 / a.Wo, ox0 = rem0 - oy0 * a.Wo;
-    const long long lin0 = ((long long)n0 * a.H + oy0 * a.stride) * a.W + ox0 * a.stride;     // uniform
     unsigned voffA[AP][9];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
@@ -124,116 +208,129 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
         }
     }
     // base of the A descriptor: channel slice of the tap-(0,0) pixel of row m0 (may lie below a.in: never dereferenced there)
-    const float* baseA = a.in + ((lin0 - (a.W + 1)) * a.in_cs + a.in_choff);
-    const i32x4 rsrcA = make_rsrc(baseA);
+    const i32x4 rsrcA = make_rsrc(a.in + ((lin0 - (a.W + 1)) * a.in_cs + a.in_choff));
     unsigned tapoff[18];                      // SGPRs: byte offset of (tap, half) inside a chunk
 #pragma unroll
     for (int j = 0; j < 18; ++j) {
         const int t = j >> 1, ky = t / 3, kx = t % 3;
         tapoff[j] = __builtin_amdgcn_readfirstlane((unsigned)(((ky * a.W + kx) * a.in_cs + (j & 1) * 16) * 4));
     }
-    // ---- B: weight rows of this workgroup's channel tile
-    unsigned voffB[BP];
-#pragma unroll
-    for (int p = 0; p < BP; ++p) {
-        const int rr = srow + RP * p;                       // row inside the BN tile
-        const int frag = min(f0 + (rr >> 4), a.n16 - 1);    // clamp: partial last channel tile
-        voffB[p] = (unsigned)((((frag - f0) * 16 + (rr & 15)) * Ktot + sc * 4) * 4);
-    }
-    const i32x4 rsrcB = make_rsrc(a.w + (long long)f0 * 16 * Ktot);
-
-    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + wave * 1024u);
-    const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);
-    const float* const a_rd = lds + (wm * MF * 16) * 16 + ld_off;
-    const float* const b_rd = lds + BM * 16 + (wn * NF * 16) * 16 + ld_off;
-    const bool a_last = AP > AFULL && (AFULL * RP + wave * 16 < BM);      // this wave takes part in the partial pass
-    const bool b_last = BP > BFULL && (BFULL * RP + wave * 16 < BN);
-
-    f32x4 acc[MF][NF], part[MF][NF];
-#pragma unroll
-    for (int f = 0; f < MF; ++f)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    PADEL_TAP_WEIGHTS()
 
     unsigned s_chunk = 0;                     // byte offset of the current 32-channel chunk inside a pixel
-    unsigned s_kb = 0;                        // byte offset of the current chunk inside a weight row (18 steps x 64 B)
+    unsigned s_kb = 0;                        // byte offset of the current block inside a weight row (64 B per k-step)
+    // step 1 of the NEXT block is (tap 0, half 1) in a full chunk but (tap 1, half 0) in the tail block: its SGPR and
+    // lane offsets sit in registers that are re-selected once per chunk (step 0 is (tap 0, half 0) either way)
+    bool nxt_tail = nfull == 0;
+    unsigned wrap_off1 = nxt_tail ? tapoff[2] : tapoff[1];
+    unsigned wrapv1[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) wrapv1[p] = nxt_tail ? voffA[p][1] : voffA[p][0];
 
-    // request chunk-relative step JR (of the current chunk, or of the next one when WRAP) into ring stage JR % 3
-#define PADEL_TAP_REQUEST(JR, WRAP)                                                                              \
-    do {                                                                                                         \
-        constexpr int SR_ = (JR) % 3;                                                                            \
-        const unsigned sa_ = s_chunk + tapoff[JR] + ((WRAP) ? 128u : 0u);                                        \
-        const unsigned sb_ = s_kb + ((JR) + ((WRAP) ? 18 : 0)) * 64u;                                            \
-        if constexpr (AFULL >= 1) dma16<SR_ * STAGE_B>(voffA[0][(JR) >> 1], rsrcA, sa_, lds_wave);               \
-        if constexpr (AFULL >= 2) dma16<SR_ * STAGE_B + RP * 64>(voffA[1][(JR) >> 1], rsrcA, sa_, lds_wave);     \
-        if constexpr (AP > AFULL) { if (a_last) dma16<SR_ * STAGE_B + AFULL * RP * 64>(voffA[AP - 1][(JR) >> 1], rsrcA, sa_, lds_wave); } \
-        if constexpr (BFULL >= 1) dma16<SR_ * STAGE_B + BM * 64>(voffB[0], rsrcB, sb_, lds_wave);                \
-        if constexpr (BFULL >= 2) dma16<SR_ * STAGE_B + BM * 64 + RP * 64>(voffB[1], rsrcB, sb_, lds_wave);      \
-        if constexpr (BP > BFULL) { if (b_last) dma16<SR_ * STAGE_B + BM * 64 + BFULL * RP * 64>(voffB[BP - 1], rsrcB, sb_, lds_wave); } \
-    } while (0)
-
-    // one k-step: chunk-relative step J is read from ring stage J % 3 while step J + 2 is requested
-#define PADEL_TAP_STEP(J)                                                                                        \
-    do {                                                                                                         \
-        constexpr int ST_ = (J) % 3;                                                                             \
-        wait_vm<AFULL + BFULL>();               /* own requests of step J landed (the younger ones may fly on) */ \
+    // chunk-relative step J of a full chunk: read stage J % 3, request step J + 2 (steps 16, 17 request the next block)
+#define PADEL_TAP_STEP(J)                                                                                         \
+    do {                                                                                                          \
+        wait_vm<AP + BFULL>();                  /* own requests of step J landed (the younger ones may fly on) */ \
         __builtin_amdgcn_s_barrier();           /* ... everybody's did; stage (J + 2) % 3 is free again */        \
-        PADEL_TAP_REQUEST(((J) + 2) % 18, (J) + 2 >= 18);                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                       \
-        {                                                                                                        \
-            f32x4 A_[MF], B_[NF];                                                                                \
-            _Pragma("unroll") for (int f = 0; f < MF; ++f) A_[f] = *reinterpret_cast<const f32x4*>(a_rd + ST_ * STAGE + f * 256); \
-            _Pragma("unroll") for (int j = 0; j < NF; ++j) B_[j] = *reinterpret_cast<const f32x4*>(b_rd + ST_ * STAGE + j * 256); \
-            __builtin_amdgcn_s_setprio(1);                                                                       \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                     \
-                _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                   \
-                    _Pragma("unroll") for (int j = 0; j < NF; ++j)                                               \
-                        part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[f][kk], B_[j][kk], part[f][j], 0, 0, 0); \
-            __builtin_amdgcn_s_setprio(0);                                                                       \
-        }                                                                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if constexpr ((J) + 2 < 18)                                                                               \
+            PADEL_TAP_DMA(((J) + 2) % 3, s_chunk + tapoff[((J) + 2) % 18], s_kb + ((J) + 2) * 64u,                \
+                          voffA[0][(((J) + 2) % 18) >> 1], voffA[AP - 1][(((J) + 2) % 18) >> 1]);                 \
+        else if constexpr ((J) == 16)                                                                             \
+            PADEL_TAP_DMA(0, s_chunk + 128u + tapoff[0], s_kb + 18 * 64u, voffA[0][0], voffA[AP - 1][0]);         \
+        else                                                                                                      \
+            PADEL_TAP_DMA(1, s_chunk + 128u + wrap_off1, s_kb + 19 * 64u, wrapv1[0], wrapv1[AP - 1]);             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_TAP_COMPUTE((J) % 3);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    // step J of the tail block (tap J, half 0): nothing is requested past its last step, so step 8 drains the queue
+#define PADEL_TAP_TSTEP(J)                                                                                        \
+    do {                                                                                                          \
+        if constexpr ((J) == 8) wait_vm<0>(); else wait_vm<AP + BFULL>();                                         \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        if constexpr ((J) + 2 < 9)                                                                                \
+            PADEL_TAP_DMA(((J) + 2) % 3, s_chunk + tapoff[2 * ((J) + 2 < 9 ? (J) + 2 : 0)], s_kb + ((J) + 2) * 64u, \
+                          voffA[0][(J) + 2 < 9 ? (J) + 2 : 0], voffA[AP - 1][(J) + 2 < 9 ? (J) + 2 : 0]);         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_TAP_COMPUTE((J) % 3);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 
-    static_assert(AFULL <= 2 && BFULL <= 2, "at most two full passes per operand");
-    PADEL_TAP_REQUEST(0, false);
-    PADEL_TAP_REQUEST(1, false);
-    for (int c = 0; c < nchunks; ++c) {
+    PADEL_TAP_DMA(0, tapoff[0], 0u, voffA[0][0], voffA[AP - 1][0]);
+    PADEL_TAP_DMA(1, wrap_off1, 64u, wrapv1[0], wrapv1[AP - 1]);
+    for (int c = 0; c < nfull; ++c) {
+        nxt_tail = has_tail && c == nfull - 1;
+        wrap_off1 = nxt_tail ? tapoff[2] : tapoff[1];
+#pragma unroll
+        for (int p = 0; p < AP; ++p) wrapv1[p] = nxt_tail ? voffA[p][1] : voffA[p][0];
         PADEL_TAP_STEP(0);  PADEL_TAP_STEP(1);  PADEL_TAP_STEP(2);  PADEL_TAP_STEP(3);  PADEL_TAP_STEP(4);  PADEL_TAP_STEP(5);
         PADEL_TAP_STEP(6);  PADEL_TAP_STEP(7);  PADEL_TAP_STEP(8);  PADEL_TAP_STEP(9);  PADEL_TAP_STEP(10); PADEL_TAP_STEP(11);
         PADEL_TAP_STEP(12); PADEL_TAP_STEP(13); PADEL_TAP_STEP(14); PADEL_TAP_STEP(15); PADEL_TAP_STEP(16); PADEL_TAP_STEP(17);
-#pragma unroll
-        for (int f = 0; f < MF; ++f)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        PADEL_TAP_FLUSH();
         s_chunk += 128u;
         s_kb += 18u * 64u;
     }
-    wait_vm<0>();           // the two trailing requests must land before this workgroup's LDS is released
-
-    // epilogue: lane holds D[row = lq*4 + r][col = lr] of each 16x16 fragment
-    const int act = a.act;
-    const int mw = m0 + wm * MF * 16;
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int fr = f0 + wn * NF + j;
-        const int co = fr * 16 + lr;
-        const bool cv = co < a.cout;
-        const float b = a.bias[min(fr, a.n16 - 1) * 16 + lr];
-#pragma unroll
-        for (int f = 0; f < MF; ++f) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int m = mw + f * 16 + lq * 4 + rr;
-                if (cv && m < a.M) {
-                    float v = act_apply5(acc[f][j][rr] + b, act);
-                    if (a.res) v += a.res[(long long)m * a.res_cs + a.res_choff + co];
-                    a.out[(long long)m * a.out_cs + a.out_choff + co] = v;
-                }
-            }
-        }
+    if (has_tail) {
+        PADEL_TAP_TSTEP(0); PADEL_TAP_TSTEP(1); PADEL_TAP_TSTEP(2); PADEL_TAP_TSTEP(3); PADEL_TAP_TSTEP(4);
+        PADEL_TAP_TSTEP(5); PADEL_TAP_TSTEP(6); PADEL_TAP_TSTEP(7); PADEL_TAP_TSTEP(8);
+        PADEL_TAP_FLUSH();
+    } else {
+        wait_vm<0>();       // the two trailing requests must land before this workgroup's LDS is released
     }
+    tap_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq);
 #undef PADEL_TAP_STEP
-#undef PADEL_TAP_REQUEST
+#undef PADEL_TAP_TSTEP
+}
+
+// =====================================================================================================  1x1
+template <int WM, int WN, int MF, int NF>
+__global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF)) conv_tap1_kernel(const ConvArgs a) {
+    PADEL_TAP_GEOMETRY(4)
+    const int nks = a.cin >> 4;              // 16 channels per k-step
+    const int Ktot = nks * 16;
+
+    unsigned voffA[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        int m = m0 + srow + RP * p;
+        const bool rv = m < a.M;
+        if (!rv) m = m0;
+        const int n = m / HoWo;
+        const int rem = m - n * HoWo;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
+        voffA[p] = rv ? (unsigned)(((lin - lin0) * a.in_cs + sc * 4) * 4) : kOutOfRange;
+    }
+    const i32x4 rsrcA = make_rsrc(a.in + (lin0 * a.in_cs + a.in_choff));
+    PADEL_TAP_WEIGHTS()
+
+    unsigned s_k = 0;                         // byte offset of the current block: 64 B per k-step in a pixel AND in a weight row
+    // step J of a 16-step accumulation block: read stage J % 4, request step J + 2 (past the end: unused slack bytes)
+#define PADEL_TAP1_STEP(J)                                                                                        \
+    if ((J) < nb) {                                                                                               \
+        wait_vm<AP + BFULL>();                                                                                    \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        PADEL_TAP_DMA(((J) + 2) % 4, s_k + ((J) + 2) * 64u, s_k + ((J) + 2) * 64u, voffA[0], voffA[AP - 1]);      \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_TAP_COMPUTE((J) % 4);                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }
+
+    PADEL_TAP_DMA(0, 0u, 0u, voffA[0], voffA[AP - 1]);
+    PADEL_TAP_DMA(1, 64u, 64u, voffA[0], voffA[AP - 1]);
+    for (int k = 0; k < nks; k += 16) {
+        const int nb = min(16, nks - k);
+        PADEL_TAP1_STEP(0)  PADEL_TAP1_STEP(1)  PADEL_TAP1_STEP(2)  PADEL_TAP1_STEP(3)
+        PADEL_TAP1_STEP(4)  PADEL_TAP1_STEP(5)  PADEL_TAP1_STEP(6)  PADEL_TAP1_STEP(7)
+        PADEL_TAP1_STEP(8)  PADEL_TAP1_STEP(9)  PADEL_TAP1_STEP(10) PADEL_TAP1_STEP(11)
+        PADEL_TAP1_STEP(12) PADEL_TAP1_STEP(13) PADEL_TAP1_STEP(14) PADEL_TAP1_STEP(15)
+        PADEL_TAP_FLUSH();
+        s_k += 16u * 64u;
+    }
+    wait_vm<0>();           // the two trailing requests must land before this workgroup's LDS is released
+    tap_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq);
+#undef PADEL_TAP1_STEP
 }
 
 template <int WM, int WN, int MF, int NF>
@@ -242,24 +339,49 @@ static hipError_t launch_t(const ConvArgs& a_in, hipStream_t s) {
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
     dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
-    hipLaunchKernelGGL((conv_tap_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+    if (a.ksize == 3) hipLaunchKernelGGL((conv_tap_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+    else hipLaunchKernelGGL((conv_tap1_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     return hipGetLastError();
 }
 
 // same variant ids as conv_lds.hip / conv_ring.hip; hipErrorNotSupported when the layer or the tile is not covered
 hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s) {
-    if (a.ksize != 3 || (a.cin & 31) || a.cin < 32) return hipErrorNotSupported;
+    if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16) return hipErrorNotSupported;
     switch (variant) {
         case 6: return launch_t<2, 2, 2, 4>(a, s);    //  64 x 128
         case 7: return launch_t<2, 2, 2, 3>(a, s);    //  64 x  96
         case 9: return launch_t<4, 1, 2, 4>(a, s);    // 128 x  64
         case 10: return launch_t<2, 2, 4, 2>(a, s);   // 128 x  64 (2x2 waves)
         case 11: return launch_t<4, 1, 2, 2>(a, s);   // 128 x  32
+        case 12: return launch_t<4, 1, 2, 1>(a, s);   // 128 x  16
         case 13: return launch_t<4, 2, 2, 3>(a, s);   // 128 x  96,  8 waves
         case 14: return launch_t<4, 2, 2, 4>(a, s);   // 128 x 128,  8 waves
         case 15: return launch_t<4, 2, 2, 2>(a, s);   // 128 x  64,  8 waves
+        case 20: return launch_t<4, 1, 2, 3>(a, s);   // 128 x  48
     }
     return hipErrorNotSupported;
+}
+
+// Tile choice for the tap kernels.  Measured on MI355X (profiles/conv_tap_sweep_r1.txt) every tile runs at
+// 113-121 TFLOP/s when its shape fits the layer exactly (128x16: ~0.8 of that), so the choice is about padding waste
+// (channel tile and pixel tile fill) and about the last, partly filled round of workgroups.
+int choose_conv_tap_variant(int M, int n16) {
+    struct V { int id, bm, nf; float speed; };
+    static const V vs[] = {{7, 64, 6, 1.00f},  {13, 128, 6, 0.99f}, {9, 128, 4, 0.99f}, {14, 128, 8, 1.00f}, {6, 64, 8, 0.98f},
+                           {20, 128, 3, 0.98f}, {11, 128, 2, 0.99f}, {12, 128, 1, 0.80f}};
+    float best = -1.f;
+    int bv = 7;
+    for (const V& v : vs) {
+        const int ntiles = (n16 + v.nf - 1) / v.nf;
+        const long long mtiles = (M + v.bm - 1) / v.bm;
+        const float fill = (float)n16 / (float)(ntiles * v.nf) * (float)M / (float)(mtiles * v.bm);
+        const long long blocks = mtiles * ntiles;
+        const long long per_cu = (blocks + 255) / 256;
+        const float occ = (float)blocks / (256.f * (float)per_cu);
+        const float sc = v.speed * fill * occ;
+        if (sc > best) { best = sc; bv = v.id; }
+    }
+    return bv;
 }
 
 }  // namespace padel

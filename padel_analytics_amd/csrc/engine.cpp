@@ -432,26 +432,30 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.cin = o.cin; a.cout = o.cout; a.n16 = o.npad / 16; a.ksize = o.ksize; a.stride = o.stride; a.act = o.act;
             a.M = n * Ho * Wo;
             a.tune = getenv("PADEL_CONV_TUNE") ? atoi(getenv("PADEL_CONV_TUNE")) : 1;   // default: s_setprio around MFMA clusters
+            // kernel choice: v5 tap kernels (conv_tap.hip) unless a tuning override asks for an older generation:
+            //   PADEL_CONV_TAP=0 | PADEL_CONV_IMPL=direct|lds | PADEL_CONV_RING=1 | PADEL_CONV_PIPE=1 ; a forced
+            //   PADEL_CONV_LDS_VARIANT picks the tile (of the LDS kernel, or of the tap kernel with PADEL_CONV_TAP=1)
+            const bool use_ring = getenv("PADEL_CONV_RING") && atoi(getenv("PADEL_CONV_RING"));
+            const bool use_pipe = getenv("PADEL_CONV_PIPE") && atoi(getenv("PADEL_CONV_PIPE"));
+            const bool forced_tile = getenv("PADEL_CONV_LDS_VARIANT") != nullptr;
+            const bool use_tap = getenv("PADEL_CONV_TAP") ? atoi(getenv("PADEL_CONV_TAP")) != 0
+                                                          : (!getenv("PADEL_CONV_IMPL") && !forced_tile && !use_ring && !use_pipe);
             int mf = 0, nf = 0;
-            const int lv = choose_conv_lds_variant(a.M, a.n16);
-            if (lv >= 0) conv_lds_variant_shape(lv, &mf, &nf);      // profile rows carry BM, BN for the LDS kernel
+            const int lv = (use_tap && !forced_tile) ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16);
+            if (lv >= 0) conv_lds_variant_shape(lv, &mf, &nf);      // profile rows carry BM, BN of the workgroup tile
             else choose_conv_tile(a.M, a.n16, &mf, &nf);
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
             if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = mf; pr->nf = nf; }
-            const bool use_pipe = getenv("PADEL_CONV_PIPE") && atoi(getenv("PADEL_CONV_PIPE"));
             // tuning only: PADEL_CONV_DBG=<file> collects the DIAG-16 timeline of this launch (conv_lds.hip) into <file>
             unsigned long long* dbg_dev = nullptr;
             size_t dbg_bytes = 0;
-            if (const char* dbgf = getenv("PADEL_CONV_DBG")) {
-                (void)dbgf;
-                int bm = 64, bn = 96;
+            if (getenv("PADEL_CONV_DBG")) {
+                const int bm = 64, bn = 96;
                 dbg_bytes = (size_t)((a.M + bm - 1) / bm) * ((o.npad + bn - 1) / bn) * kConvDbgWords * 8;
                 if (hipMalloc(&dbg_dev, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(dbg_dev, 0, dbg_bytes, s);
                 else dbg_dev = nullptr;
                 a.dbg = dbg_dev;
             }
-            const bool use_ring = getenv("PADEL_CONV_RING") && atoi(getenv("PADEL_CONV_RING"));
-            const bool use_tap = getenv("PADEL_CONV_TAP") && atoi(getenv("PADEL_CONV_TAP"));
             if (lv >= 0 && use_tap) {
                 r = launch_conv_tap(a, lv, s);
                 if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);

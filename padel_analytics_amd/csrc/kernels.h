@@ -55,6 +55,7 @@ hipError_t launch_conv_ring(const ConvArgs& a, int variant, hipStream_t s);
 // chunk of a pixel / weight row, so every buffer a conv reads is allocated with kConvReadSlack extra bytes
 hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s);
 constexpr size_t kConvReadSlack = 512;
+int choose_conv_tap_variant(int M, int n16);
 
 struct StemArgs {
     const uint8_t* in;    // net input u8 NHWC4 [B][H][W][4]

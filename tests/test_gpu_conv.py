@@ -83,8 +83,8 @@ def test_conv_variants(gpu_engine, case):
             _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_RING=1)
             for rep in range(2):                       # twice: a DMA/barrier race would not be deterministic
                 outs[f"R{v}.{rep}"] = _run(gpu_engine, case, x, w, b, None)
-        if k == 3 and cin % 32 == 0:                   # v5: tap-unrolled DMA ring (buffer addressing, zeros by range check)
-            for v in (6, 7, 9, 10, 11, 13, 14, 15):
+        if True:                                       # v5: tap-unrolled DMA ring (buffer addressing, zeros by range check)
+            for v in (6, 7, 9, 10, 11, 12, 13, 14, 15, 20):
                 _setenv(PADEL_CONV_LDS_VARIANT=v, PADEL_CONV_TAP=1)
                 for rep in range(2):
                     outs[f"T{v}.{rep}"] = _run(gpu_engine, case, x, w, b, None)
