@@ -107,29 +107,54 @@ constexpr int tap_min_waves(int nw, int frags) {
             _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
     } while (0)
 
-// epilogue: lane holds D[row = lq*4 + r][col = lr] of each 16x16 fragment
-template <int MF, int NF>
-__device__ __forceinline__ void tap_epilogue(const ConvArgs& a, const f32x4 (&acc)[MF][NF], int mw, int fw, int lr, int lq) {
-    const int act = a.act;
+// epilogue: lane holds D[row = lq*4 + r][col = lr] of each 16x16 fragment.  Under MFMA contention every epilogue
+// instruction costs a wave ~26 cycles (profiles/conv_timeline_r1.txt), so the activation switch, the residual test
+// and the tile-edge predicates are hoisted into wave-uniform template cases instead of being re-decided per element
+// (same arithmetic per element in every case: results do not depend on which case runs).
+template <int MF, int NF, int ACT, bool RES, bool FULL>
+__device__ __forceinline__ void tap_epilogue_case(const ConvArgs& a, const f32x4 (&acc)[MF][NF], int mw, int fw, int lr, int lq) {
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         const int fr = fw + j;
         const int co = fr * 16 + lr;
-        const bool cv = co < a.cout;
-        const float b = a.bias[min(fr, a.n16 - 1) * 16 + lr];
+        const bool cv = FULL || co < a.cout;
+        const float b = a.bias[(FULL ? fr : min(fr, a.n16 - 1)) * 16 + lr];
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int m = mw + f * 16 + lq * 4 + rr;
-                if (cv && m < a.M) {
-                    float v = act_apply5(acc[f][j][rr] + b, act);
-                    if (a.res) v += a.res[(long long)m * a.res_cs + a.res_choff + co];
+                if (FULL || (cv && m < a.M)) {
+                    float v = acc[f][j][rr] + b;
+                    if (ACT == ACT_SILU) v = v / (1.0f + expf(-v));
+                    else if (ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
+                    else if (ACT == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    if (RES) v += a.res[(long long)m * a.res_cs + a.res_choff + co];
                     a.out[(long long)m * a.out_cs + a.out_choff + co] = v;
                 }
             }
         }
     }
+}
+
+template <int MF, int NF, int ACT>
+__device__ __forceinline__ void tap_epilogue_act(const ConvArgs& a, const f32x4 (&acc)[MF][NF], int mw, int fw, int lr, int lq, bool full) {
+    if (a.res) {
+        if (full) tap_epilogue_case<MF, NF, ACT, true, true>(a, acc, mw, fw, lr, lq);
+        else tap_epilogue_case<MF, NF, ACT, true, false>(a, acc, mw, fw, lr, lq);
+    } else {
+        if (full) tap_epilogue_case<MF, NF, ACT, false, true>(a, acc, mw, fw, lr, lq);
+        else tap_epilogue_case<MF, NF, ACT, false, false>(a, acc, mw, fw, lr, lq);
+    }
+}
+
+// `full`: every row and channel of the WORKGROUP's tile exists (wave-uniform)
+template <int MF, int NF>
+__device__ __forceinline__ void tap_epilogue(const ConvArgs& a, const f32x4 (&acc)[MF][NF], int mw, int fw, int lr, int lq, bool full) {
+    if (a.act == ACT_SILU) tap_epilogue_act<MF, NF, ACT_SILU>(a, acc, mw, fw, lr, lq, full);
+    else if (a.act == ACT_RELU) tap_epilogue_act<MF, NF, ACT_RELU>(a, acc, mw, fw, lr, lq, full);
+    else if (a.act == ACT_SIGMOID) tap_epilogue_act<MF, NF, ACT_SIGMOID>(a, acc, mw, fw, lr, lq, full);
+    else tap_epilogue_act<MF, NF, ACT_NONE>(a, acc, mw, fw, lr, lq, full);
 }
 
 // common head of both kernels: tile geometry, wave / lane ids, XCD-aware tile index
@@ -277,13 +302,13 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
     } else {
         wait_vm<0>();       // the two trailing requests must land before this workgroup's LDS is released
     }
-    tap_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq);
+    tap_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq, m0 + BM <= a.M && (f0 + WN * NF) * 16 <= a.cout);
 #undef PADEL_TAP_STEP
 #undef PADEL_TAP_TSTEP
 }
 
 // =====================================================================================================  1x1
-template <int WM, int WN, int MF, int NF>
+template <int WM, int WN, int MF, int NF, int PD>
 __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF)) conv_tap1_kernel(const ConvArgs a) {
     PADEL_TAP_GEOMETRY(4)
     const int nks = a.cin >> 4;              // 16 channels per k-step
@@ -306,12 +331,15 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
     PADEL_TAP_WEIGHTS()
 
     unsigned s_k = 0;                         // byte offset of the current block: 64 B per k-step in a pixel AND in a weight row
-    // step J of a 16-step accumulation block: read stage J % 4, request step J + 2 (past the end: unused slack bytes)
+    // step J of a 16-step accumulation block: read stage J % 4, request step J + PD (past the end: unused slack
+    // bytes).  PD = 3 uses the whole ring: the stage being refilled was read one step ago, and every wave finished
+    // those reads before it arrived at this step's barrier.
+    static_assert(PD == 2 || PD == 3, "prefetch distance");
 #define PADEL_TAP1_STEP(J)                                                                                        \
     if ((J) < nb) {                                                                                               \
-        wait_vm<AP + BFULL>();                                                                                    \
+        wait_vm<(PD - 1) * (AP + BFULL)>();                                                                       \
         __builtin_amdgcn_s_barrier();                                                                             \
-        PADEL_TAP_DMA(((J) + 2) % 4, s_k + ((J) + 2) * 64u, s_k + ((J) + 2) * 64u, voffA[0], voffA[AP - 1]);      \
+        PADEL_TAP_DMA(((J) + PD) % 4, s_k + ((J) + PD) * 64u, s_k + ((J) + PD) * 64u, voffA[0], voffA[AP - 1]);   \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_TAP_COMPUTE((J) % 4);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -319,6 +347,7 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
 
     PADEL_TAP_DMA(0, 0u, 0u, voffA[0], voffA[AP - 1]);
     PADEL_TAP_DMA(1, 64u, 64u, voffA[0], voffA[AP - 1]);
+    if constexpr (PD == 3) PADEL_TAP_DMA(2, 128u, 128u, voffA[0], voffA[AP - 1]);
     for (int k = 0; k < nks; k += 16) {
         const int nb = min(16, nks - k);
         PADEL_TAP1_STEP(0)  PADEL_TAP1_STEP(1)  PADEL_TAP1_STEP(2)  PADEL_TAP1_STEP(3)
@@ -329,7 +358,7 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
         s_k += 16u * 64u;
     }
     wait_vm<0>();           // the two trailing requests must land before this workgroup's LDS is released
-    tap_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq);
+    tap_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq, m0 + BM <= a.M && (f0 + WN * NF) * 16 <= a.cout);
 #undef PADEL_TAP1_STEP
 }
 
@@ -339,8 +368,10 @@ static hipError_t launch_t(const ConvArgs& a_in, hipStream_t s) {
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
     dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
+    static const int pd = getenv("PADEL_CONV_TAP_PD") ? atoi(getenv("PADEL_CONV_TAP_PD")) : 2;
     if (a.ksize == 3) hipLaunchKernelGGL((conv_tap_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
-    else hipLaunchKernelGGL((conv_tap1_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+    else if (pd == 3) hipLaunchKernelGGL((conv_tap1_kernel<WM, WN, MF, NF, 3>), grid, dim3(64 * WM * WN), 0, s, a);
+    else hipLaunchKernelGGL((conv_tap1_kernel<WM, WN, MF, NF, 2>), grid, dim3(64 * WM * WN), 0, s, a);
     return hipGetLastError();
 }
 

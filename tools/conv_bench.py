@@ -80,6 +80,8 @@ if __name__ == "__main__":
         elif t.startswith("P"):
             env["PADEL_CONV_LDS_VARIANT"] = t[1:]
             env["PADEL_CONV_PIPE"] = "1"
+        elif t.startswith("A"):                       # default kernel choice with 1x1 prefetch distance N: ApN
+            env["PADEL_CONV_TAP_PD"] = t[2:]
         elif t.startswith("T"):                       # v5 tap-unrolled DMA ring (3x3, cin % 32 == 0), same variant ids
             v, _, tune = t[1:].partition("t")
             env["PADEL_CONV_LDS_VARIANT"] = v
