@@ -111,6 +111,8 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # RCCL over xGMI
+        # setup (weight synthesis / packing) is host work in every rank: share the cores instead of oversubscribing
+        torch.set_num_threads(max(1, min(64, (os.cpu_count() or 8) // max(world, 1))))
 
     for kv in filter(None, a.scales.split(",")):
         k, v = kv.split("=")
