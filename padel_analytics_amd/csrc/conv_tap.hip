@@ -308,8 +308,15 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
 }
 
 // =====================================================================================================  1x1
+// the 4-stage ring caps residency at 160 KB / (4 stages): ask the register allocator for no more than that
+constexpr int tap1_min_waves(int nw, int frags, int stage_bytes) {
+    const int by_lds = (160 * 1024 / (4 * stage_bytes)) * nw / 4;
+    const int want = tap_min_waves(nw, frags);
+    return by_lds < want ? (by_lds < 1 ? 1 : by_lds) : want;
+}
+
 template <int WM, int WN, int MF, int NF, int PD>
-__global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF)) conv_tap1_kernel(const ConvArgs a) {
+__global__ void __launch_bounds__(64 * WM * WN, tap1_min_waves(WM * WN, MF * NF, (WM * MF + WN * NF) * 16 * 64)) conv_tap1_kernel(const ConvArgs a) {
     PADEL_TAP_GEOMETRY(4)
     const int nks = a.cin >> 4;              // 16 channels per k-step
     const int Ktot = nks * 16;
