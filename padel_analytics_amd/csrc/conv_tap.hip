@@ -69,6 +69,11 @@ __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// n / d for 0 <= n < 2^31 with the (magic, shift) pair of fill_fastdiv (kernels.h): 3 instructions instead of ~35
+__device__ __forceinline__ int fastdiv(int n, unsigned magic, unsigned shift) {
+    return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
+}
+
 constexpr int tap_min_waves(int nw, int frags) {
     return nw == 4 ? (frags <= 6 ? 5 : 4) : 4;
 }
@@ -183,7 +188,8 @@ __device__ __forceinline__ void tap_epilogue(const ConvArgs& a, const f32x4 (&ac
     const int HoWo = a.Ho * a.Wo;                                                                                 \
     const int srow = tid >> 2;                                                                                    \
     const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);     /* source chunk of LDS slot tid&3 (swizzle) */  \
-    const int n0 = m0 / HoWo, rem0 = m0 - n0 * HoWo, oy0 = rem0 / a.Wo, ox0 = rem0 - oy0 * a.Wo;                  \
+    const int n0 = fastdiv(m0, a.howo_magic, a.howo_shift), rem0 = m0 - n0 * HoWo;                                \
+    const int oy0 = fastdiv(rem0, a.wo_magic, a.wo_shift), ox0 = rem0 - oy0 * a.Wo;                               \
     const long long lin0 = ((long long)n0 * a.H + oy0 * a.stride) * a.W + ox0 * a.stride;     /* uniform */       \
     const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + wave * 1024u);            \
     const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);                                       \
@@ -219,18 +225,20 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
         int m = m0 + srow + RP * p;
         const bool rv = m < a.M;
         if (!rv) m = m0;
-        const int n = m / HoWo;
+        const int n = fastdiv(m, a.howo_magic, a.howo_shift);
         const int rem = m - n * HoWo;
-        const int oy = rem / a.Wo;
+        const int oy = fastdiv(rem, a.wo_magic, a.wo_shift);
         const int ox = rem - oy * a.Wo;
         const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
         const unsigned off = (unsigned)(((lin - lin0) * a.in_cs + sc * 4) * 4);
+        bool vy[3], vx[3];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ky = t / 3, kx = t % 3;
-            const bool v = rv && (unsigned)(oy * a.stride - 1 + ky) < (unsigned)a.H && (unsigned)(ox * a.stride - 1 + kx) < (unsigned)a.W;
-            voffA[p][t] = v ? off : kOutOfRange;
+        for (int d = 0; d < 3; ++d) {
+            vy[d] = rv && (unsigned)(oy * a.stride - 1 + d) < (unsigned)a.H;
+            vx[d] = (unsigned)(ox * a.stride - 1 + d) < (unsigned)a.W;
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) voffA[p][t] = (vy[t / 3] && vx[t % 3]) ? off : kOutOfRange;
     }
     // base of the A descriptor: channel slice of the tap-(0,0) pixel of row m0 (may lie below a.in: never dereferenced there)
     const i32x4 rsrcA = make_rsrc(a.in + ((lin0 - (a.W + 1)) * a.in_cs + a.in_choff));
@@ -327,9 +335,9 @@ __global__ void __launch_bounds__(64 * WM * WN, tap1_min_waves(WM * WN, MF * NF,
         int m = m0 + srow + RP * p;
         const bool rv = m < a.M;
         if (!rv) m = m0;
-        const int n = m / HoWo;
+        const int n = fastdiv(m, a.howo_magic, a.howo_shift);
         const int rem = m - n * HoWo;
-        const int oy = rem / a.Wo;
+        const int oy = fastdiv(rem, a.wo_magic, a.wo_shift);
         const int ox = rem - oy * a.Wo;
         const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
         voffA[p] = rv ? (unsigned)(((lin - lin0) * a.in_cs + sc * 4) * 4) : kOutOfRange;

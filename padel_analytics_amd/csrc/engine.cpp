@@ -431,6 +431,8 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.H = m->net_h >> ib.level; a.W = m->net_w >> ib.level; a.Ho = Ho; a.Wo = Wo;
             a.cin = o.cin; a.cout = o.cout; a.n16 = o.npad / 16; a.ksize = o.ksize; a.stride = o.stride; a.act = o.act;
             a.M = n * Ho * Wo;
+            fill_fastdiv((unsigned)(Ho * Wo), &a.howo_magic, &a.howo_shift);
+            fill_fastdiv((unsigned)Wo, &a.wo_magic, &a.wo_shift);
             a.tune = getenv("PADEL_CONV_TUNE") ? atoi(getenv("PADEL_CONV_TUNE")) : 1;   // default: s_setprio around MFMA clusters
             // kernel choice: v5 tap kernels (conv_tap.hip) unless a tuning override asks for an older generation:
             //   PADEL_CONV_TAP=0 | PADEL_CONV_IMPL=direct|lds | PADEL_CONV_RING=1 | PADEL_CONV_PIPE=1 ; a forced

@@ -32,7 +32,16 @@ struct ConvArgs {
     int n_mtiles;         // ceil(M / (4 * MF * 16))
     int tune;             // bit 0: s_setprio(1) around MFMA clusters; bit 1: staggered workgroup start
     unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_lds.hip DIAG 16
+    // m / (Ho*Wo) and rem / Wo without an integer-division sequence (conv_tap.hip prologue): q = (umulhi(n, magic) + n) >> shift,
+    // exact for 0 <= n < 2^31 (fill_fastdiv below; the conv kernels' rows satisfy n < 2^31)
+    unsigned howo_magic, howo_shift, wo_magic, wo_shift;
 };
+inline void fill_fastdiv(unsigned d, unsigned* magic, unsigned* shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *magic = (unsigned)((((1ull << 32) * ((1ull << s) - d)) / d) + 1ull);
+    *shift = s;
+}
 constexpr int kConvDbgSteps = 64;                       // k-steps kept per wave (ring)
 constexpr int kConvDbgWords = 8 + 4 * kConvDbgSteps * 5;   // u64 words per workgroup: header + 4 waves x steps x 5 stamps
 
