@@ -1,5 +1,7 @@
-"""GPU unit test of the conv kernels through the C-ABI: every tile variant of the register-direct kernel
-(conv_igemm.hip) and of the LDS kernel (conv_lds.hip) against torch.nn.functional.conv2d (fp32 CPU), on
+"""GPU unit test of the conv kernels through the C-ABI: every tile variant of all five kernel generations — the
+register-direct kernel (conv_igemm.hip), the LDS kernel (conv_lds.hip), the pipelined LDS kernel (conv_pipe.hip), the
+LDS-DMA ring (conv_ring.hip) and the default tap-unrolled kernels (conv_tap.hip) — against
+torch.nn.functional.conv2d (fp64 CPU), on
 shapes that exercise stride 2, 1x1, the 16-channel K tail (cin % 32 == 16), partial channel tiles
 (cout = 80 -> 5 fragments), the M tail, the fused residual and every activation; and against each other
 BITWISE (same K order + same accumulation blocks => identical results)."""
