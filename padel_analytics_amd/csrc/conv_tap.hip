@@ -106,6 +106,21 @@ constexpr int tap_min_waves(int nw, int frags) {
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
 
+// the same two halves separately (timeline instantiation only)
+#define PADEL_TAP_FRAGS_DBG(ST_)                                                                                  \
+    f32x4 A_[MF], B_[NF];                                                                                         \
+    _Pragma("unroll") for (int f = 0; f < MF; ++f) A_[f] = *reinterpret_cast<const f32x4*>(a_rd + (ST_) * STAGE + f * 256); \
+    _Pragma("unroll") for (int j = 0; j < NF; ++j) B_[j] = *reinterpret_cast<const f32x4*>(b_rd + (ST_) * STAGE + j * 256);
+#define PADEL_TAP_MFMAS_DBG()                                                                                     \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                          \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
+                _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                    \
+                    part[f][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(A_[f][kk], B_[j][kk], part[f][j], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+
 #define PADEL_TAP_FLUSH()                                                                                         \
     do {                                                                                                          \
         _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                            \
@@ -211,9 +226,25 @@ __device__ __forceinline__ void tap_epilogue(const ConvArgs& a, const f32x4 (&ac
     const i32x4 rsrcB = make_rsrc(a.w + (long long)f0 * 16 * Ktot);
 
 // =====================================================================================================  3x3
-template <int WM, int WN, int MF, int NF>
+// DBG (tuning only, PADEL_CONV_DIAG=16 on the 64x96 tile): every wave stamps s_memtime at 5 points of every k-step
+// (step top / own requests landed / barrier passed / fragments in registers / last MFMA issued) into an LDS ring that is
+// dumped to a.dbg at the end — same dump format as conv_lds.hip's DIAG 16, read by tools/timeline_probe.py --kernel tap.
+template <int WM, int WN, int MF, int NF, bool DBG = false>
 __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF)) conv_tap_kernel(const ConvArgs a) {
     PADEL_TAP_GEOMETRY(3)
+    __shared__ unsigned long long stamps[DBG ? 4 * kConvDbgSteps * 5 + 4 * 64 : 1];
+    unsigned long long t_begin = 0;
+    int dbg_k = 0;                           // global k-step index of step 0 of the current block
+    if constexpr (DBG) t_begin = __builtin_amdgcn_s_memtime();
+#define PADEL_TAP_STAMP(J, slot)                                                                                  \
+    do {                                                                                                          \
+        if constexpr (DBG) {                                                                                      \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
+            const int real_ = ((wave & 3) * kConvDbgSteps + ((dbg_k + (J)) & (kConvDbgSteps - 1))) * 5 + (slot);  \
+            const int dummy_ = 4 * kConvDbgSteps * 5 + (wave & 3) * 64 + lane;                                    \
+            stamps[lane == 0 ? real_ : dummy_] = t_;                                                              \
+        }                                                                                                         \
+    } while (0)
     const int nfull = a.cin >> 5;            // 32-channel chunks: 18 k-steps each
     const bool has_tail = (a.cin & 16) != 0; // + 9 k-steps of the last 16 channels
     const int Ktot = (nfull * 18 + (has_tail ? 9 : 0)) * 16;
@@ -263,8 +294,11 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
     // chunk-relative step J of a full chunk: read stage J % 3, request step J + 2 (steps 16, 17 request the next block)
 #define PADEL_TAP_STEP(J)                                                                                         \
     do {                                                                                                          \
+        PADEL_TAP_STAMP(J, 0);                                                                                    \
         wait_vm<AP + BFULL>();                  /* own requests of step J landed (the younger ones may fly on) */ \
+        PADEL_TAP_STAMP(J, 1);                                                                                    \
         __builtin_amdgcn_s_barrier();           /* ... everybody's did; stage (J + 2) % 3 is free again */        \
+        PADEL_TAP_STAMP(J, 2);                                                                                    \
         if constexpr ((J) + 2 < 18)                                                                               \
             PADEL_TAP_DMA(((J) + 2) % 3, s_chunk + tapoff[((J) + 2) % 18], s_kb + ((J) + 2) * 64u,                \
                           voffA[0][(((J) + 2) % 18) >> 1], voffA[AP - 1][(((J) + 2) % 18) >> 1]);                 \
@@ -273,7 +307,15 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
         else                                                                                                      \
             PADEL_TAP_DMA(1, s_chunk + 128u + wrap_off1, s_kb + 19 * 64u, wrapv1[0], wrapv1[AP - 1]);             \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_TAP_COMPUTE((J) % 3);                                                                               \
+        if constexpr (DBG) {                                                                                      \
+            PADEL_TAP_FRAGS_DBG((J) % 3)                                                                          \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+            PADEL_TAP_STAMP(J, 3);                                                                                \
+            PADEL_TAP_MFMAS_DBG();                                                                                \
+            PADEL_TAP_STAMP(J, 4);                                                                                \
+        } else {                                                                                                  \
+            PADEL_TAP_COMPUTE((J) % 3);                                                                           \
+        }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
     // step J of the tail block (tap J, half 0): nothing is requested past its last step, so step 8 drains the queue
@@ -302,6 +344,7 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
         PADEL_TAP_FLUSH();
         s_chunk += 128u;
         s_kb += 18u * 64u;
+        dbg_k += 18;
     }
     if (has_tail) {
         PADEL_TAP_TSTEP(0); PADEL_TAP_TSTEP(1); PADEL_TAP_TSTEP(2); PADEL_TAP_TSTEP(3); PADEL_TAP_TSTEP(4);
@@ -311,6 +354,21 @@ __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF))
         wait_vm<0>();       // the two trailing requests must land before this workgroup's LDS is released
     }
     tap_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq, m0 + BM <= a.M && (f0 + WN * NF) * 16 <= a.cout);
+    if constexpr (DBG) {
+        if (a.dbg) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            unsigned long long* d = a.dbg + (long long)(blockIdx.y * gridDim.x + blockIdx.x) * kConvDbgWords;
+            for (int i = tid; i < 4 * kConvDbgSteps * 5; i += 64 * NW) d[8 + i] = stamps[i];
+            if (lane == 0 && wave < 4) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+                const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+                d[wave] = ((unsigned long long)xcc << 32) | hw;
+                if (wave == 0) { d[4] = t_begin; d[5] = t_end; d[6] = (unsigned long long)(nfull * 18 + (has_tail ? 9 : 0)); d[7] = (unsigned long long)bid; }
+            }
+        }
+    }
+#undef PADEL_TAP_STAMP
 #undef PADEL_TAP_STEP
 #undef PADEL_TAP_TSTEP
 }
@@ -384,6 +442,12 @@ static hipError_t launch_t(const ConvArgs& a_in, hipStream_t s) {
     a.n_mtiles = (a.M + BM - 1) / BM;
     dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
     static const int pd = getenv("PADEL_CONV_TAP_PD") ? atoi(getenv("PADEL_CONV_TAP_PD")) : 2;
+    if constexpr (WM == 2 && WN == 2 && MF == 2 && NF == 3) {
+        if (a.ksize == 3 && a.dbg && getenv("PADEL_CONV_DIAG") && atoi(getenv("PADEL_CONV_DIAG")) == 16) {
+            hipLaunchKernelGGL((conv_tap_kernel<2, 2, 2, 3, true>), grid, dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     if (a.ksize == 3) hipLaunchKernelGGL((conv_tap_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     else if (pd == 3) hipLaunchKernelGGL((conv_tap1_kernel<WM, WN, MF, NF, 3>), grid, dim3(64 * WM * WN), 0, s, a);
     else hipLaunchKernelGGL((conv_tap1_kernel<WM, WN, MF, NF, 2>), grid, dim3(64 * WM * WN), 0, s, a);

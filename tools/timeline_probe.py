@@ -17,8 +17,10 @@ sys.path.insert(0, str(ROOT))
 STEPS, WORDS = 64, 8 + 4 * 64 * 5
 
 
-def run_conv(dump, B=64, H=48, W=80, cin=192, cout=192):
+def run_conv(dump, kernel="lds", B=64, H=48, W=80, cin=192, cout=192):
     os.environ.update(PADEL_CONV_LDS_VARIANT="7", PADEL_CONV_DIAG="16", PADEL_CONV_DBG=dump)
+    if kernel == "tap":
+        os.environ["PADEL_CONV_TAP"] = "1"
     from padel_analytics_amd import engine as E, graph as G
     eng = E.default_engine(0)
     eng.set_profiling(True)
@@ -43,8 +45,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/timeline.txt")
     ap.add_argument("--dump", default="/tmp/padel_conv_timeline.bin")
+    ap.add_argument("--kernel", default="lds", choices=["lds", "tap"],
+                    help="lds = conv_lds_kernel (v2) DIAG 16; tap = conv_tap_kernel (v5) timeline instantiation")
     a = ap.parse_args()
-    ms = run_conv(a.dump)
+    ms = run_conv(a.dump, a.kernel)
     raw = np.fromfile(a.dump, dtype=np.uint64)
     nblk = raw.size // WORDS
     raw = raw[: nblk * WORDS].reshape(nblk, WORDS)
@@ -53,6 +57,7 @@ def main():
     nks = int(hdr[0, 6])
     out = []
     P = out.append
+    P(f"kernel: {'conv_tap_kernel<2,2,2,3> (v5)' if a.kernel == 'tap' else 'conv_lds_kernel<2,2,2,3,3,1> (v2)'}")
     P(f"conv 192->192 3x3, M = 245760, tile 64x96, {nblk} workgroups, {nks} k-steps, instrumented kernel time {ms:.3f} ms")
     life = (hdr[:, 5].astype(np.int64) - hdr[:, 4].astype(np.int64))
     P(f"workgroup lifetime (s_memtime ticks): mean {life.mean():.0f}  p10 {np.percentile(life, 10):.0f}  p90 {np.percentile(life, 90):.0f}"
@@ -62,14 +67,24 @@ def main():
     sl = steps & (STEPS - 1)
     t = st[:, :, sl, :]                                     # (blk, wave, step, 5)
     nxt = st[:, :, (steps + 1) & (STEPS - 1), 0]
-    seg = {
-        "t0->t1 issue prefetch + wait fragments (ds_read)": t[..., 1] - t[..., 0],
-        "t1->t2 24 MFMAs issued (768 if alone)": t[..., 2] - t[..., 1],
-        "t2->t3 wait prefetch (vmcnt 0)": t[..., 3] - t[..., 2],
-        "t3->t4 ds_write + barrier": t[..., 4] - t[..., 3],
-        "t4->t0' loop back": nxt - t[..., 4],
-        "whole k-step": nxt - t[..., 0],
-    }
+    if a.kernel == "tap":
+        seg = {
+            "t0->t1 wait own requests of this step (vmcnt n)": t[..., 1] - t[..., 0],
+            "t1->t2 barrier": t[..., 2] - t[..., 1],
+            "t2->t3 issue 2-3 DMA requests + wait fragments (ds_read)": t[..., 3] - t[..., 2],
+            "t3->t4 24 MFMAs issued (768 if alone)": t[..., 4] - t[..., 3],
+            "t4->t0' to the next step": nxt - t[..., 4],
+            "whole k-step": nxt - t[..., 0],
+        }
+    else:
+        seg = {
+            "t0->t1 issue prefetch + wait fragments (ds_read)": t[..., 1] - t[..., 0],
+            "t1->t2 24 MFMAs issued (768 if alone)": t[..., 2] - t[..., 1],
+            "t2->t3 wait prefetch (vmcnt 0)": t[..., 3] - t[..., 2],
+            "t3->t4 ds_write + barrier": t[..., 4] - t[..., 3],
+            "t4->t0' loop back": nxt - t[..., 4],
+            "whole k-step": nxt - t[..., 0],
+        }
     P("\nper k-step segment, ticks (all workgroups, waves, steps %d..%d):" % (steps[0], steps[-1]))
     for k, v in seg.items():
         v = v.reshape(-1)
@@ -77,7 +92,7 @@ def main():
     # prologue / epilogue (ring keeps steps nks-64 ..): epilogue = last MFMA issued -> end stamp
     first = max(nks - STEPS, 0)
     t_first = st[:, 0, first & (STEPS - 1), 0]
-    t_lastm = st[:, 0, (nks - 1) & (STEPS - 1), 2]
+    t_lastm = st[:, 0, (nks - 1) & (STEPS - 1), 4 if a.kernel == "tap" else 2]
     tb, te = hdr[:, 4].astype(np.int64), hdr[:, 5].astype(np.int64)
     epi = te - t_lastm
     mainloop = (t_lastm - t_first) / (nks - first)
@@ -114,7 +129,9 @@ def main():
             for s in steps:
                 e = st[b, wv, s & (STEPS - 1)]
                 n0 = st[b, wv, (s + 1) & (STEPS - 1), 0]
-                for (lo, hi, ch) in ((e[0], e[1], "l"), (e[1], e[2], "M"), (e[2], e[3], "w"), (e[3], e[4], "b"), (e[4], n0, ".")):
+                segs = (((e[0], e[1], "w"), (e[1], e[2], "b"), (e[2], e[3], "l"), (e[3], e[4], "M"), (e[4], n0, ".")) if a.kernel == "tap"
+                        else ((e[0], e[1], "l"), (e[1], e[2], "M"), (e[2], e[3], "w"), (e[3], e[4], "b"), (e[4], n0, ".")))
+                for (lo, hi, ch) in segs:
                     c0, c1 = int((lo - t_lo) // res), int((hi - t_lo) // res)
                     for c in range(max(c0, 0), min(c1 + 1, width)):
                         row[c] = ch
