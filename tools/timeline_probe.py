@@ -136,8 +136,10 @@ def main():
                     for c in range(max(c0, 0), min(c1 + 1, width)):
                         row[c] = ch
             P(f"     wg {int(hdr[b, 7]):5d} simd {simd}: " + "".join(row))
-    P("  legend: l = prefetch issue + ds_read wait, M = MFMA burst being issued, w = vmcnt wait, b = ds_write + barrier; "
-      f"1 column = {res} ticks")
+    P("  legend: " + ("w = counted vmcnt wait, b = barrier, l = DMA requests + ds_read wait, M = MFMA burst being issued"
+                     if a.kernel == "tap" else
+                     "l = prefetch issue + ds_read wait, M = MFMA burst being issued, w = vmcnt wait, b = ds_write + barrier")
+      + f"; 1 column = {res} ticks")
     # compact copy of 16 CUs for offline analysis
     keep = np.where(np.isin(key, uniq[:16]))[0]
     np.savez_compressed(str(Path(a.out).with_suffix(".npz")), hdr=hdr[keep], st=(st[keep] - tb[keep, None, None, None]).astype(np.int32),
