@@ -89,14 +89,31 @@ int pa_device_malloc(pa_engine* eng, size_t nbytes, void** out_dev);
 int pa_device_free(pa_engine* eng, void* dev);
 int pa_memcpy_h2d(pa_engine* eng, void* dst_dev, const void* src_host, size_t nbytes);
 int pa_memcpy_d2h(pa_engine* eng, void* dst_host, const void* src_dev, size_t nbytes);
+/* host -> HBM on the engine's copy stream: does not queue behind inference launched from another host
+ * thread, so the next batch of frames uploads while the current one computes (the reference decodes and
+ * uploads per tracker, trackers/runner.py:215-220; the runner's fan-out mode uploads once per batch)   */
+int pa_upload(pa_engine* eng, void* dst_dev, const void* src_host, size_t nbytes);
+
+/* tuning knobs (tests / tools only).  Defaults come from the environment ONCE at pa_engine_create
+ * (PADEL_CONV_IMPL=tap|lds, PADEL_CONV_VARIANT, PADEL_CONV_TUNE, PADEL_CONV_TAP_PD, PADEL_GRAPH, PADEL_ALIAS).
+ * keys: "impl" (0 tap kernels, 1 LDS cross-check kernel), "variant" (forced tile id, -1 auto), "tune",
+ * "tap_pd" (2|3), "graph" (hipGraph replay of the op list), "alias" (liveness-shared activation arena),
+ * "timeline" (s_memtime-instrumented 3x3 kernel, dump to pa_engine_set_timeline_path)                 */
+int pa_engine_set_tuning(pa_engine* eng, const char* key, int value);
+int pa_engine_set_timeline_path(pa_engine* eng, const char* path);
 
 /* ---- models ---- */
-/* weights: packed blob produced by the host graph builder; copied to HBM, caller keeps ownership */
+/* weights: packed blob produced by the host graph builder; copied to HBM, caller keeps ownership.
+ * weights == NULL: the blob is allocated zero-filled and filled by pa_engine_bcast_weights (ranks that did
+ * not load the checkpoint)                                                                             */
 int pa_model_create(pa_engine* eng, const pa_model_desc* desc, const float* weights, size_t n_floats,
                     pa_model** out);
 void pa_model_destroy(pa_model* m);
 /* frames / windows processed per replay of the graph (activation buffers are sized for it); default 64 */
 int pa_model_set_max_batch(pa_model* m, int max_batch);
+/* activation bytes of the current plan: the liveness-shared arena actually allocated, and the sum of the
+ * logical buffers it replaces */
+int pa_model_plan_bytes(pa_model* m, size_t* arena_bytes, size_t* logical_bytes);
 
 enum pa_pre_mode {
     PA_PRE_LETTERBOX = 0,   /* ultralytics LetterBox(auto, stride 32), cv2 INTER_LINEAR, pad 114    */
@@ -124,6 +141,11 @@ int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const
  * pa_yolo_head_shape; channels [0,64) box DFL logits, [64,64+nc) class logits, then nk keypoint values) */
 int pa_yolo_head_shape(pa_model* m, int level, int* h, int* w, int* c);
 int pa_yolo_read_head(pa_model* m, int level, int n, float* out);
+
+/* the u8 network input (NHWC4: R,G,B,0 as the network sees them) the last pa_yolo_infer call built from its
+ * first n frames — byte-exact check of the letterbox (cv2 INTER_LINEAR) / Pillow-bicubic preprocessing */
+int pa_yolo_netin_shape(pa_model* m, int* h, int* w);
+int pa_yolo_read_netin(pa_model* m, int n, uint8_t* out);
 
 /* generic graph forward (TrackNet): x = n x H x W x C_in fp32 NHWC (C_in = channels of buffer 0) ->
  * contents of buffer head_buf[0]: n x (H>>level) x (W>>level) x channels fp32 */
@@ -158,6 +180,37 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames_bgr, int n, int frames_on_dev
 
 /* predict_location on caller-supplied masks (n x 288 x 512 uint8, n <= max_batch + 7) -> n x 4 {x, y, w, h} */
 int pa_ball_locate(pa_ball* b, const uint8_t* masks, int n, int32_t* out_rects);
+
+/* ---- multi-GPU: one process per GPU, frames shard by batch, the ONLY collective is the one-time broadcast
+ * of the packed weight blob from the rank that loaded the checkpoint; RCCL over xGMI,
+ * HBM to HBM, no host bounce.  The reference has no distributed code (single `.to(device)`,
+ * trackers/tracker.py:172-174) — this replaces "load the .pt in every process".
+ * Bootstrap: rank 0 calls pa_comm_unique_id (128 bytes), the host side ships the bytes to the other ranks
+ * out of band (torch.distributed store / any channel), every rank calls pa_engine_comm_init.          */
+int pa_comm_unique_id(void* out, size_t cap);
+int pa_engine_comm_init(pa_engine* eng, const void* unique_id, size_t id_bytes, int nranks, int rank);
+void pa_engine_comm_destroy(pa_engine* eng);
+int pa_engine_bcast_weights(pa_engine* eng, pa_model* m, int root);
+/* in-place broadcast of nbytes of device memory (e.g. the ball tracker's background median) */
+int pa_engine_bcast(pa_engine* eng, void* dev_ptr, size_t nbytes, int root);
+/* max over ranks of one double (bench: step time of the slowest rank) */
+int pa_engine_allreduce_max(pa_engine* eng, double* value);
+
+/* ---- host-native ByteTrack: `self.byte_track.update_with_detections(detections)`,
+ * trackers/players_tracker/players_tracker.py:367-369 (constructed at :311 with frame_rate = fps; supervision
+ * defaults track_activation_threshold .25, lost_track_buffer 30, minimum_matching_threshold .8).  Stateful and
+ * sequential in frame order; pure host code (no GPU needed).  One call consumes a batch of frames in order:
+ * boxes n_frames x stride x 6 {x1,y1,x2,y2,conf,cls} (pa_yolo_infer layout, stride = max_det), counts n_frames,
+ * keep (optional) n_frames x stride bytes — 0 drops the box before tracking (polygon-zone filter,
+ * players_tracker.py:364-365); out_ids n_frames x stride: public track id of each box, -1 = dropped
+ * (unmatched / unconfirmed / filtered).                                                                  */
+typedef struct pa_bytetrack pa_bytetrack;
+int pa_bytetrack_create(float track_activation_threshold, int lost_track_buffer, float minimum_matching_threshold,
+                        int frame_rate, pa_bytetrack** out);
+void pa_bytetrack_destroy(pa_bytetrack* b);
+void pa_bytetrack_reset(pa_bytetrack* b);
+int pa_bytetrack_update_batch(pa_bytetrack* b, const float* boxes, const int32_t* counts, const uint8_t* keep,
+                              int n_frames, int stride, int32_t* out_ids);
 
 /* ---- profiling (bench.py roofline): per-op device times of the LAST inference, HIP events on the
  * engine's stream.  kinds/ms/flops are host arrays of capacity cap; returns the number of records. */

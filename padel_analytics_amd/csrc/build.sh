@@ -5,12 +5,14 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value"
 mkdir -p build
 pids=()
-for f in conv_igemm.hip conv_lds.hip conv_pipe.hip conv_ring.hip conv_tap.hip kernels_misc.hip postproc.hip tracknet_post.hip; do
+for f in conv_lds.hip conv_tap.hip kernels_misc.hip postproc.hip tracknet_post.hip; do
   [ -f "$f" ] || continue
   hipcc $FLAGS -c "$f" -o "build/${f%.hip}.o" &
   pids+=($!)
 done
 hipcc $FLAGS -x hip -c engine.cpp -o build/engine.o &
+pids+=($!)
+g++ -O2 -std=c++17 -fPIC -Wall -c bytetrack.cpp -o build/bytetrack.o &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../libpadel_hip.so build/*.o -Wl,-rpath,/opt/rocm/lib

@@ -300,48 +300,14 @@ __global__ void __launch_bounds__(256, (MF * NF <= 6 && KB == 1) ? 5 : 1) conv_l
     }
 }
 
-static int lds_kb() {
-    const char* e = getenv("PADEL_CONV_KB");
-    return e ? atoi(e) : 1;
-}
-
 template <int WM, int WN, int MF, int NF>
 static hipError_t launch_l(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
     dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
-    const int kb = lds_kb();
-    // tuning probes: PADEL_CONV_DYNLDS = extra dynamic LDS bytes per workgroup (caps residency),
-    // PADEL_CONV_OCC = print the runtime's occupancy answer for this instantiation
-    const size_t dyn = getenv("PADEL_CONV_DYNLDS") ? (size_t)atoi(getenv("PADEL_CONV_DYNLDS")) : 0;
-    if (getenv("PADEL_CONV_OCC")) {
-        int nb = -1;
-        if (a.ksize == 3) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<WM, WN, MF, NF, 3, 1>, 256, dyn);
-        else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_lds_kernel<WM, WN, MF, NF, 1, 1>, 256, dyn);
-        hipFuncAttributes fa{};
-        if (a.ksize == 3) (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(conv_lds_kernel<WM, WN, MF, NF, 3, 1>));
-        fprintf(stderr, "[occ] tile %dx%d ks%d: %d workgroups/CU (dyn LDS %zu), regs %d, static LDS %zu, grid %u x %u\n",
-                BM, WN * NF * 16, a.ksize, nb, dyn, fa.numRegs, fa.sharedSizeBytes, grid.x, grid.y);
-    }
-    if constexpr (WM == 2 && WN == 2 && MF == 2 && NF == 3) {
-        const int diag = getenv("PADEL_CONV_DIAG") ? atoi(getenv("PADEL_CONV_DIAG")) : 0;
-        if (diag && a.ksize == 3) {
-            if (diag == 1) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 1>), grid, dim3(256), dyn, s, a);
-            else if (diag == 6) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 6>), grid, dim3(256), dyn, s, a);
-            else if (diag == 7) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 7>), grid, dim3(256), dyn, s, a);
-            else if (diag == 15) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 15>), grid, dim3(256), dyn, s, a);
-            else if (diag == 2) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 2>), grid, dim3(256), dyn, s, a);
-            else if (diag == 14) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 14>), grid, dim3(256), dyn, s, a);
-            else if (diag == 16) hipLaunchKernelGGL((conv_lds_kernel<2, 2, 2, 3, 3, 1, 16>), grid, dim3(256), dyn, s, a);
-            else return hipErrorInvalidValue;
-            return hipGetLastError();
-        }
-    }
-    if (a.ksize == 3 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 2>), grid, dim3(256), dyn, s, a);
-    else if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 1>), grid, dim3(256), dyn, s, a);
-    else if (a.ksize == 1 && kb == 2) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 2>), grid, dim3(256), dyn, s, a);
-    else if (a.ksize == 1) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 1>), grid, dim3(256), dyn, s, a);
+    if (a.ksize == 3) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 3, 1>), grid, dim3(256), 0, s, a);
+    else if (a.ksize == 1) hipLaunchKernelGGL((conv_lds_kernel<WM, WN, MF, NF, 1, 1>), grid, dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
@@ -362,17 +328,14 @@ static const LdsVariant lds_variants[] = {
     {10, 2, 2, 4, 2},  // 128 x  64 (2x2 waves)
     {11, 4, 1, 2, 2},  // 128 x  32
     {12, 4, 1, 2, 1},  // 128 x  16
-    // ring-only (conv_ring.hip): 8 or 16 waves per workgroup
+    // tap kernel only (conv_tap.hip): 8 waves per workgroup / 128 x 48
     {13, 4, 2, 2, 3},  // 128 x  96
     {14, 4, 2, 2, 4},  // 128 x 128
     {15, 4, 2, 2, 2},  // 128 x  64
-    {16, 8, 2, 2, 3},  // 256 x  96
-    {17, 4, 4, 2, 3},  // 128 x 192
-    {18, 2, 4, 2, 3},  //  64 x 192
-    {19, 8, 1, 2, 3},  // 256 x  48
     {20, 4, 1, 2, 3},  // 128 x  48
 };
-constexpr int kFirstRingOnly = 13;
+constexpr int kNumLdsVariants = 13;      // ids 0..12 are instantiated for the LDS kernel
+
 
 hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s) {
     switch (variant) {
@@ -390,24 +353,17 @@ hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s) {
         case 11: return launch_l<4, 1, 2, 2>(a, s);
         case 12: return launch_l<4, 1, 2, 1>(a, s);
     }
-    if (variant >= kFirstRingOnly) return launch_conv_ring(a, variant, s);
-    return hipErrorInvalidValue;
+    return hipErrorNotSupported;
 }
 
 int choose_conv_lds_variant(int M, int n16) {
-    // tuning overrides (tools/conv_bench.py)
-    const char* impl = getenv("PADEL_CONV_IMPL");
-    const int forced = getenv("PADEL_CONV_LDS_VARIANT") ? atoi(getenv("PADEL_CONV_LDS_VARIANT")) : -1;
-    if (impl && impl[0] == 'd') return -1;
-    if (forced >= 0) return forced;
-    if (impl && impl[0] == 'l') {} else if (n16 == 3) return -1;   // 48 channels: direct 4x3 measured faster
     // relative speeds measured on MI355X (profiles/conv_lds_sweep_r1.txt): mid-size tiles at 3-4 waves/SIMD
     // beat the 128x128 tile (1 wave/SIMD cannot hide its own barriers)
     static const float speed[] = {0.60f, 0.92f, 0.70f, 0.85f, 0.88f, 0.62f, 0.99f, 1.00f, 0.75f, 1.05f, 1.03f, 0.92f, 0.50f};
     float best = -1.f;
     int bv = 0;
     for (const auto& v : lds_variants) {
-        if (v.id >= kFirstRingOnly) break;                 // not in the heuristic yet
+        if (v.id >= kNumLdsVariants) break;
         const int bm = v.wm * v.mf * 16, nfw = v.wn * v.nf;
         const int ntiles = (n16 + nfw - 1) / nfw;
         const long long mtiles = (M + bm - 1) / bm;
@@ -422,12 +378,12 @@ int choose_conv_lds_variant(int M, int n16) {
     return bv;
 }
 
-int conv_lds_num_variants() { return (int)(sizeof(lds_variants) / sizeof(lds_variants[0])); }
+int conv_lds_num_variants() { return kNumLdsVariants; }
 
-void conv_lds_variant_shape(int variant, int* bm, int* bn) {
-    const LdsVariant& v = lds_variants[variant];
-    *bm = v.wm * v.mf * 16;
-    *bn = v.wn * v.nf * 16;
+bool conv_variant_shape(int variant, int* bm, int* bn) {
+    for (const auto& v : lds_variants)
+        if (v.id == variant) { *bm = v.wm * v.mf * 16; *bn = v.wn * v.nf * 16; return true; }
+    return false;
 }
 
 }  // namespace padel

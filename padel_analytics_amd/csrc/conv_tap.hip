@@ -441,9 +441,9 @@ static hipError_t launch_t(const ConvArgs& a_in, hipStream_t s) {
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
     dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
-    static const int pd = getenv("PADEL_CONV_TAP_PD") ? atoi(getenv("PADEL_CONV_TAP_PD")) : 2;
+    const int pd = a.tap_pd;
     if constexpr (WM == 2 && WN == 2 && MF == 2 && NF == 3) {
-        if (a.ksize == 3 && a.dbg && getenv("PADEL_CONV_DIAG") && atoi(getenv("PADEL_CONV_DIAG")) == 16) {
+        if (a.ksize == 3 && a.dbg) {        // timeline instantiation (pa_engine_set_tuning "timeline")
             hipLaunchKernelGGL((conv_tap_kernel<2, 2, 2, 3, true>), grid, dim3(256), 0, s, a);
             return hipGetLastError();
         }

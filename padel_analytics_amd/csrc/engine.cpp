@@ -3,12 +3,15 @@
 // C-ABI declared in include/padel_hip.h.
 #include "../../include/padel_hip.h"
 #include "kernels.h"
+#include <rccl/rccl.h>      // types only: librccl is dlopen'ed on first use (see the RCCL section)
 
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -16,13 +19,34 @@ using namespace padel;
 
 static thread_local std::string g_err;
 
+// Tuning knobs: read from the environment ONCE at pa_engine_create (PADEL_CONV_IMPL=tap|lds, PADEL_CONV_VARIANT,
+// PADEL_CONV_TUNE, PADEL_CONV_TAP_PD, PADEL_GRAPH, PADEL_ALIAS), changed afterwards only through
+// pa_engine_set_tuning — the replay loop never touches getenv.
+struct Tuning {
+    int impl = 0;        // 0: tap-unrolled LDS-DMA kernels (default), 1: LDS kernel (the bitwise cross-check)
+    int variant = -1;    // forced tile id (tests / tools), -1: per-layer heuristic
+    int tune = 1;        // bit 0: s_setprio around MFMA clusters
+    int tap_pd = 2;      // prefetch distance of the 1x1 tap kernel
+    int graph = 0;       // 1: replay the op list of a (model, batch) from a captured hipGraph
+    int timeline = 0;    // 1: 3x3 tap launches of the 64x96 tile run the s_memtime-instrumented instantiation
+    int alias = 1;       // 1: activation buffers share one arena by liveness, 0: disjoint ranges
+};
+
+struct pa_comm;
+
 struct pa_engine {
     int dev = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // uploads that must not queue behind compute (pa_upload)
     std::string err;
     bool profiling = false;
     float* zeros = nullptr;   // 256 B of zeros: source of padded conv taps
+    Tuning t;
+    std::string timeline_path;
+    pa_comm* comm = nullptr;  // RCCL communicator (pa_engine_comm_init), optional
 };
+
+static int env_int(const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; }
 
 #define PA_FAIL(eng, ...)                                        \
     do {                                                         \
@@ -55,6 +79,9 @@ struct pa_model {
     int net_h = 0, net_w = 0;
     int rw = 0, rh = 0, top = 0, left = 0, lb_mode = 0;
     std::vector<float*> bptr;
+    void* arena = nullptr;                 // what bptr points into
+    size_t arena_bytes = 0, logical_bytes = 0;   // bytes of the plan with / without liveness aliasing
+    std::map<int, hipGraphExec_t> graphs;  // op-list replay per batch size (tuning "graph")
     uint8_t* d_frames = nullptr; size_t frames_cap = 0;
     uint8_t* d_netin = nullptr;
     uint8_t* d_tmp = nullptr;
@@ -95,18 +122,48 @@ int pa_engine_create(int device_id, pa_engine** out) {
     e->dev = device_id;
     hipError_t r = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "hipStreamCreate: %s", hipGetErrorString(r)); }
+    if (r == hipSuccess) r = hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking);
+    if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "hipStreamCreate: %s", hipGetErrorString(r)); }
     r = hipMalloc((void**)&e->zeros, 256);
     if (r == hipSuccess) r = hipMemset(e->zeros, 0, 256);
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "zero page: %s", hipGetErrorString(r)); }
+    if (const char* v = getenv("PADEL_CONV_IMPL")) e->t.impl = (v[0] == 'l') ? 1 : 0;
+    e->t.variant = env_int("PADEL_CONV_VARIANT", -1);
+    e->t.tune = env_int("PADEL_CONV_TUNE", 1);
+    e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
+    e->t.graph = env_int("PADEL_GRAPH", 0);
+    e->t.alias = env_int("PADEL_ALIAS", 1);
     *out = e;
+    return 0;
+}
+
+int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
+    if (!e || !key) return 1;
+    const std::string k = key;
+    if (k == "impl") e->t.impl = value ? 1 : 0;
+    else if (k == "variant") e->t.variant = value;
+    else if (k == "tune") e->t.tune = value;
+    else if (k == "tap_pd") e->t.tap_pd = (value == 3) ? 3 : 2;
+    else if (k == "graph") e->t.graph = value ? 1 : 0;
+    else if (k == "timeline") e->t.timeline = value ? 1 : 0;
+    else if (k == "alias") e->t.alias = value ? 1 : 0;
+    else PA_FAIL(e, "pa_engine_set_tuning: unknown key '%s'", key);
+    return 0;
+}
+
+int pa_engine_set_timeline_path(pa_engine* e, const char* path) {
+    if (!e) return 1;
+    e->timeline_path = path ? path : "";
     return 0;
 }
 
 void pa_engine_destroy(pa_engine* e) {
     if (!e) return;
     hipSetDevice(e->dev);
+    pa_engine_comm_destroy(e);
     if (e->zeros) hipFree(e->zeros);
     if (e->stream) hipStreamDestroy(e->stream);
+    if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     delete e;
 }
 
@@ -132,6 +189,12 @@ int pa_memcpy_h2d(pa_engine* e, void* dst, const void* src, size_t n) {
     PA_HIP(e, hipSetDevice(e->dev));
     PA_HIP(e, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, e->stream));
     PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+int pa_upload(pa_engine* e, void* dst, const void* src, size_t n) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, e->copy_stream));
+    PA_HIP(e, hipStreamSynchronize(e->copy_stream));
     return 0;
 }
 int pa_memcpy_d2h(pa_engine* e, void* dst, const void* src, size_t n) {
@@ -195,7 +258,8 @@ static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) 
 }
 
 int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weights, size_t n_floats, pa_model** out) {
-    if (!e || !desc || !weights || !out) PA_FAIL(e, "pa_model_create: NULL argument");
+    // weights == NULL: the blob is allocated zero-filled and arrives through pa_engine_bcast_weights
+    if (!e || !desc || !out) PA_FAIL(e, "pa_model_create: NULL argument");
     if (validate_desc(e, desc, n_floats)) return 1;
     PA_HIP(e, hipSetDevice(e->dev));
     pa_model* m = new pa_model();
@@ -207,7 +271,10 @@ int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weight
     m->d.ops = m->ops.data();
     m->n_w = n_floats;
     hipError_t r = hipMalloc((void**)&m->d_w, n_floats * sizeof(float) + kConvReadSlack);
-    if (r == hipSuccess) r = hipMemcpyAsync(m->d_w, weights, n_floats * sizeof(float), hipMemcpyHostToDevice, e->stream);
+    if (r == hipSuccess)
+        r = weights ? hipMemcpyAsync(m->d_w, weights, n_floats * sizeof(float), hipMemcpyHostToDevice, e->stream)
+                    : hipMemsetAsync(m->d_w, 0, n_floats * sizeof(float), e->stream);
+    if (r == hipSuccess) r = hipMemsetAsync(m->d_w + n_floats, 0, kConvReadSlack, e->stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
     if (r != hipSuccess) { delete m; PA_FAIL(e, "weights upload: %s", hipGetErrorString(r)); }
     *out = m;
@@ -215,7 +282,10 @@ int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weight
 }
 
 static void free_plan(pa_model* m) {
-    for (float* p : m->bptr) if (p) hipFree(p);
+    for (auto& g : m->graphs) hipGraphExecDestroy(g.second);
+    m->graphs.clear();
+    if (m->arena) hipFree(m->arena);
+    m->arena = nullptr;
     m->bptr.clear();
     void* ptrs[] = {m->d_netin, m->d_tmp, m->d_xtab, m->d_ytab, m->d_hb, m->d_hk, m->d_vb, m->d_vk, m->d_cand,
                     m->d_cidx, m->d_ccnt, m->d_keys, m->d_order, m->d_supp, m->d_oboxes, m->d_okpts, m->d_ocnt};
@@ -306,19 +376,63 @@ static hipError_t upload(pa_engine* e, int32_t** dptr, const std::vector<int32_t
     return hipStreamSynchronize(e->stream);
 }
 
+// Activation memory plan.  Every logical buffer of the graph needs batch * H * W * channels floats, but most
+// are dead most of the time (a C2f's scratch dies with the C2f): buffers whose live ranges on the op list do not
+// overlap share bytes of ONE arena (first-fit by offset over the buffers ordered by first use).  A buffer is
+// live from the first op that touches it to the last one; the network input of a TrackNet graph (buffer 0) is
+// live from before op 0, head buffers stay live past the last op (decode / NMS / pa_yolo_read_head read them).
+// Aliased bytes always hold finite fp32 activations, so a zero-weighted pad channel still contributes exactly 0.
 static int plan_buffers(pa_model* m, int batch) {
     pa_engine* e = m->e;
     int maxl = 0;
     for (const auto& b : m->bufs) maxl = std::max(maxl, b.level);
     const int mask = (1 << maxl) - 1;
     if ((m->net_h & mask) || (m->net_w & mask)) PA_FAIL(e, "network input %dx%d is not a multiple of %d", m->net_h, m->net_w, mask + 1);
-    m->bptr.assign(m->bufs.size(), nullptr);
-    for (size_t i = 0; i < m->bufs.size(); ++i) {
-        const size_t H = m->net_h >> m->bufs[i].level, W = m->net_w >> m->bufs[i].level;
-        const size_t bytes = (size_t)batch * H * W * m->bufs[i].channels * sizeof(float);
-        PA_HIP(e, hipMalloc((void**)&m->bptr[i], bytes + kConvReadSlack));
-        PA_HIP(e, hipMemsetAsync(m->bptr[i], 0, bytes + kConvReadSlack, e->stream));
+    const int nb = (int)m->bufs.size(), nops = (int)m->ops.size();
+    std::vector<int> first(nb, nops + 1), last(nb, -2);
+    auto touch = [&](int b, int i) { if (b >= 0 && b < nb) { first[b] = std::min(first[b], i); last[b] = std::max(last[b], i); } };
+    for (int i = 0; i < nops; ++i) {
+        const pa_op_desc& o = m->ops[i];
+        if (o.kind != PA_OP_STEM) touch(o.in_buf, i);
+        touch(o.out_buf, i);
+        if (o.kind == PA_OP_CONV && o.res_buf >= 0) touch(o.res_buf, i);
     }
+    if (m->d.task == PA_TASK_TRACKNET) touch(0, -1);
+    for (int l = 0; l < 3; ++l) touch(m->d.head_buf[l], nops + 1);
+    std::vector<size_t> bytes(nb), off(nb, 0);
+    size_t logical = 0;
+    for (int i = 0; i < nb; ++i) {
+        const size_t H = m->net_h >> m->bufs[i].level, W = m->net_w >> m->bufs[i].level;
+        bytes[i] = ((size_t)batch * H * W * m->bufs[i].channels * sizeof(float) + kConvReadSlack + 255) & ~(size_t)255;
+        logical += bytes[i];
+    }
+    size_t total = 0;
+    if (e->t.alias) {
+        std::vector<int> order(nb);
+        for (int i = 0; i < nb; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return first[a] < first[b]; });
+        std::vector<int> act;                                     // placed buffers still live, sorted by offset
+        for (int b : order) {
+            if (last[b] < first[b]) continue;                     // never touched: offset 0, never accessed
+            act.erase(std::remove_if(act.begin(), act.end(), [&](int a) { return last[a] < first[b]; }), act.end());
+            size_t o = 0;
+            for (int a : act) {
+                if (o + bytes[b] <= off[a]) break;
+                o = std::max(o, off[a] + bytes[a]);
+            }
+            off[b] = o;
+            act.insert(std::upper_bound(act.begin(), act.end(), b, [&](int x, int y) { return off[x] < off[y]; }), b);
+            total = std::max(total, o + bytes[b]);
+        }
+    } else {
+        for (int i = 0; i < nb; ++i) { off[i] = total; total += bytes[i]; }
+    }
+    PA_HIP(e, hipMalloc(&m->arena, total + kConvReadSlack));
+    PA_HIP(e, hipMemsetAsync(m->arena, 0, total + kConvReadSlack, e->stream));
+    m->bptr.assign(nb, nullptr);
+    for (int i = 0; i < nb; ++i) m->bptr[i] = reinterpret_cast<float*>(static_cast<char*>(m->arena) + off[i]);
+    m->arena_bytes = total;
+    m->logical_bytes = logical;
     m->p_batch = batch;
     return 0;
 }
@@ -433,48 +547,36 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.M = n * Ho * Wo;
             fill_fastdiv((unsigned)(Ho * Wo), &a.howo_magic, &a.howo_shift);
             fill_fastdiv((unsigned)Wo, &a.wo_magic, &a.wo_shift);
-            a.tune = getenv("PADEL_CONV_TUNE") ? atoi(getenv("PADEL_CONV_TUNE")) : 1;   // default: s_setprio around MFMA clusters
-            // kernel choice: v5 tap kernels (conv_tap.hip) unless a tuning override asks for an older generation:
-            //   PADEL_CONV_TAP=0 | PADEL_CONV_IMPL=direct|lds | PADEL_CONV_RING=1 | PADEL_CONV_PIPE=1 ; a forced
-            //   PADEL_CONV_LDS_VARIANT picks the tile (of the LDS kernel, or of the tap kernel with PADEL_CONV_TAP=1)
-            const bool use_ring = getenv("PADEL_CONV_RING") && atoi(getenv("PADEL_CONV_RING"));
-            const bool use_pipe = getenv("PADEL_CONV_PIPE") && atoi(getenv("PADEL_CONV_PIPE"));
-            const bool forced_tile = getenv("PADEL_CONV_LDS_VARIANT") != nullptr;
-            const bool use_tap = getenv("PADEL_CONV_TAP") ? atoi(getenv("PADEL_CONV_TAP")) != 0
-                                                          : (!getenv("PADEL_CONV_IMPL") && !forced_tile && !use_ring && !use_pipe);
-            int mf = 0, nf = 0;
-            const int lv = (use_tap && !forced_tile) ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16);
-            if (lv >= 0) conv_lds_variant_shape(lv, &mf, &nf);      // profile rows carry BM, BN of the workgroup tile
-            else choose_conv_tile(a.M, a.n16, &mf, &nf);
+            a.tune = e->t.tune; a.tap_pd = e->t.tap_pd;
+            // kernel choice: tap kernels (conv_tap.hip) unless tuning asks for the LDS cross-check kernel; a forced
+            // variant picks the tile of whichever kernel is selected
+            const bool use_tap = e->t.impl == 0;
+            const int lv = e->t.variant >= 0 ? e->t.variant
+                                             : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
+            int bm = 0, bn = 0;
+            conv_variant_shape(lv, &bm, &bn);                        // profile rows carry BM, BN of the workgroup tile
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
-            if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = mf; pr->nf = nf; }
-            // tuning only: PADEL_CONV_DBG=<file> collects the DIAG-16 timeline of this launch (conv_lds.hip) into <file>
+            if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = bm; pr->nf = bn; }
+            // tuning only ("timeline"): collect the s_memtime timeline of this launch into timeline_path
             unsigned long long* dbg_dev = nullptr;
             size_t dbg_bytes = 0;
-            if (getenv("PADEL_CONV_DBG")) {
-                const int bm = 64, bn = 96;
-                dbg_bytes = (size_t)((a.M + bm - 1) / bm) * ((o.npad + bn - 1) / bn) * kConvDbgWords * 8;
+            if (e->t.timeline && use_tap && lv == 7 && o.ksize == 3 && !e->timeline_path.empty()) {
+                dbg_bytes = (size_t)((a.M + 63) / 64) * ((o.npad + 95) / 96) * kConvDbgWords * 8;
                 if (hipMalloc(&dbg_dev, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(dbg_dev, 0, dbg_bytes, s);
                 else dbg_dev = nullptr;
                 a.dbg = dbg_dev;
             }
-            if (lv >= 0 && use_tap) {
+            if (use_tap) {
                 r = launch_conv_tap(a, lv, s);
-                if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);
-            } else if (lv >= 0 && use_ring) {
-                r = launch_conv_ring(a, lv, s);
-                if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);
-            } else if (lv >= 0 && use_pipe) {
-                r = launch_conv_pipe(a, lv, s);
-                if (r == hipErrorNotSupported) r = launch_conv_lds(a, lv, s);
+                if (r == hipErrorNotSupported && e->t.variant < 0) r = launch_conv_lds(a, choose_conv_lds_variant(a.M, a.n16), s);
             } else {
-                r = lv >= 0 ? launch_conv_lds(a, lv, s) : launch_conv_igemm(a, mf, nf, s);
+                r = launch_conv_lds(a, lv, s);
             }
             if (dbg_dev) {
                 (void)hipStreamSynchronize(s);
                 std::vector<unsigned long long> host(dbg_bytes / 8);
                 (void)hipMemcpy(host.data(), dbg_dev, dbg_bytes, hipMemcpyDeviceToHost);
-                if (FILE* f = fopen(getenv("PADEL_CONV_DBG"), "wb")) { fwrite(host.data(), 1, dbg_bytes, f); fclose(f); }
+                if (FILE* f = fopen(e->timeline_path.c_str(), "wb")) { fwrite(host.data(), 1, dbg_bytes, f); fclose(f); }
                 (void)hipFree(dbg_dev);
             }
         } else if (o.kind == PA_OP_STEM) {
@@ -499,6 +601,30 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
         prof_end(m, pr);
         if (r != hipSuccess) PA_FAIL(e, "op %zu (kind %d) launch failed: %s", i, o.kind, hipGetErrorString(r));
     }
+    return 0;
+}
+
+// run_ops, or (tuning "graph", not while profiling) the replay of its capture for this batch size: the op list of
+// an n-scale graph is ~100 launches of 10-40 us each, where per-launch host work shows
+static int run_graph(pa_model* m, int n, size_t* pi) {
+    pa_engine* e = m->e;
+    if (!e->t.graph || e->profiling || e->t.timeline) return run_ops(m, n, pi);
+    auto it = m->graphs.find(n);
+    if (it == m->graphs.end()) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        PA_HIP(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+        size_t dummy = 0;
+        const int rc = run_ops(m, n, &dummy);
+        const hipError_t r = hipStreamEndCapture(e->stream, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return 1; }
+        if (r != hipSuccess) PA_FAIL(e, "hipStreamEndCapture: %s", hipGetErrorString(r));
+        const hipError_t ri = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ri != hipSuccess) PA_FAIL(e, "hipGraphInstantiate: %s", hipGetErrorString(ri));
+        it = m->graphs.emplace(n, ge).first;
+    }
+    PA_HIP(e, hipGraphLaunch(it->second, e->stream));
     return 0;
 }
 
@@ -583,7 +709,7 @@ int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const
         prof_end(m, pr);
         if (r != hipSuccess) PA_FAIL(e, "preprocess launch failed: %s", hipGetErrorString(r));
         // ---- network
-        if (run_ops(m, nb, &pi)) return 1;
+        if (run_graph(m, nb, &pi)) return 1;
         // ---- decode + NMS
         DecodeArgs da{};
         for (int l = 0; l < 3; ++l) da.lv[l] = m->lv[l];
@@ -639,6 +765,28 @@ int pa_yolo_read_head(pa_model* m, int level, int n, float* out) {
     return 0;
 }
 
+int pa_yolo_netin_shape(pa_model* m, int* h, int* w) {
+    if (!m->planned || m->d.task == PA_TASK_TRACKNET) PA_FAIL(m->e, "pa_yolo_netin_shape: no YOLO plan");
+    *h = m->net_h; *w = m->net_w;
+    return 0;
+}
+
+int pa_yolo_read_netin(pa_model* m, int n, uint8_t* out) {
+    pa_engine* e = m->e;
+    if (!m->planned || !m->d_netin || n < 1 || n > m->last_n || !out) PA_FAIL(e, "pa_yolo_read_netin: no plan / bad n");
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipMemcpyAsync(out, m->d_netin, (size_t)n * m->net_h * m->net_w * 4, hipMemcpyDeviceToHost, e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+int pa_model_plan_bytes(pa_model* m, size_t* arena_bytes, size_t* logical_bytes) {
+    if (!m->planned) PA_FAIL(m->e, "pa_model_plan_bytes: no plan yet");
+    if (arena_bytes) *arena_bytes = m->arena_bytes;
+    if (logical_bytes) *logical_bytes = m->logical_bytes;
+    return 0;
+}
+
 int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on_device, float* out, int out_on_device) {
     if (!m) return 1;
     pa_engine* e = m->e;
@@ -662,7 +810,7 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
         const size_t in_bytes = (size_t)nb * h * w * cin * sizeof(float);
         PA_HIP(e, hipMemcpyAsync(m->bptr[0], x + (size_t)c0 * h * w * cin, in_bytes,
                                  x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-        if (run_ops(m, nb, &pi)) return 1;
+        if (run_graph(m, nb, &pi)) return 1;
         const size_t ohw = (size_t)(h >> m->bufs[ob].level) * (w >> m->bufs[ob].level);
         const size_t out_bytes = (size_t)nb * ohw * cout * sizeof(float);
         PA_HIP(e, hipMemcpyAsync(out + (size_t)c0 * ohw * cout, m->bptr[ob], out_bytes,
@@ -703,8 +851,7 @@ int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
     if (m->d.task != PA_TASK_TRACKNET) PA_FAIL(e, "pa_ball_create: not a TrackNet model");
     if (m->bufs[0].channels != 32) PA_FAIL(e, "pa_ball_create: TrackNet input buffer must have 32 channels (27 + pad)");
     PA_HIP(e, hipSetDevice(e->dev));
-    if (src_h <= 0 || src_w <= 0 || (src_h == BALL_H && src_w == BALL_W))
-        PA_FAIL(e, "pa_ball_create: unsupported source size %dx%d", src_w, src_h);
+    if (src_h <= 0 || src_w <= 0) PA_FAIL(e, "pa_ball_create: unsupported source size %dx%d", src_w, src_h);
     if (m->bufs[m->d.head_buf[0]].channels < 8)
         PA_FAIL(e, "pa_ball_create: TrackNet output has %d channels (< 8)", m->bufs[m->d.head_buf[0]].channels);
     pa_ball* b = new pa_ball();
@@ -734,6 +881,14 @@ int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
     std::vector<int32_t> bb, kk;
     if (src_w != BALL_W) { b->hks = pil_coeffs(src_w, BALL_W, bb, kk); PA_HIP(e, upload(e, &b->d_hb, bb)); PA_HIP(e, upload(e, &b->d_hk, kk)); }
     if (src_h != BALL_H) { b->vks = pil_coeffs(src_h, BALL_H, bb, kk); PA_HIP(e, upload(e, &b->d_vb, bb)); PA_HIP(e, upload(e, &b->d_vk, kk)); }
+    if (src_h == BALL_H && src_w == BALL_W) {
+        // identity "resample": one tap of weight 1.0 (1 << 22) per output row
+        b->vks = 1;
+        bb.assign((size_t)BALL_H * 2, 0);
+        kk.assign((size_t)BALL_H, 1 << 22);
+        for (int y = 0; y < BALL_H; ++y) { bb[2 * y] = y; bb[2 * y + 1] = 1; }
+        PA_HIP(e, upload(e, &b->d_vb, bb)); PA_HIP(e, upload(e, &b->d_vk, kk));
+    }
     guard.ok = true;
     *out = b;
     return 0;
@@ -769,6 +924,15 @@ static int ball_resize(pa_ball* b, const uint8_t* src, int n, uint8_t* dst, int 
         ResamplePassArgs a{};
         a.in = cur; a.out = dst; a.B = n; a.in_h = b->h; a.in_w = cw; a.in_c = 3;
         a.out_h = BALL_H; a.out_w = cw; a.out_c = 3; a.vertical = 1; a.bounds = b->d_vb; a.coefs = b->d_vk; a.ksize = b->vks;
+        a.reverse = reverse;
+        r = launch_resample_pass(a, s);
+    }
+    if (r == hipSuccess && b->w == BALL_W && b->h == BALL_H) {
+        // source already 512x288: Pillow's resize is the identity, only the channel order may change
+        // (letterbox kernel in copy mode writes 4-byte pixels, so use a 1-tap "resample" instead)
+        ResamplePassArgs a{};
+        a.in = src; a.out = dst; a.B = n; a.in_h = b->h; a.in_w = b->w; a.in_c = 3;
+        a.out_h = BALL_H; a.out_w = BALL_W; a.out_c = 3; a.vertical = 1; a.bounds = b->d_vb; a.coefs = b->d_vk; a.ksize = b->vks;
         a.reverse = reverse;
         r = launch_resample_pass(a, s);
     }
@@ -825,6 +989,9 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
     pa_model* m = b->m;
     pa_engine* e = m->e;
     if (!b->have_bg) PA_FAIL(e, "pa_ball_feed: set the background first");
+    if (b->B != m->max_batch)
+        PA_FAIL(e, "pa_ball_feed: the model's max_batch changed (%d -> %d) after the session was created; create a new session",
+                b->B, m->max_batch);
     if (n < 0 || n > b->B || (n > 0 && !frames)) PA_FAIL(e, "pa_ball_feed: n = %d (max %d)", n, b->B);
     PA_HIP(e, hipSetDevice(e->dev));
     hipStream_t s = e->stream;
@@ -862,7 +1029,7 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
             aa.B = nw; aa.H = BALL_H; aa.W = BALL_W; aa.ring = b->ring; aa.first_slot = (int)(g_lo % b->ring);
             hipError_t r = launch_ball_assemble(aa, s);
             if (r != hipSuccess) PA_FAIL(e, "ball assemble launch failed: %s", hipGetErrorString(r));
-            if (run_ops(m, nw, &prof_n)) return 1;
+            if (run_graph(m, nw, &prof_n)) return 1;
             PA_HIP(e, hipMemcpyAsync(b->d_Y + (size_t)7 * HW * b->cs, m->bptr[m->d.head_buf[0]],
                                      (size_t)nw * HW * b->cs * sizeof(float), hipMemcpyDeviceToDevice, s));
             for (int i = 0; i < nw; ++i) {             // frame g = g_lo + i: rows i .. i+7 (row r <-> window g_lo - 7 + r)
@@ -954,6 +1121,116 @@ int pa_model_last_profile(pa_model* m, int cap, int32_t* kinds, float* ms, doubl
         kinds[n] = m->prof[i].kind; ms[n] = m->prof[i].ms; flops[n] = m->prof[i].flops; ksizes[n] = m->prof[i].ksize;
     }
     return n;
+}
+
+// ------------------------------------------------------------------------------- RCCL (one-time weight broadcast)
+// librccl is dlopen'ed on first use: a process that already holds torch's bundled librccl.so.1 gets that one
+// (same SONAME), a standalone process the ROCm one; single-GPU users never load it.
+
+struct pa_comm {
+    void* lib = nullptr;
+    ncclComm_t comm = nullptr;
+    int nranks = 0, rank = 0;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static void* rccl_lib() {
+    static void* lib = nullptr;
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    return lib;
+}
+
+int pa_comm_unique_id(void* out, size_t cap) {
+    if (!out || cap < NCCL_UNIQUE_ID_BYTES) PA_FAIL((pa_engine*)nullptr, "pa_comm_unique_id: need %d bytes", NCCL_UNIQUE_ID_BYTES);
+    void* lib = rccl_lib();
+    if (!lib) PA_FAIL((pa_engine*)nullptr, "librccl.so.1 not found: %s", dlerror());
+    auto get = (ncclResult_t (*)(ncclUniqueId*))dlsym(lib, "ncclGetUniqueId");
+    if (!get) PA_FAIL((pa_engine*)nullptr, "ncclGetUniqueId missing");
+    ncclUniqueId id;
+    const ncclResult_t r = get(&id);
+    if (r != ncclSuccess) PA_FAIL((pa_engine*)nullptr, "ncclGetUniqueId failed (%d)", (int)r);
+    memcpy(out, &id, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int pa_engine_comm_init(pa_engine* e, const void* unique_id, size_t id_bytes, int nranks, int rank) {
+    if (!e || !unique_id || id_bytes < NCCL_UNIQUE_ID_BYTES || nranks < 1 || rank < 0 || rank >= nranks)
+        PA_FAIL(e, "pa_engine_comm_init: bad arguments");
+    if (e->comm) PA_FAIL(e, "pa_engine_comm_init: communicator already initialised");
+    void* lib = rccl_lib();
+    if (!lib) PA_FAIL(e, "librccl.so.1 not found: %s", dlerror());
+    pa_comm* c = new pa_comm();
+    c->lib = lib; c->nranks = nranks; c->rank = rank;
+    c->CommInitRank = (decltype(c->CommInitRank))dlsym(lib, "ncclCommInitRank");
+    c->CommDestroy = (decltype(c->CommDestroy))dlsym(lib, "ncclCommDestroy");
+    c->Broadcast = (decltype(c->Broadcast))dlsym(lib, "ncclBroadcast");
+    c->AllReduce = (decltype(c->AllReduce))dlsym(lib, "ncclAllReduce");
+    c->GetErrorString = (decltype(c->GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!c->CommInitRank || !c->CommDestroy || !c->Broadcast || !c->AllReduce || !c->GetErrorString) {
+        delete c;
+        PA_FAIL(e, "librccl: missing symbols");
+    }
+    PA_HIP(e, hipSetDevice(e->dev));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, NCCL_UNIQUE_ID_BYTES);
+    const ncclResult_t r = c->CommInitRank(&c->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+        const char* msg = c->GetErrorString(r);
+        delete c;
+        PA_FAIL(e, "ncclCommInitRank(%d/%d): %s", rank, nranks, msg);
+    }
+    e->comm = c;
+    return 0;
+}
+
+void pa_engine_comm_destroy(pa_engine* e) {
+    if (!e || !e->comm) return;
+    hipSetDevice(e->dev);
+    hipStreamSynchronize(e->stream);
+    if (e->comm->comm) e->comm->CommDestroy(e->comm->comm);
+    delete e->comm;
+    e->comm = nullptr;
+}
+
+// in-place broadcast of device memory from `root` over the engine's communicator (xGMI inside a node)
+int pa_engine_bcast(pa_engine* e, void* dev_ptr, size_t nbytes, int root) {
+    if (!e || !dev_ptr) return 1;
+    if (!e->comm) PA_FAIL(e, "pa_engine_bcast: call pa_engine_comm_init first");
+    PA_HIP(e, hipSetDevice(e->dev));
+    const ncclResult_t r = e->comm->Broadcast(dev_ptr, dev_ptr, nbytes, ncclUint8, root, e->comm->comm, e->stream);
+    if (r != ncclSuccess) PA_FAIL(e, "ncclBroadcast: %s", e->comm->GetErrorString(r));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// the one collective of the path: the packed weight blob goes from the rank that loaded the checkpoint to every
+// other GPU, HBM to HBM (north_star "one-time RCCL broadcast of weights over xGMI")
+int pa_engine_bcast_weights(pa_engine* e, pa_model* m, int root) {
+    if (!e || !m || m->e != e) return 1;
+    return pa_engine_bcast(e, m->d_w, m->n_w * sizeof(float), root);
+}
+
+// max over ranks of one double (bench: step time) — keeps the measurement inside the same communicator
+int pa_engine_allreduce_max(pa_engine* e, double* value) {
+    if (!e || !value) return 1;
+    if (!e->comm) PA_FAIL(e, "pa_engine_allreduce_max: call pa_engine_comm_init first");
+    PA_HIP(e, hipSetDevice(e->dev));
+    double* d = nullptr;
+    PA_HIP(e, hipMalloc((void**)&d, sizeof(double)));
+    hipError_t h = hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, e->stream);
+    ncclResult_t r = ncclSuccess;
+    if (h == hipSuccess) r = e->comm->AllReduce(d, d, 1, ncclDouble, ncclMax, e->comm->comm, e->stream);
+    if (h == hipSuccess && r == ncclSuccess) h = hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    hipFree(d);
+    if (r != ncclSuccess) PA_FAIL(e, "ncclAllReduce: %s", e->comm->GetErrorString(r));
+    if (h != hipSuccess) PA_FAIL(e, "pa_engine_allreduce_max: %s", hipGetErrorString(h));
+    return 0;
 }
 
 }  // extern "C"

@@ -31,6 +31,7 @@ struct ConvArgs {
     int M;                // batch * Ho * Wo
     int n_mtiles;         // ceil(M / (4 * MF * 16))
     int tune;             // bit 0: s_setprio(1) around MFMA clusters; bit 1: staggered workgroup start
+    int tap_pd;           // 1x1 tap kernel: prefetch distance 2 or 3 (pa_engine_set_tuning "tap_pd")
     unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_lds.hip DIAG 16
     // m / (Ho*Wo) and rem / Wo without an integer-division sequence (conv_tap.hip prologue): q = (umulhi(n, magic) + n) >> shift,
     // exact for 0 <= n < 2^31 (fill_fastdiv below; the conv kernels' rows satisfy n < 2^31)
@@ -45,24 +46,17 @@ inline void fill_fastdiv(unsigned d, unsigned* magic, unsigned* shift) {
 constexpr int kConvDbgSteps = 64;                       // k-steps kept per wave (ring)
 constexpr int kConvDbgWords = 8 + 4 * kConvDbgSteps * 5;   // u64 words per workgroup: header + 4 waves x steps x 5 stamps
 
-// implicit-GEMM conv on v_mfma_f32_16x16x4_f32; MF in {1,2,4}, NF in {1..6}
-hipError_t launch_conv_igemm(const ConvArgs& a, int mf, int nf, hipStream_t s);
-// heuristic tile choice for a (M, npad16) problem: returns mf, nf and the N padding it implies
-void choose_conv_tile(int M, int n16, int* mf, int* nf);
-
-// v2: LDS-staged workgroup tiles (conv_lds.hip); bit-identical results to the register-direct kernel
-hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s);
+// Two generations of the implicit-GEMM conv on v_mfma_f32_16x16x4_f32 ship in the library: the default tap-unrolled
+// LDS-DMA ring (conv_tap.hip) and the register-staged LDS kernel (conv_lds.hip), kept as its bitwise cross-check
+// (same K order and accumulation blocks => identical results; tests/test_gpu_conv.py).  Three retired generations
+// live in tools/legacy_conv/ and are not built.  Tile variants share one id space (conv_variant_shape).
+hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s);     // ids 0..12
 int conv_lds_num_variants();
-void conv_lds_variant_shape(int variant, int* bm, int* bn);
-// returns the LDS variant to use for (M, n16), or -1 to use the register-direct kernel
 int choose_conv_lds_variant(int M, int n16);
-// v3 (opt-in): 3-stage LDS ring + double-buffered fragments; same variant ids, hipErrorNotSupported if not instantiated
-hipError_t launch_conv_pipe(const ConvArgs& a, int variant, hipStream_t s);
-// v4: LDS-DMA ring (conv_ring.hip); hipErrorNotSupported for tiles it is not instantiated for
-hipError_t launch_conv_ring(const ConvArgs& a, int variant, hipStream_t s);
-// v5: tap-unrolled LDS-DMA ring for 3x3 convs with cin % 32 == 0 (conv_tap.hip); reads up to 128 B past the last
-// chunk of a pixel / weight row, so every buffer a conv reads is allocated with kConvReadSlack extra bytes
-hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s);
+bool conv_variant_shape(int variant, int* bm, int* bn);                         // false: unknown id
+// conv_tap.hip reads up to 128 B past the last chunk of a pixel / weight row, so every buffer a conv reads is
+// allocated with kConvReadSlack extra bytes; hipErrorNotSupported when the layer or the tile is not covered
+hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s);      // ids 6,7,9..15,20
 constexpr size_t kConvReadSlack = 512;
 int choose_conv_tap_variant(int M, int n16);
 

@@ -63,6 +63,11 @@ ABI_SYMBOLS = [
     "pa_yolo_read_head", "pa_tracknet_infer", "pa_engine_set_profiling", "pa_model_last_profile",
     "pa_model_profile_text", "pa_ball_create", "pa_ball_destroy", "pa_ball_set_background", "pa_ball_feed",
     "pa_ball_locate", "pa_ball_background_from_frames",
+    "pa_upload", "pa_engine_set_tuning", "pa_engine_set_timeline_path", "pa_model_plan_bytes",
+    "pa_yolo_netin_shape", "pa_yolo_read_netin",
+    "pa_comm_unique_id", "pa_engine_comm_init", "pa_engine_comm_destroy", "pa_engine_bcast_weights",
+    "pa_engine_bcast", "pa_engine_allreduce_max",
+    "pa_bytetrack_create", "pa_bytetrack_destroy", "pa_bytetrack_reset", "pa_bytetrack_update_batch",
 ]
 
 
@@ -112,6 +117,25 @@ def load_library():
     lib.pa_ball_feed.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, C.POINTER(i32)]
     lib.pa_ball_locate.argtypes = [vp, vp, i32, vp]
     lib.pa_ball_background_from_frames.argtypes = [vp, vp, i32, i32, vp]
+    lib.pa_upload.argtypes = [vp, vp, vp, sz]
+    lib.pa_engine_set_tuning.argtypes = [vp, C.c_char_p, i32]
+    lib.pa_engine_set_timeline_path.argtypes = [vp, C.c_char_p]
+    lib.pa_model_plan_bytes.argtypes = [vp, C.POINTER(sz), C.POINTER(sz)]
+    lib.pa_yolo_netin_shape.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.pa_yolo_read_netin.argtypes = [vp, i32, vp]
+    lib.pa_comm_unique_id.argtypes = [vp, sz]
+    lib.pa_engine_comm_init.argtypes = [vp, vp, sz, i32, i32]
+    lib.pa_engine_comm_destroy.argtypes = [vp]
+    lib.pa_engine_comm_destroy.restype = None
+    lib.pa_engine_bcast_weights.argtypes = [vp, vp, i32]
+    lib.pa_engine_bcast.argtypes = [vp, vp, sz, i32]
+    lib.pa_engine_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.pa_bytetrack_create.argtypes = [C.c_float, i32, C.c_float, i32, C.POINTER(vp)]
+    lib.pa_bytetrack_destroy.argtypes = [vp]
+    lib.pa_bytetrack_destroy.restype = None
+    lib.pa_bytetrack_reset.argtypes = [vp]
+    lib.pa_bytetrack_reset.restype = None
+    lib.pa_bytetrack_update_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     if lib.pa_abi_version() != 1:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
@@ -119,18 +143,29 @@ def load_library():
 
 
 class DeviceBuffer:
-    """Raw HBM allocation owned by an Engine (bench keeps frame batches resident with it)."""
+    """Raw HBM allocation owned by an Engine (bench keeps frame batches resident with it).  ``view(off, n)``
+    gives a non-owning window of the same memory (a batch of frames inside a resident clip)."""
 
-    def __init__(self, engine: "Engine", nbytes: int):
+    def __init__(self, engine: "Engine", nbytes: int, _ptr: Optional[int] = None):
         self.engine, self.nbytes = engine, nbytes
-        p = C.c_void_p()
-        engine._check(engine.lib.pa_device_malloc(engine.handle, nbytes, C.byref(p)))
-        self.ptr = p.value
+        self.owner = _ptr is None
+        if _ptr is None:
+            p = C.c_void_p()
+            engine._check(engine.lib.pa_device_malloc(engine.handle, nbytes, C.byref(p)))
+            _ptr = p.value
+        self.ptr = _ptr
 
-    def upload(self, arr: np.ndarray) -> "DeviceBuffer":
+    def view(self, offset: int, nbytes: int) -> "DeviceBuffer":
+        assert 0 <= offset and offset + nbytes <= self.nbytes
+        return DeviceBuffer(self.engine, nbytes, _ptr=self.ptr + offset)
+
+    def upload(self, arr: np.ndarray, copy_stream: bool = False) -> "DeviceBuffer":
+        """copy_stream=True: use the engine's copy stream (pa_upload) — the copy does not queue behind inference
+        launched from another host thread."""
         arr = np.ascontiguousarray(arr)
         assert arr.nbytes <= self.nbytes
-        self.engine._check(self.engine.lib.pa_memcpy_h2d(self.engine.handle, self.ptr, arr.ctypes.data, arr.nbytes))
+        f = self.engine.lib.pa_upload if copy_stream else self.engine.lib.pa_memcpy_h2d
+        self.engine._check(f(self.engine.handle, self.ptr, arr.ctypes.data, arr.nbytes))
         return self
 
     def download(self, arr: np.ndarray) -> np.ndarray:
@@ -139,9 +174,9 @@ class DeviceBuffer:
         return arr
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.owner:
             self.engine.lib.pa_device_free(self.engine.handle, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
 
 class Engine:
@@ -170,6 +205,28 @@ class Engine:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
+    def set_tuning(self, **kv):
+        """Tests / tools only: impl (0 tap, 1 lds), variant (tile id, -1 auto), tune, tap_pd, graph, alias, timeline."""
+        for k, v in kv.items():
+            self._check(self.lib.pa_engine_set_tuning(self.handle, k.encode(), int(v)))
+
+    # ---- multi-GPU: RCCL communicator owned by the library (include/padel_hip.h "multi-GPU")
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
+        self._check(self.lib.pa_engine_comm_init(self.handle, buf, len(unique_id), nranks, rank))
+        self.nranks, self.rank = nranks, rank
+
+    def bcast_weights(self, model: "Model", root: int = 0):
+        self._check(self.lib.pa_engine_bcast_weights(self.handle, model.handle, root))
+
+    def bcast(self, buf: DeviceBuffer, nbytes: int, root: int = 0):
+        self._check(self.lib.pa_engine_bcast(self.handle, buf.ptr, nbytes, root))
+
+    def allreduce_max(self, value: float) -> float:
+        v = C.c_double(value)
+        self._check(self.lib.pa_engine_allreduce_max(self.handle, C.byref(v)))
+        return v.value
+
     def close(self):
         if self.handle:
             self.lib.pa_engine_destroy(self.handle)
@@ -177,6 +234,15 @@ class Engine:
 
 
 _default_engines: dict = {}
+
+
+def comm_unique_id() -> bytes:
+    """128-byte RCCL unique id (rank 0 creates it; ship it to the other ranks out of band)."""
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    if lib.pa_comm_unique_id(buf, 128) != 0:
+        raise EngineError(lib.pa_last_error(None).decode())
+    return buf.raw
 
 
 def default_engine(device_id: Optional[int] = None) -> Engine:
@@ -195,9 +261,12 @@ def default_engine(device_id: Optional[int] = None) -> Engine:
 class Model:
     """A graph + weights resident in HBM on one engine."""
 
-    def __init__(self, engine: Engine, graph: G.Graph, blob: Optional[np.ndarray] = None):
+    def __init__(self, engine: Engine, graph: G.Graph, blob: Optional[np.ndarray] = None, *, empty: bool = False):
+        """empty=True: allocate the weight blob in HBM without uploading anything — it arrives through
+        ``engine.bcast_weights(model)`` from the rank that loaded the checkpoint."""
         self.engine, self.graph = engine, graph
-        blob = graph.blob() if blob is None else np.ascontiguousarray(blob, np.float32)
+        if not empty:
+            blob = graph.blob() if blob is None else np.ascontiguousarray(blob, np.float32)
         bufs = (pa_buf_desc * len(graph.bufs))(*[pa_buf_desc(l, c) for l, c in graph.bufs])
         ops = (pa_op_desc * len(graph.ops))()
         for i, o in enumerate(graph.ops):
@@ -208,7 +277,8 @@ class Model:
         for i in range(3):
             d.head_buf[i] = graph.head_buf[i] if i < len(graph.head_buf) else -1
         h = C.c_void_p()
-        engine._check(engine.lib.pa_model_create(engine.handle, C.byref(d), blob.ctypes.data, blob.size, C.byref(h)))
+        engine._check(engine.lib.pa_model_create(engine.handle, C.byref(d), None if empty else blob.ctypes.data,
+                                                 graph.n_floats if empty else blob.size, C.byref(h)))
         self.handle = h
         self.max_batch = 64
 
@@ -253,6 +323,20 @@ class Model:
         self.engine._check(self.engine.lib.pa_yolo_read_head(self.handle, level, n, out.ctypes.data))
         return out
 
+    def read_netin(self, n: int) -> np.ndarray:
+        """u8 NHWC4 network input of the first n frames of the last yolo_infer call."""
+        hh, ww = C.c_int(), C.c_int()
+        self.engine._check(self.engine.lib.pa_yolo_netin_shape(self.handle, C.byref(hh), C.byref(ww)))
+        out = np.empty((n, hh.value, ww.value, 4), np.uint8)
+        self.engine._check(self.engine.lib.pa_yolo_read_netin(self.handle, n, out.ctypes.data))
+        return out
+
+    def plan_bytes(self) -> tuple:
+        """(arena bytes allocated, sum of the logical buffers) of the current activation plan."""
+        a, l = C.c_size_t(), C.c_size_t()
+        self.engine._check(self.engine.lib.pa_model_plan_bytes(self.handle, C.byref(a), C.byref(l)))
+        return a.value, l.value
+
     def tracknet_infer(self, x: np.ndarray) -> np.ndarray:
         """x: (n, H, W, C_in) fp32 NHWC -> (n, H, W, C_out) fp32."""
         x = np.ascontiguousarray(x, np.float32)
@@ -286,6 +370,46 @@ class Model:
     def close(self):
         if self.handle:
             self.engine.lib.pa_model_destroy(self.handle)
+            self.handle = None
+
+
+class NativeByteTrack:
+    """``pa_bytetrack_*``: the host-native (C++) twin of ``padel_analytics_amd.bytetrack.ByteTrack`` — same
+    algorithm, orderings and id semantics (tests/test_bytetrack_golden.py pins both to the same fixtures); consumes
+    a whole batch of frames per call.  Host code inside libpadel_hip.so: works without a GPU."""
+
+    def __init__(self, track_activation_threshold: float = 0.25, lost_track_buffer: int = 30,
+                 minimum_matching_threshold: float = 0.8, frame_rate: int = 30):
+        self.lib = load_library()
+        h = C.c_void_p()
+        if self.lib.pa_bytetrack_create(track_activation_threshold, lost_track_buffer, minimum_matching_threshold,
+                                        int(frame_rate), C.byref(h)) != 0:
+            raise EngineError("pa_bytetrack_create failed")
+        self.handle = h
+
+    def reset(self) -> None:
+        self.lib.pa_bytetrack_reset(self.handle)
+
+    def update_batch(self, boxes: np.ndarray, counts: np.ndarray, keep: Optional[np.ndarray] = None) -> np.ndarray:
+        """boxes (n, stride, 6) fp32, counts (n,) int32, keep (n, stride) bool/uint8 | None -> ids (n, stride) int32."""
+        boxes = np.ascontiguousarray(boxes, np.float32)
+        counts = np.ascontiguousarray(counts, np.int32)
+        n, stride, six = boxes.shape
+        assert six == 6 and counts.shape == (n,)
+        kp = None
+        if keep is not None:
+            keep = np.ascontiguousarray(keep, np.uint8)
+            assert keep.shape == (n, stride)
+            kp = keep.ctypes.data
+        ids = np.empty((n, stride), np.int32)
+        if self.lib.pa_bytetrack_update_batch(self.handle, boxes.ctypes.data, counts.ctypes.data, kp, n, stride,
+                                              ids.ctypes.data) != 0:
+            raise EngineError("pa_bytetrack_update_batch failed")
+        return ids
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self.lib.pa_bytetrack_destroy(self.handle)
             self.handle = None
 
 
