@@ -94,10 +94,16 @@ class PolygonZone:
         self.current_count = 0
 
     def trigger(self, detections: Detections) -> np.ndarray:
-        if len(detections) == 0:
+        inside = self.trigger_boxes(detections.xyxy)
+        self.current_count = int(inside.sum())
+        return inside
+
+    def trigger_boxes(self, xyxy: np.ndarray) -> np.ndarray:
+        """``trigger`` on a bare (m, 4) box array (the tracker calls it once per batch of frames)."""
+        if len(xyxy) == 0:
             return np.zeros((0,), bool)
         w, h = self.frame_resolution_wh
-        b = detections.xyxy.copy()
+        b = np.array(xyxy, dtype=np.float32).reshape(-1, 4)
         b[:, [0, 2]] = b[:, [0, 2]].clip(0, w)
         b[:, [1, 3]] = b[:, [1, 3]].clip(0, h)
         if self.triggering_position == "bottom_center":
@@ -107,6 +113,4 @@ class PolygonZone:
         else:
             raise ValueError(self.triggering_position)
         ax, ay = np.ceil(ax).astype(int), np.ceil(ay).astype(int)
-        inside = self.mask[ay, ax].astype(bool)
-        self.current_count = int(inside.sum())
-        return inside
+        return self.mask[ay, ax].astype(bool)

@@ -17,6 +17,44 @@ def shard_range(n: int, rank: int, world: int) -> tuple:
     return start, start + base + (1 if rank < rem else 0)
 
 
+def rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def broadcast_array(arr: Optional[np.ndarray], shape: tuple, dtype, src: int = 0) -> np.ndarray:
+    """Small host array (the ball tracker's background median) from `src` to every rank."""
+    import torch
+    import torch.distributed as dist
+    if world_size() == 1:
+        assert arr is not None
+        return arr
+    if rank() == src:
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype).reshape(shape).copy())
+    else:
+        t = torch.empty(shape, dtype=torch.from_numpy(np.empty(0, dtype)).dtype)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
+def share_unique_id(make_id) -> bytes:
+    """RCCL bootstrap for ``Engine.comm_init``: rank 0 calls ``make_id()`` (``engine.comm_unique_id``), the 128
+    bytes reach the other ranks through the process group's store (TCP, out of band of the data path)."""
+    import torch.distributed as dist
+    if world_size() == 1:
+        return make_id()
+    box = [make_id() if rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
+
+
 def broadcast_blob(blob: Optional[np.ndarray], n_floats: int, src: int = 0, device=None) -> np.ndarray:
     """Broadcast the fp32 weight blob; ranks != src pass None.  `device`: torch device the collective runs on
     ("cuda:k" for RCCL, None/cpu for gloo)."""

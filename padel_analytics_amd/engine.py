@@ -407,6 +407,17 @@ class NativeByteTrack:
             raise EngineError("pa_bytetrack_update_batch failed")
         return ids
 
+    def update_with_detections(self, detections):
+        """Single-frame form with the signature of ``sv.ByteTrack.update_with_detections`` (players_tracker.py:367)."""
+        n = len(detections)
+        boxes = np.zeros((1, max(n, 1), 6), np.float32)
+        boxes[0, :n, :4] = detections.xyxy
+        boxes[0, :n, 4] = 1.0 if detections.confidence is None else detections.confidence
+        ids = self.update_batch(boxes, np.array([n], np.int32))[0, :n]
+        out = detections[np.nonzero(ids >= 0)[0]]
+        out.tracker_id = ids[ids >= 0].astype(int)
+        return out
+
     def __del__(self):
         if getattr(self, "handle", None):
             self.lib.pa_bytetrack_destroy(self.handle)
@@ -431,33 +442,45 @@ class BallSession:
         assert m.shape == (self.src_h, self.src_w, 3), m.shape
         self.model.engine._check(self.model.engine.lib.pa_ball_set_background(self.handle, m.ctypes.data))
 
-    def background_from_frames(self, frames_bgr: np.ndarray, want_median: bool = False):
-        """Median background of (n, h, w, 3) uint8 BGR frames on the device (np.median + uint8 truncation)."""
-        f = np.ascontiguousarray(frames_bgr, np.uint8)
-        n = len(f)
-        assert f.shape == (n, self.src_h, self.src_w, 3)
+    def background_from_frames(self, frames_bgr, want_median: bool = False, n: Optional[int] = None):
+        """Median background of (n, h, w, 3) uint8 BGR frames on the device (np.median + uint8 truncation).
+        ``frames_bgr``: ndarray, or a DeviceBuffer holding ``n`` frames."""
+        on_dev = isinstance(frames_bgr, DeviceBuffer)
+        if on_dev:
+            ptr = frames_bgr.ptr
+            assert n is not None and frames_bgr.nbytes >= n * self.src_h * self.src_w * 3
+        else:
+            f = np.ascontiguousarray(frames_bgr, np.uint8)
+            n = len(f)
+            assert f.shape == (n, self.src_h, self.src_w, 3)
+            ptr = f.ctypes.data
         med = np.empty((self.src_h, self.src_w, 3), np.uint8) if want_median else None
         self.model.engine._check(self.model.engine.lib.pa_ball_background_from_frames(
-            self.handle, f.ctypes.data, n, 0, med.ctypes.data if want_median else None))
+            self.handle, ptr, n, int(on_dev), med.ctypes.data if want_median else None))
         return med
 
-    def feed(self, frames_bgr: Optional[np.ndarray], flush: bool = False, want_heat: bool = False,
-             want_rects: bool = False, want_masks: bool = True):
-        """frames_bgr: (n, h, w, 3) uint8 with n <= max_feed (or None with flush=True).
-        Returns (masks (k,288,512) uint8 | None, heat (k,288,512) fp32 | None[, rects (k,4) int32]): outputs for
-        the next k frames in order; rects = predict_location of each mask computed on the device."""
-        n = 0 if frames_bgr is None else len(frames_bgr)
+    def feed(self, frames_bgr, flush: bool = False, want_heat: bool = False,
+             want_rects: bool = False, want_masks: bool = True, n: Optional[int] = None):
+        """frames_bgr: (n, h, w, 3) uint8 with n <= max_feed, a DeviceBuffer holding ``n`` such frames, or None with
+        flush=True.  Returns (masks (k,288,512) uint8 | None, heat (k,288,512) fp32 | None[, rects (k,4) int32]):
+        outputs for the next k frames in order; rects = predict_location of each mask computed on the device."""
+        on_dev = isinstance(frames_bgr, DeviceBuffer)
         ptr = None
-        if n:
-            frames_bgr = np.ascontiguousarray(frames_bgr, np.uint8)
-            assert frames_bgr.shape == (n, self.src_h, self.src_w, 3) and n <= self.max_feed
-            ptr = frames_bgr.ctypes.data
+        if on_dev:
+            assert n is not None and 0 < n <= self.max_feed and frames_bgr.nbytes >= n * self.src_h * self.src_w * 3
+            ptr = frames_bgr.ptr
+        else:
+            n = 0 if frames_bgr is None else len(frames_bgr)
+            if n:
+                frames_bgr = np.ascontiguousarray(frames_bgr, np.uint8)
+                assert frames_bgr.shape == (n, self.src_h, self.src_w, 3) and n <= self.max_feed
+                ptr = frames_bgr.ctypes.data
         masks = np.empty((n + 7, self.H, self.W), np.uint8) if (want_masks or not want_rects) else None
         heat = np.empty((n + 7, self.H, self.W), np.float32) if want_heat else None
         rects = np.empty((n + 7, 4), np.int32) if want_rects else None
         cnt = C.c_int(0)
         self.model.engine._check(self.model.engine.lib.pa_ball_feed(
-            self.handle, ptr, n, 0, int(flush), masks.ctypes.data if masks is not None else None,
+            self.handle, ptr, n, int(on_dev), int(flush), masks.ctypes.data if masks is not None else None,
             heat.ctypes.data if want_heat else None, rects.ctypes.data if want_rects else None, C.byref(cnt)))
         k = cnt.value
         out = (None if masks is None else masks[:k], heat[:k] if want_heat else None)

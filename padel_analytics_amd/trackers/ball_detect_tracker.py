@@ -1,0 +1,96 @@
+"""Ball tracker on a YOLOv8 detect model — SURVEY.md §8 row a16 (no reference counterpart: the reference's
+``BallTracker`` is TrackNetV3, ``ball_tracker.py:208-708``; BASELINE's configs name "players + ball YOLOv8 detect").
+
+Same plugin contract and the same result type as the reference's ball tracker: one ``Ball(frame, xy, visibility)``
+per frame (``ball_tracker.py:139-163``), ``__str__() == "ball_tracker"`` so it is a drop-in for ``BallTracker`` in
+``TrackingRunner``.  Per frame: the nc=1 detector's top-1 box after NMS (rows come back sorted by confidence, so
+``max_det=1`` is exactly the best surviving box); ``xy`` = box centre in source pixels, ``visibility`` = 1 iff the
+frame has a detection, otherwise ``xy = (0, 0)``, ``visibility = 0`` — the convention of the reference's
+``predict_modified`` ("visibility 0 iff both coordinates are 0", ``predict.py:149-221``).
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Iterable, Optional, Type
+
+import numpy as np
+
+from ..yolo import YOLO
+from .ball_tracker import Ball
+from .tracker import NoPredictFrames, Object, Tracker
+
+
+class BallDetectTracker(Tracker):
+    CONF = 0.25
+    IOU = 0.7
+    IMGSZ = 640
+    streams = False
+
+    def __init__(self, model_path: str, batch_size: int, conf: Optional[float] = None,
+                 load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None):
+        super().__init__(load_path=load_path, save_path=save_path)
+        self.model = YOLO(model_path)
+        if self.model.task != "detect":
+            raise ValueError(f"{model_path}: BallDetectTracker needs a YOLOv8 detect checkpoint")
+        self.batch_size = batch_size
+        if conf is not None:
+            self.CONF = float(conf)
+        self._next_frame = 0
+
+    def video_info_post_init(self, video_info) -> "BallDetectTracker": return self
+
+    def object(self) -> Type[Object]: return Ball
+
+    def draw_kwargs(self) -> dict: return {}
+
+    def __str__(self) -> str: return "ball_tracker"
+
+    def restart(self) -> None:
+        self.results.restart()
+        self._next_frame = 0
+
+    def to(self, device: str) -> None:
+        self.model.to(device)
+
+    def infer_sample(self, sample, **kwargs):
+        # players path convention: raw BGR frames reach the network in their own channel order (App. C #1)
+        boxes, _, counts, _, _, _ = self.model.infer_frames(sample, self.CONF, self.IOU, self.IMGSZ, classes=None,
+                                                            max_det=1, channel_reverse=False)
+        return boxes, counts
+
+    @staticmethod
+    def top1_to_xyv(boxes: np.ndarray, counts: np.ndarray) -> list:
+        """(n, >=1, 6) boxes + (n,) counts -> [(x, y, visibility)]: centre of the best box, (0, 0, 0) without one."""
+        out = []
+        for i in range(len(counts)):
+            if counts[i] > 0:
+                x1, y1, x2, y2 = (float(v) for v in boxes[i, 0, :4])
+                out.append(((x1 + x2) / 2, (y1 + y2) / 2, 1))
+            else:
+                out.append((0.0, 0.0, 0))
+        return out
+
+    def post_sample(self, raw, **kwargs) -> list:
+        preds = []
+        for x, y, v in self.top1_to_xyv(*raw):
+            preds.append(Ball(frame=self._next_frame, xy=(x, y), visibility=v))
+            self._next_frame += 1
+        return preds
+
+    def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> list:
+        return self.post_sample(self.infer_sample(sample, **kwargs), **kwargs)
+
+    def predict_frames(self, frame_generator, **kwargs):
+        raise NoPredictFrames()
+
+    # sharded: frame numbers are global, assigned on rank 0 after the gather
+    def predict_partial(self, frame_generator, *, first_frame: int = 0, head_context: int = 0, tail_context: int = 0,
+                        **kwargs) -> list:
+        from .tracker import _sampler
+        out = []
+        for sample in _sampler(frame_generator, self.batch_size):
+            out += self.top1_to_xyv(*self.infer_sample(sample))
+        return out
+
+    def merge_partials(self, partials: list, **kwargs) -> list:
+        return [Ball(frame=i, xy=(x, y), visibility=v) for i, (x, y, v) in enumerate(partials)]

@@ -24,7 +24,7 @@ from typing import Iterable, Optional, Type
 import numpy as np
 from scipy import ndimage
 
-from .. import checkpoint, engine as E, graph as G, inpaint
+from .. import checkpoint, engine as E, graph as G, inpaint, video
 from .tracker import NoPredictSample, Object, Tracker
 
 
@@ -65,6 +65,9 @@ class BallTracker(Tracker):
     TRAJECTORY_LENGTH = 8
     HEIGHT = 288
     WIDTH = 512
+    # a frame's ensembled heat map needs the 8 windows that contain it: 7 frames before and 7 after
+    temporal_context = (TRAJECTORY_LENGTH - 1, TRAJECTORY_LENGTH - 1)
+    streams = True
 
     def __init__(self, tracking_model_path: str, inpainting_model_path: Optional[str], batch_size: int,
                  median_max_sample_num: int = 1800, median: Optional[np.ndarray] = None,
@@ -117,28 +120,64 @@ class BallTracker(Tracker):
         raise NoPredictSample()
 
     def predict_frames(self, frame_generator: Iterable[np.ndarray], total_frames: int = None, **kwargs) -> list:
+        return self.merge_partials(self.predict_partial(frame_generator))
+
+    # ---- background (iterable.py:59-78): np.median of the first median_max_sample_num frames, on the device
+    def compute_median(self, frames) -> np.ndarray:
+        """(h, w, 3) uint8 RGB median of a list of BGR frames (host arrays or HBM-resident DeviceFrames).  In sharded
+        runs rank 0 computes it over the head of the clip and every rank receives it (``self.median``)."""
+        self.to("cuda")
+        h0, w0 = frames[0].shape[:2]
+        sess = E.BallSession(self._model, h0, w0)
+        try:
+            dev = video.device_batch(frames)
+            if dev is not None:
+                return sess.background_from_frames(dev[0], want_median=True, n=dev[1])
+            return sess.background_from_frames(np.stack(frames), want_median=True)
+        finally:
+            sess.close()
+
+    def predict_partial(self, frame_generator: Iterable[np.ndarray], *, first_frame: int = 0, head_context: int = 0,
+                        tail_context: int = 0, **kwargs) -> list:
+        """TrackNet stage over one contiguous range of the clip -> [(x, y, visibility)] per OWNED frame.
+
+        ``frame_generator`` yields ``head_context`` frames before the owned range and ``tail_context`` after it.  The
+        session treats what it is fed as a stream with its own head (plain means over the windows seen so far) and
+        tail; the outputs of the context frames are exactly the ones that differ from the unsharded stream, and
+        they are dropped: an owned frame with >= 7 frames fed before it gets the full weighted ensemble, and one
+        within 7 frames of the real start / end of the clip gets the reference's head / tail means because there
+        the context is empty (``head_context == 0`` / ``tail_context == 0``)."""
         self.to("cuda")
         it = iter(frame_generator)
         head = []
         median = self.median
         if median is None:                       # iterable.py:59-74 (RGB frames, np.median, uint8 truncation)
+            if first_frame != 0:
+                raise ValueError("a shard that does not start at frame 0 needs the clip's background median (set .median)")
             for f in it:
                 head.append(f)
                 if len(head) == self.median_max_sample_num:
                     break
             if not head:
                 return []
-        first = head[0] if head else next(it)
+        first = head[0] if head else next(it, None)
+        if first is None:
+            return []
         if not head:
             head = [first]
         h0, w0 = first.shape[:2]
+        self._last_hw = (h0, w0)
         w_scaler, h_scaler = w0 / self.WIDTH, h0 / self.HEIGHT
         sess = E.BallSession(self._model, h0, w0)
         if median is None:                       # K11: np.median(frames_rgb, 0).astype(uint8) on the device
-            sess.background_from_frames(np.stack(head))
+            dev = video.device_batch(head)
+            if dev is not None:
+                sess.background_from_frames(dev[0], n=dev[1])
+            else:
+                sess.background_from_frames(np.stack(head))
         else:
             sess.set_background(median)
-        xs, ys, vs = [], [], []
+        out = []
 
         def consume(res):
             masks, _, rects = res
@@ -147,30 +186,40 @@ class BallTracker(Tracker):
                     x, y, w, h = predict_location(masks[i])
                 cx, cy = int(x + w / 2), int(y + h / 2)
                 cx, cy = int(cx * w_scaler), int(cy * h_scaler)
-                xs.append(cx); ys.append(cy); vs.append(0 if (cx == 0 and cy == 0) else 1)
+                out.append((cx, cy, 0 if (cx == 0 and cy == 0) else 1))
 
         def chunks():
             buf = []
-            for f in head:
-                buf.append(f)
-                if len(buf) == sess.max_feed:
-                    yield buf
-                    buf = []
-            for f in it:
-                buf.append(f)
-                if len(buf) == sess.max_feed:
-                    yield buf
-                    buf = []
+            for src in (head, it):
+                for f in src:
+                    buf.append(f)
+                    if len(buf) == sess.max_feed:
+                        yield buf
+                        buf = []
             if buf:
                 yield buf
 
-        n_total = 0
+        n_fed = 0
         for c in chunks():
-            n_total += len(c)
-            consume(sess.feed(np.stack(c), want_rects=True))
+            n_fed += len(c)
+            dev = video.device_batch(c)
+            if dev is not None:
+                consume(sess.feed(dev[0], want_rects=True, n=dev[1]))
+            else:
+                consume(sess.feed(np.stack(c), want_rects=True))
         consume(sess.feed(None, flush=True, want_rects=True))
         sess.close()
-        if self.inpaintnet is not None and len(xs) == n_total:
+        if len(out) < n_fed:                       # fewer than 8 frames fed: no window, no detection (reference :688-696)
+            out += [None] * (n_fed - len(out))
+        return out[head_context:n_fed - tail_context]
+
+    def merge_partials(self, partials: list, **kwargs) -> list:
+        """InpaintNet trajectory repair over the WHOLE clip (:525-673) + ``Ball`` objects with global frame numbers."""
+        n_total = len(partials)
+        have = [p for p in partials if p is not None]
+        xs, ys, vs = [p[0] for p in have], [p[1] for p in have], [p[2] for p in have]
+        if self.inpaintnet is not None and len(xs) == n_total and n_total:
+            h0, w0 = self._frame_hw()
             fixed = inpaint.inpaint_trajectory(xs, ys, vs, w0, h0, self.inpaintnet, self.inpaintnet_seq_len,
                                                self.WIDTH, self.HEIGHT)
             if fixed and fixed[0] is not None:
@@ -185,3 +234,10 @@ class BallTracker(Tracker):
                 print(f"{self}: missing detection frame {i}")
                 out.append(Ball(frame=i, xy=(0.0, 0.0), visibility=0))
         return out
+
+    def _frame_hw(self) -> tuple:
+        if getattr(self, "_last_hw", None):
+            return self._last_hw
+        if self.video_info is None:
+            raise ValueError("BallTracker with an InpaintNet needs video_info_post_init() (frame size normalises the coordinates)")
+        return self.video_info.height, self.video_info.width

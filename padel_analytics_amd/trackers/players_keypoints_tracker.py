@@ -67,9 +67,28 @@ class PlayerKeypoints:
 
 
 class PlayersKeypoints(Object):
-    def __init__(self, players_keypoints: list) -> None:
+    """All players' keypoints of one frame (reference :165-197).  Built from ``PlayerKeypoints`` objects (reference
+    signature) or from the tracker's (n, K, 2) array of frame-pixel coordinates, in which case the per-keypoint
+    objects are created on first access."""
+
+    def __init__(self, players_keypoints: Optional[list] = None, *, xy: Optional[np.ndarray] = None,
+                 ratio: tuple = (1.0, 1.0)) -> None:
         super().__init__()
-        self.players_keypoints = players_keypoints
+        self._items = players_keypoints
+        self._xy, self._ratio = xy, ratio
+        if players_keypoints is None and xy is None:
+            self._items = []
+
+    @property
+    def players_keypoints(self) -> list:
+        if self._items is None:
+            names = PlayerKeypoints.KEYPOINTS_NAMES
+            rx, ry = self._ratio
+            # reference :303-316: keypoint[0].item() * ratio_x — the float32 value widened to a Python float first
+            self._items = [PlayerKeypoints([
+                PlayerKeypoint(id=i, name=names[i] if i < len(names) else str(i), xy=(float(kp[0]) * rx, float(kp[1]) * ry))
+                for i, kp in enumerate(person)]) for person in self._xy]
+        return self._items
 
     @classmethod
     def from_json(cls, x) -> "PlayersKeypoints":
@@ -78,7 +97,7 @@ class PlayersKeypoints(Object):
     def serialize(self) -> list:
         return [p.serialize() for p in self.players_keypoints]
 
-    def __len__(self) -> int: return len(self.players_keypoints)
+    def __len__(self) -> int: return len(self._xy) if self._items is None else len(self._items)
 
     def __iter__(self): return iter(self.players_keypoints)
 
@@ -88,6 +107,7 @@ class PlayersKeypoints(Object):
 class PlayerKeypointsTracker(Tracker):
     CONF = 0.25
     IOU = 0.7
+    streams = False
 
     def __init__(self, model_path: str, train_image_size: int, batch_size: int,
                  load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None):
@@ -116,24 +136,28 @@ class PlayerKeypointsTracker(Tracker):
     def to(self, device: str) -> None:
         self.model.to(device)
 
-    def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> list:
-        sample = list(sample)
+    def infer_sample(self, sample, **kwargs):
+        sample = sample if isinstance(sample, (list, np.ndarray)) else list(sample)
         h_frame, w_frame = sample[0].shape[:2]
-        ratio_x = w_frame / self.train_image_size
-        ratio_y = h_frame / self.train_image_size
-        results = self.model.predict_frames(sample, self.CONF, self.IOU, self.train_image_size, classes=[0],
-                                            channel_reverse=True, pil_stretch=True)
-        names = PlayerKeypoints.KEYPOINTS_NAMES
+        _, kpts, counts, _, _, _ = self.model.infer_frames(sample, self.CONF, self.IOU, self.train_image_size, classes=[0],
+                                                          channel_reverse=True, pil_stretch=True)
+        return kpts, counts, (h_frame, w_frame)
+
+    def post_sample(self, raw, **kwargs) -> list:
+        kpts, counts, (h_frame, w_frame) = raw
+        ratio = (w_frame / self.train_image_size, h_frame / self.train_image_size)     # reference :276-278
+        K, ndim = self.model.kpt_shape
         predictions = []
-        for result in results:
-            players = []
-            for person in result.keypoints.xy:                 # (K, 2)
-                players.append(PlayerKeypoints([
-                    PlayerKeypoint(id=i, name=names[i] if i < len(names) else str(i),
-                                   xy=(float(kp[0]) * ratio_x, float(kp[1]) * ratio_y))
-                    for i, kp in enumerate(person)]))
-            predictions.append(PlayersKeypoints(players))
+        for i in range(len(counts)):
+            k = kpts[i, :counts[i]].reshape(counts[i], K, ndim)
+            xy = k[..., :2].copy()
+            if ndim == 3:
+                xy[k[..., 2] < 0.5] = 0          # [upstream] Keypoints.xy zeroes points predicted invisible
+            predictions.append(PlayersKeypoints(xy=xy, ratio=ratio))
         return predictions
+
+    def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> list:
+        return self.post_sample(self.infer_sample(sample, **kwargs), **kwargs)
 
     def predict_frames(self, frame_generator, **kwargs):
         raise NoPredictFrames()

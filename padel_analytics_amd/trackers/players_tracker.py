@@ -6,6 +6,11 @@ Hot path (``predict_sample`` :341-380): a batch of BGR frames -> YOLOv8 detect (
 box rescale run in the HIP engine; the reference's host ``processor`` (BGR2RGB, :335-336) followed by
 upstream's own channel flip is the identity on channel order, so raw frames go to the device with
 ``channel_reverse=False``.  Drawing is out of scope.
+
+Host side: the polygon-zone test runs once per batch on the flattened box array, ByteTrack is the host-native
+``pa_bytetrack_*`` (one call per batch of frames), and ``Players`` materialises its ``Player`` objects on first
+access — a 64-frame batch carries thousands of boxes on the synthetic bench weights and must not cost more host
+time than its ~25 ms of GPU time.
 """
 from __future__ import annotations
 
@@ -62,18 +67,40 @@ class Player:
 
 
 class Players(Object):
-    def __init__(self, players: list):
+    """List of ``Player`` (reference :199-231).  Built either from ``Player`` objects (reference signature) or from
+    the tracker's arrays (``rows`` (k, 6) x1,y1,x2,y2,conf,cls + ``ids`` (k,)), in which case the ``Player``
+    objects are created on first access."""
+
+    def __init__(self, players: Optional[list] = None, *, rows: Optional[np.ndarray] = None,
+                 ids: Optional[np.ndarray] = None):
         super().__init__()
-        self.players = players
+        self._players = players
+        self._rows, self._ids = rows, ids
+        if players is None and rows is None:
+            self._players = []
+
+    @property
+    def players(self) -> list:
+        if self._players is None:
+            r, t = self._rows, self._ids
+            self._players = [
+                Player(Detections(xyxy=r[i:i + 1, :4], confidence=r[i:i + 1, 4], class_id=r[i:i + 1, 5].astype(int),
+                                  tracker_id=None if t is None else t[i:i + 1]))
+                for i in range(len(r))]
+        return self._players
 
     @classmethod
     def from_json(cls, x: list) -> "Players":
         return cls([Player.from_json(p) for p in x])
 
     def serialize(self) -> list:
-        return [p.serialize() for p in self.players]
+        if self._players is None:                  # straight from the arrays (same values as Player.serialize)
+            r, t = self._rows, self._ids
+            return [{"id": (int(t[i]) if (t is not None and t[i] != 0) else None), "xyxy": [float(v) for v in r[i, :4]],
+                     "projection": None, "class_id": int(r[i, 5]), "confidence": float(r[i, 4])} for i in range(len(r))]
+        return [p.serialize() for p in self._players]
 
-    def __len__(self) -> int: return len(self.players)
+    def __len__(self) -> int: return len(self._rows) if self._players is None else len(self._players)
 
     def __iter__(self): return iter(self.players)
 
@@ -84,6 +111,7 @@ class PlayerTracker(Tracker):
     CONF = 0.5
     IOU = 0.7
     IMGSZ = 640
+    streams = False
 
     def __init__(self, model_path: str, polygon_zone, batch_size: int, annotator: str = "rectangle_bounding_box",
                  show_confidence: bool = True, load_path: Optional[str | Path] = None,
@@ -98,9 +126,9 @@ class PlayerTracker(Tracker):
         self.byte_track = None
 
     def video_info_post_init(self, video_info) -> "PlayerTracker":
-        from ..bytetrack import ByteTrack
+        from ..engine import NativeByteTrack
         self.video_info = video_info
-        self.byte_track = ByteTrack(frame_rate=video_info.fps)
+        self.byte_track = NativeByteTrack(frame_rate=video_info.fps)     # reference :311
         return self
 
     def object(self) -> Type[Object]: return Players
@@ -124,17 +152,69 @@ class PlayerTracker(Tracker):
     def to(self, device: str) -> None:
         self.model.to(device)
 
+    # ---- device stage: detector over one batch of raw BGR frames (host arrays or HBM-resident DeviceFrames)
+    def infer_sample(self, sample, **kwargs):
+        boxes, _, counts, _, _, _ = self.model.infer_frames(sample, self.CONF, self.IOU, self.IMGSZ, classes=[0],
+                                                            channel_reverse=False)
+        return boxes, counts
+
+    # ---- host stage, split in the stateless part (zone) and the sequential part (ByteTrack)
+    def _zone_keep(self, boxes: np.ndarray, counts: np.ndarray) -> np.ndarray:
+        """(n, max_det) bool: rows that exist and (with a zone) whose bottom-centre anchor lies inside it
+        (reference :364-365, once per batch instead of once per frame)."""
+        valid = np.arange(boxes.shape[1])[None, :] < counts[:, None]
+        if self.polygon_zone is None:
+            return valid
+        keep = np.zeros_like(valid)
+        keep[valid] = self.polygon_zone.trigger_boxes(boxes[valid][:, :4])
+        return keep
+
+    def _track(self, boxes: np.ndarray, counts: np.ndarray, keep: Optional[np.ndarray]) -> list:
+        """Frame-sequential ids (reference :367-369) + result objects (:371-378) for a batch of frames."""
+        n = len(counts)
+        valid = np.arange(boxes.shape[1])[None, :] < counts[:, None]
+        sel = valid if keep is None else (valid & keep.astype(bool))
+        if self.byte_track is not None:
+            ids = self.byte_track.update_batch(boxes, counts, None if keep is None else keep)
+            sel = sel & (ids >= 0)
+        else:
+            ids = None
+        out = []
+        for i in range(n):
+            idx = np.nonzero(sel[i])[0]
+            out.append(Players(rows=boxes[i, idx], ids=None if ids is None else ids[i, idx].astype(int)))
+        return out
+
+    def post_sample(self, raw, **kwargs) -> list:
+        boxes, counts = raw
+        return self._track(boxes, counts, self._zone_keep(boxes, counts))
+
     def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> list:
-        results = self.model.predict_frames(sample, self.CONF, self.IOU, self.IMGSZ, classes=[0], channel_reverse=False)
-        predictions = []
-        for result in results:            # sequential in frame order: ByteTrack is stateful
-            det = Detections.from_ultralytics(result)
-            if self.polygon_zone is not None:
-                det = det[self.polygon_zone.trigger(det)]
-            if self.byte_track is not None:
-                det = self.byte_track.update_with_detections(detections=det)
-            predictions.append(Players([Player(detection=det[i]) for i in range(len(det))]))
-        return predictions
+        return self.post_sample(self.infer_sample(sample, **kwargs), **kwargs)
+
+    # ---- sharded: per-frame kept rows travel to rank 0, ByteTrack runs there in global frame order
+    def predict_partial(self, frame_generator, *, first_frame: int = 0, head_context: int = 0, tail_context: int = 0,
+                        **kwargs) -> list:
+        assert head_context == 0 and tail_context == 0
+        from .tracker import _sampler
+        out = []
+        for sample in _sampler(frame_generator, self.batch_size):
+            boxes, counts = self.infer_sample(sample)
+            keep = self._zone_keep(boxes, counts)
+            out += [boxes[i, keep[i]] for i in range(len(counts))]
+        return out
+
+    def merge_partials(self, partials: list, **kwargs) -> list:
+        out = []
+        for lo in range(0, len(partials), max(1, self.batch_size)):
+            part = partials[lo:lo + max(1, self.batch_size)]
+            stride = max(1, max(len(r) for r in part))
+            boxes = np.zeros((len(part), stride, 6), np.float32)
+            counts = np.array([len(r) for r in part], np.int32)
+            for i, r in enumerate(part):
+                boxes[i, :len(r)] = r
+            out += self._track(boxes, counts, None)
+        return out
 
     def predict_frames(self, frame_generator, **kwargs):
         raise NoPredictFrames()

@@ -3,21 +3,38 @@
 moved to the device, timed with ``timeit`` exactly where the reference times it (:222-228), moved back,
 and its predictions are cached as JSON; a tracker with cached predictions is skipped (:187-191).
 
-Additions: ``run()`` also records ``self.timings`` (seconds / frames per tracker) and prints frames/s.
+Additions (all off by default, the reference's sequential semantics stay the default):
+
+* ``run()`` records ``self.timings`` (seconds / frames per tracker) and prints frames/s;
+* ``distributed=True``: one process per GPU under ``torch.distributed``; every tracker's frames
+  are split into contiguous shards ``dist.shard_range`` (plus the tracker's ``temporal_context`` — TrackNet's 7-frame
+  halo), each rank runs the stateless part on its shard (``Tracker.predict_partial``), the per-frame partials are
+  gathered to rank 0 in frame order and the sequential part (ByteTrack ids, InpaintNet) runs there
+  (``Tracker.merge_partials``).  The ball tracker's background median is computed once on rank 0 and broadcast.
+  Results and JSON caches live on rank 0;
+* ``fanout=True``: ONE pass over the video feeds every tracker — each batch of frames is
+  uploaded to HBM once (the next batch uploads on the engine's copy stream while this one computes) and all
+  batch trackers consume the same device-resident frames; stream trackers (TrackNet) get the same handles.  The
+  reference decodes and uploads the clip once per tracker (:215-220).
+
 ``draw_and_collect_data`` (video encode, homography, analytics: SURVEY.md §1 L3') is out of scope."""
 from __future__ import annotations
 
+import threading
 import timeit
 from pathlib import Path
 from typing import Optional
 
-from .. import video
-from .tracker import Tracker
+import numpy as np
+
+from .. import dist as D, video
+from .tracker import NoPredictFrames, Tracker, _sampler
 
 
 class TrackingRunner:
     def __init__(self, trackers: list, video_path: str | Path, inference_path: str | Path, start: int = 0,
-                 end: Optional[int] = None, collect_data: bool = False) -> None:
+                 end: Optional[int] = None, collect_data: bool = False, *, distributed: bool = False,
+                 fanout: bool = False, engine=None) -> None:
         self.video_path = video_path
         self.inference_path = inference_path
         self.start = start
@@ -31,6 +48,9 @@ class TrackingRunner:
         self.collect_data = collect_data
         self.data_analytics = None
         self.timings: dict = {}
+        self.distributed = distributed
+        self.fanout = fanout
+        self.engine = engine
 
     def restart(self) -> None:
         for tracker in self.trackers.values():
@@ -39,24 +59,163 @@ class TrackingRunner:
     def draw_and_collect_data(self) -> None:
         print("runner: drawing / data collection is outside the hot path of this build (skipped)")
 
+    def _frames(self, lo: int = 0, hi: Optional[int] = None):
+        """Frames [start + lo, start + hi) of the clip (hi None: to self.end)."""
+        end = self.end if hi is None else self.start + hi
+        return video.get_video_frames_generator(self.video_path, start=self.start + lo, stride=self.stride, end=end)
+
     def run(self) -> None:
         print(f"runner: Running {self.total_frames} frames")
-        for tracker in self.trackers.values():
-            if len(tracker) != 0:
-                print(f"{tracker.__str__()}: {len(tracker)} predictions stored")
-                continue
-            tracker.to(tracker.DEVICE)
-            print(f"{str(tracker)}: Running on {tracker.DEVICE} ...")
-            frame_generator = video.get_video_frames_generator(self.video_path, start=self.start, stride=self.stride,
-                                                               end=self.end)
-            t0 = timeit.default_timer()
-            tracker.predict_and_update(frame_generator, total_frames=self.total_frames)
-            t1 = timeit.default_timer()
-            tracker.to("cpu")
-            print(f"{str(tracker)}: {t1 - t0} inference time.")
-            n = len(tracker)
-            self.timings[str(tracker)] = {"seconds": t1 - t0, "frames": n}
-            if t1 > t0:
-                print(f"{str(tracker)}: {n / (t1 - t0):.1f} frames/s")
-            tracker.save_predictions()
+        if self.fanout:
+            self._run_fanout()
+        else:
+            for tracker in self.trackers.values():
+                if len(tracker) != 0:
+                    print(f"{tracker.__str__()}: {len(tracker)} predictions stored")
+                    continue
+                tracker.to(tracker.DEVICE)
+                print(f"{str(tracker)}: Running on {tracker.DEVICE} ...")
+                t0 = timeit.default_timer()
+                if self.distributed:
+                    self._predict_sharded(tracker)
+                else:
+                    tracker.predict_and_update(self._frames(), total_frames=self.total_frames)
+                t1 = timeit.default_timer()
+                tracker.to("cpu")
+                self._report(tracker, t0, t1)
+                if not self.distributed or D.rank() == 0:
+                    tracker.save_predictions()
         self.draw_and_collect_data()
+
+    def _report(self, tracker, t0, t1) -> None:
+        print(f"{str(tracker)}: {t1 - t0} inference time.")
+        n = len(tracker)
+        self.timings[str(tracker)] = {"seconds": t1 - t0, "frames": n}
+        if t1 > t0:
+            print(f"{str(tracker)}: {n / (t1 - t0):.1f} frames/s")
+
+    # ------------------------------------------------------------------ sharded over GPUs
+    def _predict_sharded(self, tracker: Tracker) -> None:
+        rank, world = D.rank(), D.world_size()
+        n = self.total_frames
+        lo, hi = D.shard_range(n, rank, world)
+        ch, ct = tracker.temporal_context
+        head, tail = min(ch, lo), min(ct, n - hi)
+        if ch or ct:
+            self._share_background(tracker)
+        partial = tracker.predict_partial(self._frames(lo - head, hi + tail), first_frame=lo, head_context=head,
+                                          tail_context=tail, total_frames=hi - lo) if hi > lo else []
+        assert len(partial) == hi - lo, (str(tracker), len(partial), lo, hi)
+        allp = D.gather_results(partial, dst=0)
+        if rank == 0:
+            tracker.results.predictions = tracker.merge_partials(allp)
+            print(f"{tracker.__str__()}: {len(tracker.results)} predictions.")
+
+    def _share_background(self, tracker) -> None:
+        """TrackNet's background median (iterable.py:59-81) is a property of the clip's first frames: rank 0
+        computes it (on its GPU), every rank receives the (h, w, 3) uint8 array."""
+        if getattr(tracker, "median", None) is not None or not hasattr(tracker, "compute_median"):
+            return
+        med = None
+        if D.rank() == 0:
+            nmed = min(tracker.median_max_sample_num, self.total_frames)
+            med = tracker.compute_median(list(self._frames(0, nmed)))
+        tracker.median = D.broadcast_array(med, (self.video_info.height, self.video_info.width, 3), np.uint8, src=0)
+
+    # ------------------------------------------------------------------ one decode / one upload for all trackers
+    def _run_fanout(self) -> None:
+        todo = [t for t in self.trackers.values() if len(t) == 0]
+        for t in self.trackers.values():
+            if len(t) != 0:
+                print(f"{t.__str__()}: {len(t)} predictions stored")
+        if not todo:
+            return
+        batch = [t for t in todo if self._is_batch_tracker(t)]
+        stream = [t for t in todo if t not in batch]
+        bs = max([t.batch_size for t in batch] or [max(t.batch_size for t in stream)])
+        for t in todo:
+            t.to(t.DEVICE)
+            print(f"{str(t)}: Running on {t.DEVICE} (fan-out, {bs} frames per upload) ...")
+        t0 = timeit.default_timer()
+        from concurrent.futures import ThreadPoolExecutor
+
+        def batches():
+            """Batches of frames resident in HBM: device clips pass through; host frames are uploaded once per
+            batch into one of two staging clips, the next upload overlapping this batch's compute."""
+            gen = self._frames()
+            first = next(gen, None)
+            if first is None:
+                return
+            if isinstance(first, video.DeviceFrame):
+                def chain():
+                    yield first
+                    yield from gen
+                yield from _sampler(chain(), bs)
+                return
+            from .. import engine as E
+            eng = self.engine or E.default_engine()
+            h, w = first.shape[:2]
+            clips = [video.DeviceClip(eng, shape=(bs, h, w, 3)) for _ in range(2)]
+
+            def chain():
+                yield first
+                yield from gen
+
+            def stage(k, frames):
+                c = clips[k % len(clips)]
+                c.upload(np.stack(frames), copy_stream=True)
+                return [video.DeviceFrame(c, i) for i in range(len(frames))]
+
+            with ThreadPoolExecutor(max_workers=1) as up:
+                fut, k = None, 0
+                for frames in _sampler(chain(), bs):
+                    nxt = up.submit(stage, k, frames)
+                    k += 1
+                    if fut is not None:
+                        yield fut.result()
+                    fut = nxt
+                if fut is not None:
+                    yield fut.result()
+            for c in clips:
+                c.free()
+
+        with ThreadPoolExecutor(max_workers=1) as post:
+            pending = []
+            for sample in batches():
+                for t in batch:
+                    for sub in _sampler(iter(sample), t.batch_size):
+                        if t._has_stages():
+                            raw = t.infer_sample(sub)
+                            pending.append((t, post.submit(t.post_sample, raw)))
+                        else:
+                            t.results.update(t.predict_sample(sub))
+                while len(pending) > len(batch):           # host stages trail the device stages by one batch
+                    t, f = pending.pop(0)
+                    t.results.update(f.result())
+            for t, f in pending:
+                t.results.update(f.result())
+        # stream trackers (TrackNet needs the clip's background median before its first window): their own pass —
+        # over the same HBM-resident handles when the clip lives in HBM, else a second read of the source
+        for t in stream:
+            t.predict_and_update(self._frames(), total_frames=self.total_frames)
+        t1 = timeit.default_timer()
+        for t in todo:
+            t.to("cpu")
+            print(f"{t.__str__()}: {len(t.results)} predictions.")
+            self.timings[str(t)] = {"seconds": (t1 - t0) / len(todo), "frames": len(t)}
+            t.save_predictions()
+        self.timings["__fanout__"] = {"seconds": t1 - t0, "frames": self.total_frames}
+        print(f"runner: fan-out pass {t1 - t0} inference time, {self.total_frames / max(t1 - t0, 1e-9):.1f} frames/s (all trackers)")
+
+    @staticmethod
+    def _is_batch_tracker(t: Tracker) -> bool:
+        """Batch trackers answer predict_frames with NoPredictFrames (reference tracker.py:315-326)."""
+        if getattr(t, "streams", None) is not None:
+            return not t.streams
+        try:
+            t.predict_frames(iter(()))
+        except NoPredictFrames:
+            return True
+        except Exception:
+            return False
+        return False

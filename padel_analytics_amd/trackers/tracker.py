@@ -9,12 +9,22 @@ and error conventions, so ``TrackingRunner`` and user code keep working unchange
 * a tracker that works on the whole stream raises ``NoPredictSample`` from ``predict_sample``;
 * predictions are cached as JSON through ``save_predictions`` / ``load_predictions`` (:200-241).
 
+Additions that do not change what a caller sees:
+
+* a tracker may split ``predict_sample`` into ``infer_sample`` (device stage, returns raw arrays) and
+  ``post_sample`` (host stage, builds the objects); ``predict_and_update`` then runs the host stage of batch k
+  on a worker thread while the device stage of batch k+1 is in flight (ctypes releases the GIL);
+* ``predict_partial`` / ``merge_partials`` are the two halves of a prediction when the clip is sharded over GPUs
+  (``TrackingRunner(distributed=True)``): the stateless per-frame part runs on the rank that owns the frames, the
+  sequential part (ByteTrack ids, InpaintNet trajectory repair) on rank 0 after the gather.
+
 Written from scratch; host logic only (the numeric engines live behind ``padel_analytics_amd.engine``).
 """
 from __future__ import annotations
 
 import json
 from abc import ABC, abstractmethod
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from pathlib import Path
 from typing import Iterable, Iterator, Optional, Type
@@ -90,6 +100,10 @@ def _sampler(generator: Iterable[np.ndarray], sequence_length: int) -> Iterator[
 
 class Tracker(ABC):
     batch_size: int
+    #: frames of temporal context a shard needs before / after its own frames (TrackNet windows: 7 / 7)
+    temporal_context: tuple = (0, 0)
+    #: True for trackers that consume the whole stream in predict_frames (TrackNet), False for batch trackers
+    streams: Optional[bool] = None
 
     def __init__(self, load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None) -> None:
         self.results = TrackingResults()
@@ -150,12 +164,56 @@ class Tracker(ABC):
     @abstractmethod
     def predict_frames(self, frame_generator: Iterable[np.ndarray], **kwargs) -> Optional[list]: ...
 
+    # ---- optional two-stage form of predict_sample (device stage / host stage)
+    def infer_sample(self, sample: list, **kwargs):
+        raise NotImplementedError
+
+    def post_sample(self, raw, **kwargs) -> list:
+        raise NotImplementedError
+
+    def _has_stages(self) -> bool:
+        return type(self).infer_sample is not Tracker.infer_sample and type(self).post_sample is not Tracker.post_sample
+
+    def _predict_batches(self, frame_generator, update, **kwargs) -> None:
+        """Batch loop of reference tracker.py:319-326.  With the two-stage form, post_sample(batch k) runs on one
+        worker thread (in batch order) while infer_sample(batch k+1) occupies the GPU."""
+        if not self._has_stages():
+            for sample in _sampler(frame_generator, self.batch_size):
+                update(self.predict_sample(sample, **kwargs))
+            return
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            pending = []
+            for sample in _sampler(frame_generator, self.batch_size):
+                raw = self.infer_sample(sample, **kwargs)
+                pending.append(pool.submit(self.post_sample, raw, **kwargs))
+                while len(pending) > 1:                 # keep one host stage in flight behind the device stage
+                    update(pending.pop(0).result())
+            for f in pending:
+                update(f.result())
+
     def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:
         try:
             predictions = self.predict_frames(frame_generator, **kwargs)
             self.results.predictions = predictions
         except NoPredictFrames:
-            for sample in _sampler(frame_generator, self.batch_size):
-                self.results.update(self.predict_sample(sample, **kwargs))
+            self._predict_batches(frame_generator, self.results.update, **kwargs)
         print(f"{self.__str__()}: {len(self.results)} predictions.")
         return self.results
+
+    # ---- sharded prediction (SURVEY.md §8(e)): frames [first, first + n) of the clip live on this rank
+    def predict_partial(self, frame_generator: Iterable[np.ndarray], *, first_frame: int = 0, head_context: int = 0,
+                        tail_context: int = 0, **kwargs) -> list:
+        """Stateless part of the prediction for one contiguous shard.  ``frame_generator`` yields the shard's
+        frames preceded by ``head_context`` and followed by ``tail_context`` frames of temporal context (zero for
+        per-frame trackers).  Returns one picklable item per OWNED frame, in frame order."""
+        assert head_context == 0 and tail_context == 0, "per-frame trackers need no temporal context"
+        out: list = []
+        try:
+            out = self.predict_frames(frame_generator, **kwargs)
+        except NoPredictFrames:
+            self._predict_batches(frame_generator, out.extend, **kwargs)
+        return out
+
+    def merge_partials(self, partials: list, **kwargs) -> list:
+        """Sequential part, on rank 0, over the partials of ALL frames in global frame order -> final objects."""
+        return partials

@@ -3,7 +3,9 @@
 Neither is available here or on the GPU box, and the checkout ships no video, so this module provides the
 same two calls over (a) ``.npy`` frame stacks (N,H,W,3 uint8 BGR, memory-mapped), (b) seeded synthetic
 clips ``synthetic://?n=64&h=720&w=1280&fps=30&seed=0`` and (c) real video files when ``cv2`` happens to be
-importable.  Frames are HWC uint8 **BGR**, exactly what supervision yields."""
+importable, (d) ``DeviceClip`` objects: a clip already resident in HBM (the bench's device-resident mode; the
+runner's fan-out mode uploads each batch once and hands the same ``DeviceFrame`` handles to every tracker).
+Frames are HWC uint8 **BGR**, exactly what supervision yields."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -26,6 +28,8 @@ class VideoInfo:
 
     @classmethod
     def from_video_path(cls, video_path) -> "VideoInfo":
+        if isinstance(video_path, DeviceClip):
+            return cls(video_path.w, video_path.h, video_path.fps, video_path.total_frames)
         p = str(video_path)
         if p.startswith("synthetic://"):
             q = _query(p)
@@ -58,7 +62,71 @@ def _cv2():
                            "stack or a synthetic:// source") from e
 
 
+class DeviceFrame:
+    """Handle of one HWC uint8 BGR frame that lives in HBM (frame ``index`` of ``clip.buffer``).  Quacks like the
+    ndarray the trackers expect as far as they look at it on the host (``.shape``)."""
+    __slots__ = ("clip", "index")
+
+    def __init__(self, clip: "DeviceClip", index: int):
+        self.clip, self.index = clip, index
+
+    @property
+    def shape(self) -> tuple:
+        return (self.clip.h, self.clip.w, 3)
+
+
+class DeviceClip:
+    """``n`` frames resident in HBM, presented as a clip of ``n * repeat`` frames (frame i = stored frame i % n)."""
+
+    def __init__(self, engine, frames: Optional[np.ndarray] = None, *, shape: Optional[tuple] = None, repeat: int = 1,
+                 fps: int = 30):
+        if frames is not None:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            shape = frames.shape
+        self.n, self.h, self.w = int(shape[0]), int(shape[1]), int(shape[2])
+        self.repeat, self.fps = int(repeat), int(fps)
+        self.frame_bytes = self.h * self.w * 3
+        self.buffer = engine.alloc(self.n * self.frame_bytes)
+        if frames is not None:
+            self.buffer.upload(frames)
+
+    @property
+    def total_frames(self) -> int:
+        return self.n * self.repeat
+
+    def upload(self, frames: np.ndarray, first: int = 0, copy_stream: bool = True) -> None:
+        """Overwrite stored frames [first, first + len(frames)) (prefetch thread of the runner's fan-out mode)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        assert frames.shape[1:] == (self.h, self.w, 3) and first + len(frames) <= self.n
+        self.buffer.view(first * self.frame_bytes, frames.nbytes).upload(frames, copy_stream=copy_stream)
+
+    def frames(self, start: int = 0, end: Optional[int] = None, stride: int = 1) -> Iterator[DeviceFrame]:
+        stop = self.total_frames if end is None else min(end, self.total_frames)
+        for i in range(start, stop, stride):
+            yield DeviceFrame(self, i % self.n)
+
+    def free(self) -> None:
+        self.buffer.free()
+
+
+def device_batch(sample):
+    """If ``sample`` is a list of DeviceFrame handles of ONE clip with consecutive stored indices, return
+    (DeviceBuffer view over exactly those frames, n, h, w); None for host frames.  Anything else is an error: a
+    device batch must be one contiguous range (batch sizes that divide the stored clip length always are)."""
+    if isinstance(sample, np.ndarray) or not len(sample) or not isinstance(sample[0], DeviceFrame):
+        return None
+    clip, i0 = sample[0].clip, sample[0].index
+    for k, f in enumerate(sample):
+        if not isinstance(f, DeviceFrame) or f.clip is not clip or f.index != i0 + k:
+            raise ValueError("a batch of device-resident frames must be a contiguous range of one DeviceClip")
+    n = len(sample)
+    return clip.buffer.view(i0 * clip.frame_bytes, n * clip.frame_bytes), n, clip.h, clip.w
+
+
 def get_video_frames_generator(source_path, stride: int = 1, start: int = 0, end: Optional[int] = None) -> Iterator[np.ndarray]:
+    if isinstance(source_path, DeviceClip):
+        yield from source_path.frames(start, end, stride)
+        return
     p = str(source_path)
     if p.startswith("synthetic://"):
         from . import synth

@@ -83,9 +83,10 @@ class YOLO:
         if dev.startswith("cuda") or dev.isdigit():
             self._ensure_model()
         elif dev == "cpu":
-            if self._model is not None:       # runner.py:230 parks models on the host after a tracker ran
-                self._model.close()
-                self._model = None
+            # runner.py:230 parks each tracker's model on the host after it ran (the reference targets 8 GB cards,
+            # README.md:38-39).  With 288 GB of HBM the weights and the activation plan simply stay resident:
+            # re-planning per run would cost more than the parking saves.  close() releases them.
+            pass
         else:
             raise ValueError(f"unknown device {device!r}")
         return self
@@ -96,6 +97,11 @@ class YOLO:
             self._model = E.Model(eng, self.graph)
             self._model.set_max_batch(self.max_batch)
         return self._model
+
+    def close(self) -> None:
+        if self._model is not None:
+            self._model.close()
+            self._model = None
 
     def set_max_batch(self, n: int):
         self.max_batch = int(n)
@@ -116,16 +122,35 @@ class YOLO:
         ``processor`` (BGR2RGB, PIL resize) is folded into the device preprocessing:
         ``channel_reverse`` = network channel c reads frame channel 2-c; ``pil_stretch`` = Pillow
         bicubic resize to imgsz x imgsz first (players_keypoints_tracker.py:260-266)."""
-        frames = frames if isinstance(frames, (np.ndarray, E.DeviceBuffer)) else np.stack(list(frames))
-        return self._run(frames, conf, iou, imgsz, classes, max_det,
-                         E.PRE_PIL_STRETCH if pil_stretch else E.PRE_LETTERBOX, channel_reverse)
+        return self._results(*self.infer_frames(frames, conf, iou, imgsz, classes, max_det, channel_reverse=channel_reverse,
+                                                pil_stretch=pil_stretch))
+
+    def infer_frames(self, frames, conf, iou, imgsz, classes=None, max_det=300, *, channel_reverse: bool,
+                     pil_stretch: bool = False) -> tuple:
+        """The device stage alone: -> (boxes (n,max_det,6), kpts (n,max_det,nk) | None, counts (n,), (h, w), imgsz,
+        pre_mode).  ``frames``: (n,h,w,3) uint8 array, a list of such frames, or a list of ``video.DeviceFrame``
+        handles of one contiguous range of a clip that is already in HBM (no upload)."""
+        from . import video
+        pre_mode = E.PRE_PIL_STRETCH if pil_stretch else E.PRE_LETTERBOX
+        dev = None if isinstance(frames, np.ndarray) else video.device_batch(frames)
+        if dev is not None:
+            src, n, h, w = dev
+        else:
+            src = frames if isinstance(frames, np.ndarray) else np.stack(list(frames))
+            n, h, w, _ = src.shape
+        m = self._ensure_model()
+        boxes, kpts, counts = m.yolo_infer(src, n, h, w, imgsz=int(imgsz), conf=float(conf), iou=float(iou),
+                                           classes=classes, max_det=int(max_det), pre_mode=pre_mode,
+                                           channel_reverse=channel_reverse, letterbox_auto=True)
+        return boxes, kpts, counts, (h, w), int(imgsz), pre_mode
 
     def _run(self, frames: np.ndarray, conf, iou, imgsz, classes, max_det, pre_mode, reverse) -> list:
-        m = self._ensure_model()
-        n, h, w, _ = frames.shape
-        boxes, kpts, counts = m.yolo_infer(frames, n, h, w, imgsz=int(imgsz), conf=float(conf), iou=float(iou),
-                                           classes=classes, max_det=int(max_det), pre_mode=pre_mode,
-                                           channel_reverse=reverse, letterbox_auto=True)
+        return self._results(*self.infer_frames(frames, conf, iou, imgsz, classes, max_det, channel_reverse=reverse,
+                                                pil_stretch=pre_mode == E.PRE_PIL_STRETCH))
+
+    def _results(self, boxes, kpts, counts, hw, imgsz, pre_mode) -> list:
+        h, w = hw
+        n = len(counts)
         oshape = (imgsz, imgsz) if pre_mode == E.PRE_PIL_STRETCH else (h, w)
         out = []
         for i in range(n):
