@@ -14,8 +14,10 @@ The window stream is the *intended* contiguous one (th
 windows that straddle the median boundary for clips longer than ``median_range``).
 
 PINNED: TrackNet itself against the reference's own models.py (tracknet_ref.py goldens); the Pillow resize
-bit-exactly against Pillow; the ensemble against a literal transcription of the reference's buffer algebra
-(tests/test_ball_ref.py).  UNPINNED: ``cv2.findContours`` ordering (ties between equal-area rectangles) —
+bit-exactly against Pillow; ``ensemble`` / ``ensemble_weight`` / ``generate_inpaint_mask_ref`` bit-exactly against
+outputs of the reference's own ``ball_tracker.py`` (its real ``predict_frames`` loop, ``get_ensemble_weight``,
+``generate_inpaint_mask``) generated in the build container (tests/golden/make_ball_golden.py -> ball_golden.npz,
+objects_golden.json; tests/test_ball_ref.py, tests/test_inpaint.py).  UNPINNED: ``cv2.findContours`` ordering (ties between equal-area rectangles) —
 restated as 8-connected components in reverse raster-discovery order; cv2 is not installable here.
 """
 from __future__ import annotations

@@ -59,12 +59,23 @@ def _make_stub(module, name):
     return type(name, (_Bag,), {"__module__": module})
 
 
+# Globals the stub unpickler resolves for real: tensor / container plumbing only.  Everything else a pickle names
+# (ultralytics.*, but also os.system, builtins.eval, ...) becomes an inert attribute bag, so a crafted .pt cannot
+# execute code through this loader (upstream's plain torch.load(weights_only=False) would).
+_SAFE_MODULE_PREFIXES = ("torch", "collections", "numpy", "_codecs")
+_SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "slice", "complex", "bytearray", "range", "object",
+                  "int", "float", "bool", "str", "bytes"}
+
+
 class _StubUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        try:
-            return super().find_class(module, name)
-        except Exception:
-            return _make_stub(module, name)
+        root = module.split(".", 1)[0]
+        if root in _SAFE_MODULE_PREFIXES or (module == "builtins" and name in _SAFE_BUILTINS):
+            try:
+                return super().find_class(module, name)
+            except Exception:
+                return _make_stub(module, name)
+        return _make_stub(module, name)
 
 
 class _StubPickleModule:
@@ -113,8 +124,10 @@ def save_checkpoint(path, state_dict, task, nc=0, kpt_shape=None, scale=None, na
 
 def load_checkpoint(path) -> Checkpoint:
     """Load either checkpoint flavour; raises ``ValueError`` on an unrecognised layout."""
+    # plain-dict checkpoints (ours, TrackNetV3's) load under torch's safe unpickler; only Ultralytics pickles
+    # (whole nn.Modules) need the stub unpickler, which never resolves a non-tensor global (see above)
     try:
-        obj = torch.load(str(path), map_location="cpu", weights_only=False)
+        obj = torch.load(str(path), map_location="cpu", weights_only=True)
     except Exception:
         obj = torch.load(str(path), map_location="cpu", weights_only=False,
                          pickle_module=_StubPickleModule)
@@ -138,7 +151,12 @@ def load_checkpoint(path) -> Checkpoint:
         yaml = getattr(model, "yaml", None) or {}
         kpt_shape = yaml.get("kpt_shape") if isinstance(yaml, dict) else None
         if info["nk"] and not kpt_shape:
+            # no model.yaml in the pickle: nk = K * ndim is only decidable when exactly one of ndim 2 / 3 divides
+            # it (13 x 3 = 39 is; the 12-keypoint 2-D court model's 24 is NOT: it would read as 8 x 3)
             nk = info["nk"]
+            if nk % 3 == 0 and nk % 2 == 0:
+                raise ValueError(f"{path}: pose head with {nk} outputs and no kpt_shape in the checkpoint is ambiguous "
+                                 f"({nk // 2} x 2 or {nk // 3} x 3); re-save it with save_checkpoint(..., kpt_shape=...)")
             kpt_shape = (nk // 3, 3) if nk % 3 == 0 else (nk // 2, 2)
         names = getattr(model, "names", None) or {}
         return Checkpoint(sd, "pose" if info["nk"] else "detect", info["nc"],

@@ -28,7 +28,7 @@ class VideoInfo:
 
     @classmethod
     def from_video_path(cls, video_path) -> "VideoInfo":
-        if isinstance(video_path, DeviceClip):
+        if isinstance(video_path, (DeviceClip, ArrayClip)):
             return cls(video_path.w, video_path.h, video_path.fps, video_path.total_frames)
         p = str(video_path)
         if p.startswith("synthetic://"):
@@ -109,6 +109,25 @@ class DeviceClip:
         self.buffer.free()
 
 
+class ArrayClip:
+    """Host-memory clip: ``frames`` (n, h, w, 3) uint8 BGR presented as ``n * repeat`` frames (bench: the
+    PCIe-inclusive rate; tests)."""
+
+    def __init__(self, frames: np.ndarray, repeat: int = 1, fps: int = 30):
+        self.array = np.ascontiguousarray(frames, np.uint8)
+        self.n, self.h, self.w = self.array.shape[:3]
+        self.repeat, self.fps = int(repeat), int(fps)
+
+    @property
+    def total_frames(self) -> int:
+        return self.n * self.repeat
+
+    def frames(self, start: int = 0, end: Optional[int] = None, stride: int = 1) -> Iterator[np.ndarray]:
+        stop = self.total_frames if end is None else min(end, self.total_frames)
+        for i in range(start, stop, stride):
+            yield self.array[i % self.n]
+
+
 def device_batch(sample):
     """If ``sample`` is a list of DeviceFrame handles of ONE clip with consecutive stored indices, return
     (DeviceBuffer view over exactly those frames, n, h, w); None for host frames.  Anything else is an error: a
@@ -124,7 +143,7 @@ def device_batch(sample):
 
 
 def get_video_frames_generator(source_path, stride: int = 1, start: int = 0, end: Optional[int] = None) -> Iterator[np.ndarray]:
-    if isinstance(source_path, DeviceClip):
+    if isinstance(source_path, (DeviceClip, ArrayClip)):
         yield from source_path.frames(start, end, stride)
         return
     p = str(source_path)

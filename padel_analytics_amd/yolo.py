@@ -91,12 +91,25 @@ class YOLO:
             raise ValueError(f"unknown device {device!r}")
         return self
 
-    def _ensure_model(self) -> E.Model:
+    def _ensure_model(self, empty: bool = False) -> E.Model:
         if self._model is None:
             eng = self._engine or E.default_engine()
-            self._model = E.Model(eng, self.graph)
+            self._model = E.Model(eng, self.graph, empty=empty)
             self._model.set_max_batch(self.max_batch)
         return self._model
+
+    def attach(self, engine: Optional[E.Engine] = None, *, receive_weights: bool = False) -> E.Model:
+        """Create the HBM-resident model now, on ``engine``.  ``receive_weights=True``: this rank did not load the
+        checkpoint — the blob is allocated empty and must be filled by ``broadcast_weights`` (multi-GPU: only rank 0
+        reads the .pt)."""
+        if engine is not None:
+            self._engine = engine
+        return self._ensure_model(empty=receive_weights)
+
+    def broadcast_weights(self, root: int = 0) -> None:
+        """One-time RCCL broadcast of the packed weight blob, HBM to HBM, over the engine's communicator."""
+        m = self._ensure_model()
+        m.engine.bcast_weights(m, root)
 
     def close(self) -> None:
         if self._model is not None:

@@ -1,55 +1,71 @@
-"""Pins the ball-path oracle (oracle/ball_ref.py) on CPU: the ensemble against a literal transcription of
-the reference's streaming buffer loop (ball_tracker.py:421-523) for several batch sizes, the ensemble weights,
-the heat-map decode rules, and the product's host-side rectangle pick against the oracle's."""
+"""Pins the ball-path oracle (oracle/ball_ref.py) and the product's host pieces to golden outputs OF THE REFERENCE
+ITSELF: ``tests/golden/ball_golden.npz`` / ``objects_golden.json`` were produced by importing the reference's
+``trackers/ball_tracker/ball_tracker.py`` and result-object modules in the build container
+(``tests/golden/make_ball_golden.py``) — the real ``predict_frames`` ensemble loop (:421-523) with its DataLoader
+batching and 7-deep prediction buffer, ``get_ensemble_weight`` (:68-97), ``generate_inpaint_mask`` (:100-136),
+``Ball`` / ``Player`` / ``PlayerKeypoints`` serialisation.  Plus the heat-map decode rules (cv2 contour order stays
+unpinned: cv2 is not installable)."""
+import json
+from pathlib import Path
+
 import numpy as np
-import torch
+import pytest
 
 from oracle import ball_ref as br
+from padel_analytics_amd import inpaint as ip
+from padel_analytics_amd.detections import Detections
 from padel_analytics_amd.trackers.ball_tracker import Ball, predict_location
+from padel_analytics_amd.trackers.players_keypoints_tracker import PlayerKeypoint, PlayerKeypoints, PlayersKeypoints
+from padel_analytics_amd.trackers.players_tracker import Player, Players
+
+GOLD = np.load(Path(__file__).parent / "golden" / "ball_golden.npz")
+OBJ = json.loads((Path(__file__).parent / "golden" / "objects_golden.json").read_text())
 
 
-def _reference_stream_ensemble(y_all: np.ndarray, batch: int) -> np.ndarray:
-    """Transcription of the reference's loop over DataLoader batches with its 7-deep prediction buffer."""
-    seq_len, H, W = 8, y_all.shape[2], y_all.shape[3]
-    video_len = y_all.shape[0] + 7
-    num_sample, sample_count = video_len - seq_len + 1, 0
-    buffer_size = seq_len - 1
-    sample_indices = torch.arange(seq_len)
-    frame_indices = torch.arange(seq_len - 1, -1, -1)
-    y_pred_buffer = torch.zeros((buffer_size, seq_len, H, W), dtype=torch.float32)
-    weight = torch.from_numpy(br.ensemble_weight())
-    out = []
-    for b0 in range(0, y_all.shape[0], batch):
-        y_pred = torch.from_numpy(y_all[b0:b0 + batch])
-        bs = y_pred.shape[0]
-        y_pred_buffer = torch.cat((y_pred_buffer, y_pred), 0)
-        for sample_i in range(bs):
-            if sample_count < buffer_size:
-                y = y_pred_buffer[sample_indices + sample_i, frame_indices].sum(0) / (sample_count + 1)
-            else:
-                y = (y_pred_buffer[sample_indices + sample_i, frame_indices] * weight[:, None, None]).sum(0)
-            out.append(y)
-            sample_count += 1
-            if sample_count == num_sample:
-                y_pred_buffer = torch.cat((y_pred_buffer, torch.zeros((buffer_size, seq_len, H, W))), 0)
-                for frame_i in range(1, seq_len):
-                    out.append(y_pred_buffer[sample_indices + sample_i + frame_i, frame_indices].sum(0) / (seq_len - frame_i))
-        y_pred_buffer = y_pred_buffer[-buffer_size:]
-    return torch.stack(out).numpy()
+def test_ensemble_weight_matches_reference():
+    assert np.array_equal(br.ensemble_weight(8), GOLD["w_weight_8"])
+    assert np.array_equal(br.inpaint_ensemble_weight(16), GOLD["w_weight_16"])
+    for L in (8, 16, 5):
+        assert np.array_equal(ip.ensemble_weight(L), GOLD[f"w_weight_{L}"]), L
 
 
-def test_ensemble_weight():
-    assert np.allclose(br.ensemble_weight(), np.array([1, 2, 3, 4, 4, 3, 2, 1], np.float32) / 20)
+@pytest.mark.parametrize("case", range(int(GOLD["n_ens"])))
+def test_ensemble_matches_reference_predict_frames_loop(case):
+    """Oracle and product ensembles vs the heat maps the reference's own loop produced for the same window outputs
+    (video lengths 8..64, DataLoader batch sizes 1..16: head / steady-state / tail branches, buffer carry-over)."""
+    y, want = GOLD[f"ens{case}_y"], GOLD[f"ens{case}_heat"]
+    T = int(GOLD[f"ens{case}_T"])
+    got = br.ensemble(y)
+    assert got.shape == want.shape == (T,) + y.shape[2:]
+    assert np.array_equal(got, want), f"oracle ensemble differs from the reference (T={T}, batch={int(GOLD[f'ens{case}_batch'])})"
+    prod = ip.temporal_ensemble(y, ip.ensemble_weight(8))
+    assert np.abs(prod - want).max() <= 1.2e-7          # same terms, numpy summation order
 
 
-def test_ensemble_matches_reference_stream_loop():
-    rng = np.random.default_rng(0)
-    for nw, batch in ((1, 1), (5, 2), (9, 4), (20, 8), (13, 3)):
-        y = rng.uniform(0, 1, (nw, 8, 6, 10)).astype(np.float32)
-        want = _reference_stream_ensemble(y, batch)
-        got = br.ensemble(y)
-        assert got.shape == (nw + 7, 6, 10)
-        assert np.array_equal(got, want), (nw, batch)
+def test_result_objects_match_reference_serialisation():
+    for g in OBJ["ball"]:
+        a = g["args"]
+        b = Ball(frame=a["frame"], xy=tuple(a["xy"]), visibility=a["visibility"])
+        assert json.loads(json.dumps(b.serialize())) == g["serialize"] and list(b.asint()) == g["asint"]
+        assert Ball.from_json(b.serialize()).serialize() == b.serialize()
+    for g in OBJ["player"]:
+        det = Detections(np.array([g["xyxy"]], np.float32), np.array([g["confidence"]], np.float32),
+                         np.array([g["class_id"]]), None if g["tracker_id"] is None else np.array([g["tracker_id"]]))
+        p = Player(det)
+        assert json.loads(json.dumps(p.serialize())) == g["serialize"]
+        for k in ("top_left", "bottom_right", "midpoint", "feet"):
+            assert list(getattr(p, k)) == g[k], k
+        assert (p.height, p.width) == (g["height"], g["width"])
+        # the array-backed (lazy) container serialises to the same bytes as the reference's objects
+        rows = np.array([g["xyxy"] + [g["confidence"], g["class_id"]]], np.float32)
+        ids = None if g["tracker_id"] is None else np.array([g["tracker_id"]])
+        assert json.loads(json.dumps(Players(rows=rows, ids=ids).serialize())) == [g["serialize"]]
+    g = OBJ["player_keypoints"]
+    assert PlayerKeypoints.KEYPOINTS_NAMES == g["names"]
+    kps = PlayerKeypoints([PlayerKeypoint(id=i, name=n, xy=(1.5 * i, 100.0 - 2.25 * i)) for i, n in enumerate(g["names"])])
+    assert json.loads(json.dumps(kps.serialize())) == g["serialize"] and list(kps[g["names"][3]].asint()) == g["asint_3"]
+    xy = np.array([[[1.5 * i, 100.0 - 2.25 * i] for i in range(13)]], np.float32)
+    assert json.loads(json.dumps(PlayersKeypoints(xy=xy).serialize())) == [g["serialize"]]
 
 
 def test_decode_rules():
@@ -64,9 +80,3 @@ def test_decode_rules():
     heat[1, 0, 0] = 0.5              # not > 0.5
     x, y, v = br.decode_heat(heat, (1280 / 512, 720 / 288))
     assert (x[0], y[0], v[0]) == (int(24 * 2.5), int(12 * 2.5), 1) and (x[1], y[1], v[1]) == (0, 0, 0)
-
-
-def test_ball_json():
-    b = Ball(frame=3, xy=(10, 20), visibility=1)
-    assert b.serialize() == {"frame": 3, "xy": (10, 20), "visibility": 1, "projection": None}
-    assert Ball.from_json(b.serialize()).xy == (10, 20) and b.asint() == (10, 20)

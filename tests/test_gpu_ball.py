@@ -141,8 +141,19 @@ def test_ball_tracker_plugin(gpu_engine, tmp_path):
     t2 = BallTracker(str(ck), str(ick), batch_size=6, median_max_sample_num=T)
     t2.video_info_post_init(video.VideoInfo(640, 360, 30, T))
     balls2 = t2.predict_and_update(iter(frames), total_frames=T)
+    # ... and must equal the ORACLE's restatement of that stage (oracle/ball_ref.py:inpaint_stage_ref, the reference's
+    # streaming loop with the torch InpaintNet of tracknet_ref.py, itself pinned to the reference's models.py goldens)
+    # applied to the TrackNet-stage trajectory — not the product's own function
     base = [(b.xy[0], b.xy[1], b.visibility) for b in balls]
-    want = ip.inpaint_trajectory([b[0] for b in base], [b[1] for b in base], [b[2] for b in base], 640, 360,
-                                 ip.InpaintNetHost(sdi), 16)
-    assert [(b.xy[0], b.xy[1], b.visibility) for b in balls2] == want
+    want, raw = br.inpaint_stage_ref([b[0] for b in base], [b[1] for b in base], [b[2] for b in base], 640, 360,
+                                     tr.InpaintNetRef(sdi).forward, 16, batch_size=6)
+    got = [(b.xy[0], b.xy[1], b.visibility) for b in balls2]
+    assert len(got) == T == len(want)
+    checked = 0
+    for g in range(T):
+        fx, fy = raw[g]
+        if min(abs(fx - round(fx)), abs(fy - round(fy))) >= 1e-2:            # away from an int() truncation boundary
+            assert got[g] == want[g], (g, got[g], want[g], raw[g])
+            checked += 1
+    assert checked >= T // 2
     t2.to("cpu")

@@ -1,0 +1,141 @@
+"""GPU parity AT THE CONFIGURATION bench.py TIMES (BASELINE configs[2]: 64 x 1280x720, players yolov8m, ball
+yolov8n nc=1, pose yolov8m 13x3 @1280^2 — VERDICT r1 "the benched graph is never parity-tested"):
+
+* yolov8m-pose 13x3 @1280^2 against the fp32 and the fp64 oracle (2 frames);
+* the nc=1 ball detector against the oracle, and the a16 mapping top-1 box -> Ball(frame, xy, visibility);
+* batch invariance: frames i of engine(B=64, one graph pass) are BITWISE the frames i of engine(B=2) for all three
+  bench graphs — every conv tile is bit-identical (tests/test_gpu_conv.py), so the single-pass regime (M up to
+  6.5 M rows, other tile choices) adds nothing to the 2-frame parity evidence;
+* the uint8 network input after K1 (letterbox: 720p = exact 1/2 area path, 1080p = exact 1/3, 480x854 = general
+  fixed-point bilinear, 640x640 = copy) and K2 (Pillow bicubic stretch) byte-for-byte against the oracle
+  (oracle/yolov8_ref.py:letterbox_u8, Pillow itself)."""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from oracle import yolov8_ref as ref
+from padel_analytics_amd import checkpoint, engine as E, graph as G, synth
+from padel_analytics_amd.trackers import Ball, BallDetectTracker
+from tests import parity
+from tests.test_gpu_yolo_parity import _check
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames64():
+    return synth.synthetic_frames(64, 720, 1280, seed=1000)        # bench.py's rank-0 shard
+
+
+def _model(eng, name, frames, batch):
+    cfg = bench.TRACKERS[name]
+    sd = bench.make_state_dict(name, cfg, frames)
+    m = E.Model(eng, G.build_yolov8(sd, cfg["nc"], cfg["kpt"]))
+    m.set_max_batch(batch)
+    return cfg, sd, m
+
+
+def _infer(m, cfg, frames):
+    n, h, w, _ = frames.shape
+    return m.yolo_infer(frames, n, h, w, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7, classes=cfg["classes"],
+                        pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg["rev"])
+
+
+def test_pose_m_1280_parity(gpu_engine, frames64):
+    cfg, sd, m = _model(gpu_engine, "pose", frames64, 2)
+    got = _infer(m, cfg, frames64[:2])
+    m.close()
+    srcs = bench.source_for_oracle(cfg, frames64[:2])
+    _check("pose-m-1280-13x3 (bench graph)", sd, 1, (13, 3), srcs, got, cfg["conf"], 0.7, 1280)
+
+
+def test_ball_nc1_detect_parity_and_ball_mapping(gpu_engine, frames64, tmp_path):
+    cfg, sd, m = _model(gpu_engine, "ball", frames64, 4)
+    frames = frames64[:4]
+    got = _infer(m, cfg, frames)
+    m.close()
+    srcs = bench.source_for_oracle(cfg, frames)
+    # nc=1 checkpoint, classes=None: the harness's oracle call passes classes=[0], equivalent for a 1-class head
+    _check("detect-n-nc1 (bench ball graph)", sd, 1, None, srcs, got, cfg["conf"], 0.7, 640)
+    # a16: top-1 box -> Ball(frame, xy, visibility) through the plugin class, against the oracle's best box
+    checkpoint.save_checkpoint(tmp_path / "ball.pt", sd, "detect", 1, None, "n", {0: "ball"})
+    t = BallDetectTracker(str(tmp_path / "ball.pt"), batch_size=3, conf=cfg["conf"])
+    balls = t.predict_and_update(iter(frames), total_frames=len(frames))
+    r32 = ref.predict(ref.YoloV8Ref(sd, 1, None), srcs, cfg["conf"], 0.7, 640, classes=None)
+    assert len(balls) == len(frames) and all(isinstance(b, Ball) for b in balls)
+    seen = 0
+    for i, (b, r) in enumerate(zip(balls, r32)):
+        assert b.frame == i
+        if len(r["boxes"]) == 0:
+            assert (b.xy, b.visibility) == ((0.0, 0.0), 0)
+            continue
+        x1, y1, x2, y2 = r["boxes"][0, :4]
+        assert b.visibility == 1 and abs(b.xy[0] - (x1 + x2) / 2) < 0.05 and abs(b.xy[1] - (y1 + y2) / 2) < 0.05, (i, b.xy)
+        seen += 1
+    assert seen > 0
+    t.model.close()
+
+
+@pytest.mark.parametrize("name", ["players", "ball", "pose"])
+def test_batch_invariance_b64_vs_b2(gpu_engine, frames64, name):
+    cfg, sd, m = _model(gpu_engine, name, frames64, 64)
+    big = _infer(m, cfg, frames64)
+    arena, logical = m.plan_bytes()
+    m.close()
+    cfg, sd, m = _model(gpu_engine, name, frames64, 2)
+    picks = [0, 1, 30, 31, 62, 63]
+    for lo in range(0, len(picks), 2):
+        i = picks[lo]
+        small = _infer(m, cfg, frames64[i:i + 2])
+        for a, b, what in zip(big, small, ("boxes", "kpts", "counts")):
+            if a is None:
+                continue
+            assert np.array_equal(a[i:i + 2], b), f"{name}: {what} of frames {i},{i + 1} differ between B=64 and B=2"
+    m.close()
+    assert int(big[2].sum()) > 0
+    print(f"{name}: {int(big[2].sum())} detections on 64 frames; activation arena {arena / 2**30:.1f} GiB "
+          f"(logical buffers {logical / 2**30:.1f} GiB)")
+
+
+@pytest.mark.parametrize("hw", [(720, 1280), (1080, 1920), (480, 854), (640, 640)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_letterbox_u8_byte_exact(gpu_engine, hw, reverse):
+    frames = synth.synthetic_frames(3, hw[0], hw[1], seed=21)
+    sd = synth_sd()
+    m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None))
+    m.set_max_batch(3)
+    m.yolo_infer(frames, 3, hw[0], hw[1], imgsz=640, conf=0.9, iou=0.7, channel_reverse=reverse)
+    got = m.read_netin(3)
+    m.close()
+    assert (got[..., 3] == 0).all()
+    for i in range(3):
+        lb = ref.letterbox_u8(frames[i], 640, auto=True)
+        want = lb[..., ::-1] if reverse else lb
+        assert got[i, ..., :3].shape == want.shape
+        assert np.array_equal(got[i, ..., :3], want), f"{hw} frame {i}: {int((got[i, ..., :3] != want).sum())} bytes differ"
+
+
+@pytest.mark.parametrize("hw,S", [((720, 1280), 1280), ((720, 1280), 640), ((1080, 1920), 1280), ((360, 640), 640)])
+def test_pil_stretch_u8_byte_exact(gpu_engine, hw, S):
+    from PIL import Image
+    frames = synth.synthetic_frames(2, hw[0], hw[1], seed=22)
+    sd = synth_sd()
+    m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None))
+    m.set_max_batch(2)
+    m.yolo_infer(frames, 2, hw[0], hw[1], imgsz=S, conf=0.9, iou=0.7, pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
+    got = m.read_netin(2)
+    m.close()
+    for i in range(2):
+        want = np.asarray(Image.fromarray(np.ascontiguousarray(frames[i][..., ::-1])).resize((S, S)))     # RGB, bicubic
+        assert np.array_equal(got[i, ..., :3], want), f"{hw}->{S} frame {i}: {int((got[i, ..., :3] != want).sum())} bytes differ"
+
+
+_SD = {}
+
+
+def synth_sd():
+    if "n" not in _SD:
+        from padel_analytics_amd import yolo_arch
+        _SD["n"] = yolo_arch.synth_state_dict("n", 80, None, 0)
+    return _SD["n"]

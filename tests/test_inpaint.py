@@ -1,6 +1,6 @@
 """InpaintNet stage on the host: the numpy network against the reference's own models.py golden, the mask
-generator against the transcription of the reference loop (including its edge quirks), and the whole
-trajectory repair against the streaming transcription for several batch sizes."""
+generator against masks produced by the reference's own generate_inpaint_mask (including its edge quirks), and the
+whole trajectory repair against the oracle's streaming restatement for several batch sizes."""
 from pathlib import Path
 
 import numpy as np
@@ -19,19 +19,16 @@ def test_inpaintnet_host_matches_reference_golden():
     assert y.shape == GOLD["yi"].shape and np.abs(y - GOLD["yi"]).max() < 2e-6
 
 
-def test_inpaint_mask_matches_reference_loop():
-    rng = np.random.default_rng(0)
-    cases = [([1, 1, 0, 0, 1, 1], [100, 100, 0, 0, 100, 100]), ([0, 0, 1, 1], [0, 0, 90, 90]), ([1, 0, 0, 1], [80, 0, 0, 80]),
-             ([1, 1, 1, 0, 0], [70, 70, 70, 0, 0]), ([1, 1, 0, 1, 0, 0, 1], [5, 5, 0, 5, 0, 0, 99]), ([1] * 5, [50] * 5), ([0] * 5, [0] * 5)]
-    for _ in range(200):
-        n = int(rng.integers(1, 40))
-        v = (rng.uniform(size=n) > 0.4).astype(int)
-        y = np.where(v == 1, rng.integers(0, 200, n), 0)
-        cases.append((v.tolist(), y.tolist()))
-    for v, y in cases:
-        want = br.generate_inpaint_mask_ref(y, v, th_h=36.0)
-        got = ip.generate_inpaint_mask(np.array(y), np.array(v), th_h=36.0).tolist()
-        assert got == want, (v, y)
+def test_inpaint_mask_matches_reference_goldens():
+    """generate_inpaint_mask (ball_tracker.py:100-136): oracle restatement and product vs the masks the reference's
+    own function returned for 71 visibility patterns (tests/golden/make_ball_golden.py), edge quirks included."""
+    import json
+    cases = json.loads((Path(__file__).parent / "golden" / "objects_golden.json").read_text())["inpaint_masks"]
+    assert len(cases) >= 60
+    for c in cases:
+        v, y, want = c["visibility"], c["y"], c["mask"]
+        assert br.generate_inpaint_mask_ref(y, v, th_h=c["th_h"]) == want, (v, y)
+        assert ip.generate_inpaint_mask(np.array(y), np.array(v), th_h=c["th_h"]).tolist() == want, (v, y)
 
 
 def test_ensemble_weight_and_generic_ensemble():

@@ -1,7 +1,7 @@
 # MFMA utilisation of the default (v5 tap) conv kernel: one --pmc pass, kernel-trace only
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
 cd /tmp
-timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmct -o p -- python $R/tools/conv_bench.py --one 0 0 --reps 2 --shapes "m.P4.bneck,m.P3.bneck" > $R/gpurun_out/pmct.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmct -o p -- python $R/tools/conv_bench.py --tiles auto --reps 2 --shapes "m.P4.bneck,m.P3.bneck" > $R/gpurun_out/pmct.log 2>&1
 python - "$R/gpurun_out/pmct/p_counter_collection.csv" "$R/gpurun_out/pmct/p_kernel_trace.csv" <<'PY'
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))

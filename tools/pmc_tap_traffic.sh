@@ -2,7 +2,7 @@
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmct_$c -o p -- python $R/tools/conv_bench.py --one 0 0 --reps 1 --shapes "m.P4.bneck,m.head0,m.c2f.cv2" > $R/gpurun_out/pmct_$c.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/pmct_$c -o p -- python $R/tools/conv_bench.py --tiles auto --reps 1 --shapes "m.P4.bneck,m.head0,m.c2f.cv2" > $R/gpurun_out/pmct_$c.log 2>&1
 python - "$R/gpurun_out/pmct_$c/p_counter_collection.csv" $c <<'PY'
 import csv, sys, collections
 agg = collections.defaultdict(float); name = {}

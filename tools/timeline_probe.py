@@ -18,12 +18,13 @@ STEPS, WORDS = 64, 8 + 4 * 64 * 5
 
 
 def run_conv(dump, kernel="lds", B=64, H=48, W=80, cin=192, cout=192):
-    os.environ.update(PADEL_CONV_LDS_VARIANT="7", PADEL_CONV_DIAG="16", PADEL_CONV_DBG=dump)
-    if kernel == "tap":
-        os.environ["PADEL_CONV_TAP"] = "1"
+    if kernel != "tap":
+        raise SystemExit("the LDS kernel's DIAG instantiations were retired with round 2 (tools/legacy_conv/); use --kernel tap")
     from padel_analytics_amd import engine as E, graph as G
     eng = E.default_engine(0)
     eng.set_profiling(True)
+    eng.set_tuning(impl=0, variant=7, timeline=1)
+    eng.lib.pa_engine_set_timeline_path(eng.handle, dump.encode())
     rng = np.random.default_rng(0)
     g = G.Graph(task=G.TASK_TRACKNET)
     b0 = g.buf(0, cin)
@@ -45,7 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/timeline.txt")
     ap.add_argument("--dump", default="/tmp/padel_conv_timeline.bin")
-    ap.add_argument("--kernel", default="lds", choices=["lds", "tap"],
+    ap.add_argument("--kernel", default="tap", choices=["lds", "tap"],
                     help="lds = conv_lds_kernel (v2) DIAG 16; tap = conv_tap_kernel (v5) timeline instantiation")
     a = ap.parse_args()
     ms = run_conv(a.dump, a.kernel)
