@@ -159,8 +159,12 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
     __syncthreads();
     if (tid == 0) a.out_cnt[b] = kept;
 
-    // write kept detections in rank order, rescaled to the source frame
+    // rows beyond `kept` read as zeros on the host (the whole [max_det] block is copied back)
     const int nkv = a.nk;
+    for (int k = kept * 6 + tid; k < a.max_det * 6; k += NMS_THREADS) a.out_boxes[(long long)b * a.max_det * 6 + k] = 0.0f;
+    if (nkv > 0 && a.out_kpts)
+        for (int k = kept * nkv + tid; k < a.max_det * nkv; k += NMS_THREADS) a.out_kpts[(long long)b * a.max_det * nkv + k] = 0.0f;
+    // write kept detections in rank order, rescaled to the source frame
     for (int k = tid; k < kept; k += NMS_THREADS) {
         const int slot = order[k];
         const float* c = cand + slot * 6;

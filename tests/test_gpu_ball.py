@@ -149,11 +149,14 @@ def test_ball_tracker_plugin(gpu_engine, tmp_path):
                                      tr.InpaintNetRef(sdi).forward, 16, batch_size=6)
     got = [(b.xy[0], b.xy[1], b.visibility) for b in balls2]
     assert len(got) == T == len(want)
-    checked = 0
+    exact = 0
     for g in range(T):
         fx, fy = raw[g]
-        if min(abs(fx - round(fx)), abs(fy - round(fy))) >= 1e-2:            # away from an int() truncation boundary
-            assert got[g] == want[g], (g, got[g], want[g], raw[g])
-            checked += 1
-    assert checked >= T // 2
+        if got[g] == want[g]:
+            exact += 1
+            continue
+        # numpy vs torch InpaintNet differ by ~1e-6: only a coordinate sitting on an int() truncation boundary may move
+        assert min(abs(fx - round(fx)), abs(fy - round(fy))) < 1e-2, (g, got[g], want[g], raw[g])
+        assert abs(got[g][0] - want[g][0]) <= 1 and abs(got[g][1] - want[g][1]) <= 1 and got[g][2] == want[g][2], (g, got[g], want[g])
+    assert exact >= T - 2
     t2.to("cpu")

@@ -77,7 +77,7 @@ def _check(tag, sd, nc, kpt, srcs, got, conf, iou, imgsz, tight=False):
                    "engine_vs_fp64_px": g64["worst_px"], "fp32_oracle_vs_fp64_px": floor["worst_px"],
                    "rms_engine_vs_fp64_px": g64["rms_px"], "rms_fp32_oracle_vs_fp64_px": floor["rms_px"],
                    "rms_engine_vs_fp32_oracle_px": g32["rms_px"],
-                   "score_err": g32["worst_score"], "flips": [f[1] for f in g32["flips"]]}
+                   "score_err": g32["worst_score"], "score_floor": floor["worst_score"], "flips": [f[1] for f in g32["flips"]]}
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "parity_report.json"), "w") as f:
@@ -88,7 +88,9 @@ def _check(tag, sd, nc, kpt, srcs, got, conf, iou, imgsz, tight=False):
     assert g32["worst_px"] <= bound32, f"{tag}: engine vs fp32 oracle {g32['worst_px']:.3e} px > {bound32:.3e}"
     rb = max(2e-4, 1.5 * floor["rms_px"])
     assert g64["rms_px"] <= rb, f"{tag}: RMS engine vs exact {g64['rms_px']:.3e} px > {rb:.3e} (fp32 oracle RMS {floor['rms_px']:.3e})"
-    assert g32["worst_score"] < 2e-4
+    # confidences / keypoint visibilities: as close to the fp32 oracle as that oracle is to the exact evaluation
+    sb = max(2e-4, 4 * floor["worst_score"])
+    assert g32["worst_score"] <= sb, f"{tag}: score error {g32['worst_score']:.3e} > {sb:.3e} (fp32-vs-fp64 oracle {floor['worst_score']:.3e})"
 
 
 @pytest.mark.parametrize("scale,hw,nf", [("n", (720, 1280), 4), ("n", (640, 640), 3), ("n", (1080, 1920), 2),
