@@ -36,6 +36,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_FP16_MFMA_TFLOPS = 2500.0     # same guide: BF16/FP16 MFMA, dense (not the 2:1-sparsity headline)
 
 # tracker table: name -> (scale, nc, kpt_shape, imgsz, conf, classes, pre_mode, channel_reverse)
 TRACKERS = {
@@ -75,6 +76,9 @@ def parse():
                     help="also time the runner with the clip in pageable host memory: sequential (one upload per "
                          "tracker, like the reference) and fan-out (one upload per batch) — PCIe-inclusive rates")
     ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the op lists (tuning; -1 = engine default)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
+                    help="f32: the parity path (the reference runs half=False) — the headline; f16: fp16 activations / "
+                         "weights with fp32 accumulation (BASELINE configs[4]), reports its own L-inf vs the fp32 oracle")
     return ap.parse_args()
 
 
@@ -122,7 +126,7 @@ def spawn_ranks(a) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def build_trackers(names, frames, rank, B, H, W, eng, tmp):
+def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False):
     """The three plugin classes exactly as main.py:126-161 constructs them, over synthetic checkpoints.  Only rank 0
     synthesises / "loads" real weights; the other ranks create their models from an architecture-only checkpoint
     with an EMPTY weight blob in HBM and receive rank 0's blob through pa_engine_bcast_weights."""
@@ -138,11 +142,11 @@ def build_trackers(names, frames, rank, B, H, W, eng, tmp):
         if name == "players":
             sx, sy = W / 1280.0, H / 720.0
             zone = D.PolygonZone(np.array([[int(x * sx), int(y * sy)] for x, y in ZONE_720P]), frame_resolution_wh=(W, H))
-            t = PlayerTracker(str(path), zone, batch_size=B)
+            t = PlayerTracker(str(path), zone, batch_size=B, half=half)
         elif name == "pose":
-            t = PlayerKeypointsTracker(str(path), cfg["imgsz"], batch_size=B)
+            t = PlayerKeypointsTracker(str(path), cfg["imgsz"], batch_size=B, half=half)
         else:
-            t = BallDetectTracker(str(path), batch_size=B, conf=cfg["conf"])
+            t = BallDetectTracker(str(path), batch_size=B, conf=cfg["conf"], half=half)
         # frames per graph replay: the whole batch (measured on c3 in round 1: 16 -> 247, 32 -> 256, 64 -> 264
         # frames/s; small replays leave the P5 layers with ~2 rounds of workgroups)
         t.model.set_max_batch(B)
@@ -194,7 +198,7 @@ def main():
     clip = video.DeviceClip(eng, frames, repeat=max(K, Wm, 1))           # resident in HBM before timing
     tmp = tempfile.mkdtemp(prefix="padel_bench_")
     with contextlib.redirect_stdout(sys.stderr):
-        trackers, flops_per_frame = build_trackers(names, frames, rank, B, H, W, eng, tmp)
+        trackers, flops_per_frame = build_trackers(names, frames, rank, B, H, W, eng, tmp, half=a.dtype == "f16")
 
     def fence():
         eng.synchronize()
@@ -228,7 +232,7 @@ def main():
     out = {
         "metric": "frames/sec (all trackers) on 1280x720", "value": None, "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": None,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {
             "workload": desc, "frames_per_gpu_per_step": B, "frame_hw": [H, W],
             "trackers": {n: {"graph": f"yolov8{TRACKERS[n]['scale']}-{'pose13x3' if TRACKERS[n]['kpt'] else 'detect'}"
@@ -300,6 +304,7 @@ def main():
         ms1, fl1 = sum(r["ms"] for r in c1), sum(r["flops"] for r in c1)
         ms_all = sum(r["ms"] for r in recs)
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
+        PEAK = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_FP16_MFMA_TFLOPS
         traffic = None
         tpath = ROOT / "profiles" / "r2_traffic.json"          # PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc_bench_traffic.sh)
         if tpath.exists():
@@ -309,13 +314,15 @@ def main():
                            "write_bytes_per_launch": tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"], "source": tj["source"]}
         out["roofline"] = {
-            "kernel": "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)",
-            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+            "kernel": "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)"
+                      if a.dtype == "f32" else
+                      "conv_tap16_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x32_f16)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK, 4), "traffic": traffic if a.dtype == "f32" else None,
             "launches": len(c3), "avg_launch_ms": round(ms3 / max(len(c3), 1), 4),
             "flops_per_step": fl3, "kernel_ms_per_step": round(ms3, 3),
             "conv1x1": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0, "ms_per_step": round(ms1, 3),
-                        "frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if ms1 > 0 else 0.0},
+                        "frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK, 4) if ms1 > 0 else 0.0},
             "all_kernels_ms_per_step": round(ms_all, 3),
             "other_ms_per_step": {str(k): round(sum(r["ms"] for r in recs if r["kind"] == k), 3)
                                   for k in sorted({r["kind"] for r in recs}) if k != 2},
@@ -338,6 +345,8 @@ def main():
         ns = a.cpu_sample or 2
         sample = frames[:ns]
         tcpu = 0.0
+        if a.dtype != "f32":
+            a.no_fp64 = True
         par = {"linf_px_vs_fp32_oracle": 0.0, "linf_px_vs_fp64": 0.0 if not a.no_fp64 else None,
                "oracle_floor_px": 0.0 if not a.no_fp64 else None, "classes_equal": True, "detection_sets_equal": True,
                "detections": 0, "per_tracker": {}, "frames": ns,
@@ -362,6 +371,26 @@ def main():
             boxes, counts = boxes[:ns], counts[:ns]
             kpts = None if kpts is None else kpts[:ns]
             entry = {}
+            if a.dtype != "f32":
+                # reduced precision: detection sets may differ near the thresholds; report how many of the oracle's
+                # detections the path reproduces and its own L-inf on those (no parity claim for this dtype)
+                tot = mt = 0
+                worst = 0.0
+                for i, r in enumerate(r32):
+                    gb = boxes[i, :counts[i]]
+                    pairs, ru, gu = parity.match(r["boxes"], gb, tol_match=8.0)
+                    tot += len(r["boxes"]); mt += len(pairs)
+                    for i_r, i_g in pairs:
+                        worst = max(worst, float(np.abs(gb[i_g, :4] - r["boxes"][i_r, :4]).max()))
+                        if kpts is not None and r["kpts"] is not None:
+                            gk = kpts[i, i_g].reshape(*cfg["kpt"])
+                            worst = max(worst, float(np.abs(gk[..., :2] - r["kpts"][i_r][..., :2]).max()))
+                entry.update(detections=tot, matched=mt, linf_px_vs_fp32_oracle=round(worst, 4))
+                par["linf_px_vs_fp32_oracle"] = max(par["linf_px_vs_fp32_oracle"], worst)
+                par["detections"] += tot
+                par["detection_sets_equal"] = par["detection_sets_equal"] and mt == tot == int(counts.sum())
+                par["per_tracker"][name] = entry
+                continue
             try:
                 g32 = parity.compare_batch(r32, boxes, kpts, counts, cfg["conf"], 0.7, kpt_shape=cfg["kpt"])
                 entry.update(detections=g32["n"], linf_px_vs_fp32_oracle=g32["worst_px"], rms_px_vs_fp32_oracle=g32["rms_px"],

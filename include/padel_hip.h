@@ -29,7 +29,7 @@ extern "C" {
 typedef struct pa_engine pa_engine;
 typedef struct pa_model pa_model;
 
-#define PA_ABI_VERSION 1
+#define PA_ABI_VERSION 2
 
 /* ---- graph description (built on the host from a state_dict; see padel_analytics_amd/graph.py) ---- */
 
@@ -62,6 +62,13 @@ typedef struct pa_op_desc {
 
 enum pa_task { PA_TASK_DETECT = 0, PA_TASK_POSE = 1, PA_TASK_TRACKNET = 2 };
 
+/* PA_DTYPE_F32: the parity path (fp32 storage, fp32 MFMA: what the reference computes with half=False).
+ * PA_DTYPE_F16 (detect / pose only; BASELINE configs[4]): activations and conv weights are fp16, accumulation fp32
+ * (v_mfma_f32_16x16x32_f16), biases / stem weights / the Detect-Pose head maps (head_buf) stay fp32; conv weights sit
+ * in the blob as fp16 [npad][Ktot] with K order (64-channel chunk, tap, 32-channel half), cin % 32 == 0,
+ * w_off still counts 4-byte blob words.                                                                      */
+enum pa_dtype { PA_DTYPE_F32 = 0, PA_DTYPE_F16 = 1 };
+
 typedef struct pa_model_desc {
     int32_t task;
     int32_t nc;                 /* classes (detect / pose)                                          */
@@ -73,6 +80,7 @@ typedef struct pa_model_desc {
     int32_t head_buf[3];        /* detect/pose: per-level head maps, channels >= 64 + nc + nk (pixel stride);
                                    tracknet: head_buf[0] = output heat-map buffer                   */
     int32_t in_channels;        /* tracknet: channels of the fp32 input buffer (buffer 0)           */
+    int32_t dtype;              /* enum pa_dtype: storage type of activations and conv weights      */
 } pa_model_desc;
 
 /* ---- engine ---- */

@@ -207,6 +207,11 @@ int pa_memcpy_d2h(pa_engine* e, void* dst, const void* src, size_t n) {
 // ------------------------------------------------------------------------------- model
 static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) {
     if (d->n_bufs <= 0 || d->n_ops <= 0 || !d->bufs || !d->ops) PA_FAIL(e, "model desc: empty graph");
+    const bool f16 = d->dtype == PA_DTYPE_F16;
+    if (d->dtype != PA_DTYPE_F32 && d->dtype != PA_DTYPE_F16) PA_FAIL(e, "model desc: dtype %d", d->dtype);
+    // (a TASK_TRACKNET graph in fp16 is a generic op list run through pa_tracknet_infer — conv unit tests; the ball
+    // session itself is fp32 only, see pa_ball_create)
+    const int kalign = f16 ? 31 : 15, valign = f16 ? 7 : 3;      // conv K granularity, 16-byte vector granularity (elements)
     for (int i = 0; i < d->n_bufs; ++i)
         if (d->bufs[i].level < 0 || d->bufs[i].level > 6 || d->bufs[i].channels <= 0 || (d->bufs[i].channels & 3))
             PA_FAIL(e, "model desc: buffer %d (level %d, channels %d)", i, d->bufs[i].level, d->bufs[i].channels);
@@ -218,10 +223,10 @@ static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) 
         if (!okslice(o.out_buf, o.out_choff, o.cout)) PA_FAIL(e, "op %d: bad output slice", i);
         if (o.kind != PA_OP_STEM && !okslice(o.in_buf, o.in_choff, o.cin)) PA_FAIL(e, "op %d: bad input slice", i);
         if (o.kind == PA_OP_CONV) {
-            if ((o.cin & 15) || (o.in_choff & 3) || (o.ksize != 1 && o.ksize != 3) || (o.stride != 1 && o.stride != 2))
-                PA_FAIL(e, "op %d: unsupported conv (cin %d k %d s %d)", i, o.cin, o.ksize, o.stride);
+            if ((o.cin & kalign) || (o.in_choff & valign) || (o.ksize != 1 && o.ksize != 3) || (o.stride != 1 && o.stride != 2))
+                PA_FAIL(e, "op %d: unsupported conv (cin %d choff %d k %d s %d)", i, o.cin, o.in_choff, o.ksize, o.stride);
             if (o.npad < o.cout || (o.npad & 15)) PA_FAIL(e, "op %d: npad %d for cout %d", i, o.npad, o.cout);
-            const size_t wn = (size_t)o.npad * o.cin * o.ksize * o.ksize;
+            const size_t wn = (size_t)o.npad * o.cin * o.ksize * o.ksize / (f16 ? 2 : 1);
             if (o.w_off < 0 || (o.w_off & 3) || (size_t)o.w_off + wn > n_floats || o.b_off < 0 ||
                 (size_t)o.b_off + o.npad > n_floats)
                 PA_FAIL(e, "op %d: weights outside the blob", i);
@@ -233,13 +238,13 @@ static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) 
                 PA_FAIL(e, "op %d: bad stem", i);
             if (d->bufs[o.out_buf].level != 1) PA_FAIL(e, "op %d: stem output must be level 1", i);
         } else if (o.kind == PA_OP_SPPF_POOL) {
-            if ((o.cin & 3) || o.in_buf != o.out_buf || !okslice(o.in_buf, o.in_choff, 4 * o.cin))
+            if ((o.cin & valign) || (o.in_choff & valign) || o.in_buf != o.out_buf || !okslice(o.in_buf, o.in_choff, 4 * o.cin))
                 PA_FAIL(e, "op %d: bad sppf slices", i);
         } else if (o.kind == PA_OP_UPSAMPLE2X) {
-            if (d->bufs[o.out_buf].level != d->bufs[o.in_buf].level - 1 || o.cin != o.cout || (o.cin & 3))
+            if (d->bufs[o.out_buf].level != d->bufs[o.in_buf].level - 1 || o.cin != o.cout || ((o.cin | o.in_choff | o.out_choff) & valign))
                 PA_FAIL(e, "op %d: bad upsample", i);
         } else if (o.kind == PA_OP_MAXPOOL2) {
-            if (d->bufs[o.out_buf].level != d->bufs[o.in_buf].level + 1 || o.cin != o.cout || (o.cin & 3))
+            if (d->bufs[o.out_buf].level != d->bufs[o.in_buf].level + 1 || o.cin != o.cout || ((o.cin | o.in_choff | o.out_choff) & valign))
                 PA_FAIL(e, "op %d: bad maxpool", i);
         } else {
             PA_FAIL(e, "op %d: unknown kind %d", i, o.kind);
@@ -398,12 +403,18 @@ static int plan_buffers(pa_model* m, int batch) {
         if (o.kind == PA_OP_CONV && o.res_buf >= 0) touch(o.res_buf, i);
     }
     if (m->d.task == PA_TASK_TRACKNET) touch(0, -1);
+    const bool f16 = m->d.dtype == PA_DTYPE_F16;
+    auto is_head = [&](int b) { return b == m->d.head_buf[0] || b == m->d.head_buf[1] || b == m->d.head_buf[2]; };
     for (int l = 0; l < 3; ++l) touch(m->d.head_buf[l], nops + 1);
+    // fp16 models: the head maps are the only fp32 buffers; they never share bytes with fp16 buffers, so a pad
+    // channel that is read under a zero weight always holds a finite fp16 value, never reinterpreted fp32 bits
+    if (f16) for (int l = 0; l < 3; ++l) touch(m->d.head_buf[l], -1);
     std::vector<size_t> bytes(nb), off(nb, 0);
     size_t logical = 0;
     for (int i = 0; i < nb; ++i) {
         const size_t H = m->net_h >> m->bufs[i].level, W = m->net_w >> m->bufs[i].level;
-        bytes[i] = ((size_t)batch * H * W * m->bufs[i].channels * sizeof(float) + kConvReadSlack + 255) & ~(size_t)255;
+        const size_t es = (f16 && !is_head(i)) ? 2 : 4;
+        bytes[i] = ((size_t)batch * H * W * m->bufs[i].channels * es + kConvReadSlack + 255) & ~(size_t)255;
         logical += bytes[i];
     }
     size_t total = 0;
@@ -550,11 +561,15 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.tune = e->t.tune; a.tap_pd = e->t.tap_pd;
             // kernel choice: tap kernels (conv_tap.hip) unless tuning asks for the LDS cross-check kernel; a forced
             // variant picks the tile of whichever kernel is selected
-            const bool use_tap = e->t.impl == 0;
+            const bool f16 = m->d.dtype == PA_DTYPE_F16;
+            const bool use_tap = e->t.impl == 0 || f16;
+            a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
             const int lv = e->t.variant >= 0 ? e->t.variant
-                                             : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
+                           : f16 ? choose_conv_tap16_variant(a.M, a.n16)
+                                 : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
             int bm = 0, bn = 0;
-            conv_variant_shape(lv, &bm, &bn);                        // profile rows carry BM, BN of the workgroup tile
+            if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
+            else conv_variant_shape(lv, &bm, &bn);                   // profile rows carry BM, BN of the workgroup tile
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
             if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = bm; pr->nf = bn; }
             // tuning only ("timeline"): collect the s_memtime timeline of this launch into timeline_path
@@ -566,7 +581,9 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
                 else dbg_dev = nullptr;
                 a.dbg = dbg_dev;
             }
-            if (use_tap) {
+            if (f16) {
+                r = launch_conv_tap16(a, lv, s);
+            } else if (use_tap) {
                 r = launch_conv_tap(a, lv, s);
                 if (r == hipErrorNotSupported && e->t.variant < 0) r = launch_conv_lds(a, choose_conv_lds_variant(a.M, a.n16), s);
             } else {
@@ -584,19 +601,21 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.in = m->d_netin; a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;
             a.out = m->bptr[o.out_buf]; a.out_cs = ob.channels; a.out_choff = o.out_choff;
             a.H = m->net_h; a.W = m->net_w; a.Ho = Ho; a.Wo = Wo; a.cout = o.cout; a.B = n;
+            a.out_f16 = m->d.dtype == PA_DTYPE_F16;
             pr = prof_begin(m, (*pi)++, o.kind, 3, 2.0 * n * Ho * Wo * (double)o.cout * 27);
             r = launch_stem(a, s);
         } else if (o.kind == PA_OP_SPPF_POOL) {
             pr = prof_begin(m, (*pi)++, o.kind, 5, 0.0);
-            r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s);
+            r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s,
+                                 m->d.dtype == PA_DTYPE_F16);
         } else if (o.kind == PA_OP_UPSAMPLE2X) {
             pr = prof_begin(m, (*pi)++, o.kind, 0, 0.0);
             r = launch_upsample2x(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
-                                  ob.channels, o.out_choff, o.cin, n, Ho / 2, Wo / 2, s);
+                                  ob.channels, o.out_choff, o.cin, n, Ho / 2, Wo / 2, s, m->d.dtype == PA_DTYPE_F16);
         } else if (o.kind == PA_OP_MAXPOOL2) {
             pr = prof_begin(m, (*pi)++, o.kind, 2, 0.0);
             r = launch_maxpool2(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
-                                ob.channels, o.out_choff, o.cin, n, Ho * 2, Wo * 2, s);
+                                ob.channels, o.out_choff, o.cin, n, Ho * 2, Wo * 2, s, m->d.dtype == PA_DTYPE_F16);
         }
         prof_end(m, pr);
         if (r != hipSuccess) PA_FAIL(e, "op %zu (kind %d) launch failed: %s", i, o.kind, hipGetErrorString(r));
@@ -804,11 +823,12 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
     const int cin = m->bufs[0].channels;
     const int ob = m->d.head_buf[0];
     const int cout = m->bufs[ob].channels;
+    const size_t es_in = m->d.dtype == PA_DTYPE_F16 ? 2 : 4;     // fp16 graphs take their input as halves
     size_t pi = 0;
     for (int c0 = 0; c0 < n; c0 += m->max_batch) {
         const int nb = std::min(m->max_batch, n - c0);
-        const size_t in_bytes = (size_t)nb * h * w * cin * sizeof(float);
-        PA_HIP(e, hipMemcpyAsync(m->bptr[0], x + (size_t)c0 * h * w * cin, in_bytes,
+        const size_t in_bytes = (size_t)nb * h * w * cin * es_in;
+        PA_HIP(e, hipMemcpyAsync(m->bptr[0], reinterpret_cast<const char*>(x) + (size_t)c0 * h * w * cin * es_in, in_bytes,
                                  x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
         if (run_graph(m, nb, &pi)) return 1;
         const size_t ohw = (size_t)(h >> m->bufs[ob].level) * (w >> m->bufs[ob].level);
@@ -848,7 +868,7 @@ void pa_ball_destroy(pa_ball* b);
 int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
     if (!m || !out) return 1;
     pa_engine* e = m->e;
-    if (m->d.task != PA_TASK_TRACKNET) PA_FAIL(e, "pa_ball_create: not a TrackNet model");
+    if (m->d.task != PA_TASK_TRACKNET || m->d.dtype != PA_DTYPE_F32) PA_FAIL(e, "pa_ball_create: not an fp32 TrackNet model");
     if (m->bufs[0].channels != 32) PA_FAIL(e, "pa_ball_create: TrackNet input buffer must have 32 channels (27 + pad)");
     PA_HIP(e, hipSetDevice(e->dev));
     if (src_h <= 0 || src_w <= 0) PA_FAIL(e, "pa_ball_create: unsupported source size %dx%d", src_w, src_h);

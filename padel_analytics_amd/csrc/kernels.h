@@ -32,6 +32,7 @@ struct ConvArgs {
     int n_mtiles;         // ceil(M / (4 * MF * 16))
     int tune;             // bit 0: s_setprio(1) around MFMA clusters; bit 1: staggered workgroup start
     int tap_pd;           // 1x1 tap kernel: prefetch distance 2 or 3 (pa_engine_set_tuning "tap_pd")
+    int out_f32;          // fp16 kernels only: 1 = `out` is an fp32 buffer (convs that feed the Detect/Pose decode)
     unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_lds.hip DIAG 16
     // m / (Ho*Wo) and rem / Wo without an integer-division sequence (conv_tap.hip prologue): q = (umulhi(n, magic) + n) >> shift,
     // exact for 0 <= n < 2^31 (fill_fastdiv below; the conv kernels' rows satisfy n < 2^31)
@@ -59,25 +60,32 @@ bool conv_variant_shape(int variant, int* bm, int* bn);                         
 hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s);      // ids 6,7,9..15,20
 constexpr size_t kConvReadSlack = 512;
 int choose_conv_tap_variant(int M, int n16);
+// fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and
+// choff count elements); cin % 32 == 0; weights packed [Npad][Ktot] with K order (64-channel chunk, tap, 32-channel half)
+hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s);
+int choose_conv_tap16_variant(int M, int n16);
+bool conv_tap16_variant_shape(int variant, int* bm, int* bn);
 
 struct StemArgs {
     const uint8_t* in;    // net input u8 NHWC4 [B][H][W][4]
     const float* w;       // [cout][27] (ky,kx,c) fused BN
     const float* bias;    // [cout]
-    float* out;           // NHWC fp32, pixel stride out_cs
+    float* out;           // NHWC fp32 (or fp16 with out_f16), pixel stride out_cs
     int out_cs, out_choff;
     int H, W, Ho, Wo, cout, B;
+    int out_f16;          // 1: `out` is a _Float16 buffer (fp16 models; the stem itself computes in fp32)
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
 
 // SPPF: three chained MaxPool2d(5,1,2) of slice [choff, choff+c) written to the next three slices
-hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s);
+// (f16 != 0 in these three: the buffers hold _Float16 elements; cs / choff / c count elements, c % 8 == 0)
+hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16 = 0);
 // nearest x2 upsample of a slice into a slice of a buffer with twice the spatial size
 hipError_t launch_upsample2x(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
-                             int c, int B, int H, int W, hipStream_t s);
+                             int c, int B, int H, int W, hipStream_t s, int f16 = 0);
 // MaxPool2d(2,2)
 hipError_t launch_maxpool2(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
-                           int c, int B, int H, int W, hipStream_t s);
+                           int c, int B, int H, int W, hipStream_t s, int f16 = 0);
 
 // ---- preprocessing -----------------------------------------------------------------
 struct LetterboxArgs {

@@ -12,6 +12,18 @@
 namespace padel {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// 16-byte vectors of the two activation types: 4 floats or 8 halves (pools / upsample work on whole vectors)
+template <typename V> struct VecT;
+template <> struct VecT<f32x4> { static constexpr int N = 4; using E = float; };
+template <> struct VecT<f16x8> { static constexpr int N = 8; using E = _Float16; };
+template <typename V> __device__ __forceinline__ V vmax(V a, V b) {
+    V r;
+#pragma unroll
+    for (int i = 0; i < VecT<V>::N; ++i) r[i] = a[i] > b[i] ? a[i] : b[i];
+    return r;
+}
 
 // ------------------------------------------------------------------------------ letterbox
 __global__ void __launch_bounds__(256) letterbox_kernel(const LetterboxArgs a) {
@@ -132,6 +144,7 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
         }
     }
     float* o = a.out + p * a.out_cs + a.out_choff + cg * 16;
+    _Float16* oh = reinterpret_cast<_Float16*>(a.out) + p * a.out_cs + a.out_choff + cg * 16;
 #pragma unroll
     for (int c4 = 0; c4 < 4; ++c4) {
         f32x4 r;
@@ -143,7 +156,12 @@ __global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
             for (int k = 0; k < 27; ++k) acc = fmaf(x[k], ws[c * 27 + k], acc);
             r[cc] = acc / (1.0f + expf(-acc));
         }
-        *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+        if (a.out_f16) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) oh[c4 * 4 + cc] = (_Float16)r[cc];
+        } else {
+            *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+        }
     }
 }
 
@@ -155,8 +173,10 @@ hipError_t launch_stem(const StemArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------ pools / upsample
-__global__ void __launch_bounds__(256) pool5_kernel(float* buf, int cs, int src_off, int dst_off, int c4n,
+template <typename V>
+__global__ void __launch_bounds__(256) pool5_kernel(typename VecT<V>::E* buf, int cs, int src_off, int dst_off, int c4n,
                                                      int B, int H, int W) {
+    constexpr int VN = VecT<V>::N;
     const long long total = (long long)B * H * W * c4n;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
     if (i >= total) return;
@@ -165,34 +185,39 @@ __global__ void __launch_bounds__(256) pool5_kernel(float* buf, int cs, int src_
     const int x = (int)(t % W); t /= W;
     const int y = (int)(t % H);
     const int n = (int)(t / H);
-    f32x4 m = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    V m = *reinterpret_cast<const V*>(buf + (((long long)n * H + y) * W + x) * cs + src_off + c4 * VN);   // the centre is always inside
     for (int dy = -2; dy <= 2; ++dy) {
         const int yy = y + dy;
         if ((unsigned)yy >= (unsigned)H) continue;
         for (int dx = -2; dx <= 2; ++dx) {
             const int xx = x + dx;
             if ((unsigned)xx >= (unsigned)W) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(buf + (((long long)n * H + yy) * W + xx) * cs + src_off + c4 * 4);
-            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            m = vmax(m, *reinterpret_cast<const V*>(buf + (((long long)n * H + yy) * W + xx) * cs + src_off + c4 * VN));
         }
     }
-    *reinterpret_cast<f32x4*>(buf + (((long long)n * H + y) * W + x) * cs + dst_off + c4 * 4) = m;
+    *reinterpret_cast<V*>(buf + (((long long)n * H + y) * W + x) * cs + dst_off + c4 * VN) = m;
 }
 
-hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s) {
-    const long long total = (long long)B * H * W * (c / 4);
+hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16) {
+    const int vn = f16 ? 8 : 4;
+    const long long total = (long long)B * H * W * (c / vn);
     const unsigned grid = (unsigned)((total + 255) / 256);
     for (int k = 0; k < 3; ++k) {
-        hipLaunchKernelGGL(pool5_kernel, dim3(grid), dim3(256), 0, s, buf, cs, choff + k * c, choff + (k + 1) * c,
-                           c / 4, B, H, W);
+        if (f16) hipLaunchKernelGGL(pool5_kernel<f16x8>, dim3(grid), dim3(256), 0, s, reinterpret_cast<_Float16*>(buf), cs,
+                                    choff + k * c, choff + (k + 1) * c, c / vn, B, H, W);
+        else hipLaunchKernelGGL(pool5_kernel<f32x4>, dim3(grid), dim3(256), 0, s, buf, cs, choff + k * c, choff + (k + 1) * c,
+                                c / vn, B, H, W);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     return hipSuccess;
 }
 
-__global__ void __launch_bounds__(256) upsample2x_kernel(const float* in, int in_cs, int in_choff, float* out,
-                                                          int out_cs, int out_choff, int c4n, int B, int H, int W) {
+template <typename V>
+__global__ void __launch_bounds__(256) upsample2x_kernel(const typename VecT<V>::E* in, int in_cs, int in_choff,
+                                                          typename VecT<V>::E* out, int out_cs, int out_choff, int c4n,
+                                                          int B, int H, int W) {
+    constexpr int VN = VecT<V>::N;
     const int Ho = H * 2, Wo = W * 2;
     const long long total = (long long)B * Ho * Wo * c4n;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
@@ -202,20 +227,27 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const float* in, int in
     const int x = (int)(t % Wo); t /= Wo;
     const int y = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(in + (((long long)n * H + (y >> 1)) * W + (x >> 1)) * in_cs + in_choff + c4 * 4);
-    *reinterpret_cast<f32x4*>(out + (((long long)n * Ho + y) * Wo + x) * out_cs + out_choff + c4 * 4) = v;
+    const V v = *reinterpret_cast<const V*>(in + (((long long)n * H + (y >> 1)) * W + (x >> 1)) * in_cs + in_choff + c4 * VN);
+    *reinterpret_cast<V*>(out + (((long long)n * Ho + y) * Wo + x) * out_cs + out_choff + c4 * VN) = v;
 }
 
 hipError_t launch_upsample2x(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
-                             int c, int B, int H, int W, hipStream_t s) {
-    const long long total = (long long)B * H * 2 * W * 2 * (c / 4);
-    hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_cs, in_choff,
-                       out, out_cs, out_choff, c / 4, B, H, W);
+                             int c, int B, int H, int W, hipStream_t s, int f16) {
+    const int vn = f16 ? 8 : 4;
+    const long long total = (long long)B * H * 2 * W * 2 * (c / vn);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (f16) hipLaunchKernelGGL(upsample2x_kernel<f16x8>, grid, dim3(256), 0, s, reinterpret_cast<const _Float16*>(in), in_cs,
+                                in_choff, reinterpret_cast<_Float16*>(out), out_cs, out_choff, c / vn, B, H, W);
+    else hipLaunchKernelGGL(upsample2x_kernel<f32x4>, grid, dim3(256), 0, s, in, in_cs, in_choff, out, out_cs, out_choff,
+                            c / vn, B, H, W);
     return hipGetLastError();
 }
 
-__global__ void __launch_bounds__(256) maxpool2_kernel(const float* in, int in_cs, int in_choff, float* out,
-                                                        int out_cs, int out_choff, int c4n, int B, int H, int W) {
+template <typename V>
+__global__ void __launch_bounds__(256) maxpool2_kernel(const typename VecT<V>::E* in, int in_cs, int in_choff,
+                                                        typename VecT<V>::E* out, int out_cs, int out_choff, int c4n,
+                                                        int B, int H, int W) {
+    constexpr int VN = VecT<V>::N;
     const int Ho = H / 2, Wo = W / 2;
     const long long total = (long long)B * Ho * Wo * c4n;
     const long long i = blockIdx.x * 256ll + threadIdx.x;
@@ -225,24 +257,23 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const float* in, int in_c
     const int x = (int)(t % Wo); t /= Wo;
     const int y = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    const float* p = in + (((long long)n * H + 2 * y) * W + 2 * x) * in_cs + in_choff + c4 * 4;
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(p);
-    const f32x4 a1 = *reinterpret_cast<const f32x4*>(p + in_cs);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p + (long long)W * in_cs);
-    const f32x4 b1 = *reinterpret_cast<const f32x4*>(p + (long long)W * in_cs + in_cs);
-    f32x4 m;
-    m.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(b0.x, b1.x));
-    m.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(b0.y, b1.y));
-    m.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(b0.z, b1.z));
-    m.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(b0.w, b1.w));
-    *reinterpret_cast<f32x4*>(out + (((long long)n * Ho + y) * Wo + x) * out_cs + out_choff + c4 * 4) = m;
+    const auto* p = in + (((long long)n * H + 2 * y) * W + 2 * x) * in_cs + in_choff + c4 * VN;
+    const V a0 = *reinterpret_cast<const V*>(p);
+    const V a1 = *reinterpret_cast<const V*>(p + in_cs);
+    const V b0 = *reinterpret_cast<const V*>(p + (long long)W * in_cs);
+    const V b1 = *reinterpret_cast<const V*>(p + (long long)W * in_cs + in_cs);
+    *reinterpret_cast<V*>(out + (((long long)n * Ho + y) * Wo + x) * out_cs + out_choff + c4 * VN) = vmax(vmax(a0, a1), vmax(b0, b1));
 }
 
 hipError_t launch_maxpool2(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
-                           int c, int B, int H, int W, hipStream_t s) {
-    const long long total = (long long)B * (H / 2) * (W / 2) * (c / 4);
-    hipLaunchKernelGGL(maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, in_cs, in_choff,
-                       out, out_cs, out_choff, c / 4, B, H, W);
+                           int c, int B, int H, int W, hipStream_t s, int f16) {
+    const int vn = f16 ? 8 : 4;
+    const long long total = (long long)B * (H / 2) * (W / 2) * (c / vn);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (f16) hipLaunchKernelGGL(maxpool2_kernel<f16x8>, grid, dim3(256), 0, s, reinterpret_cast<const _Float16*>(in), in_cs,
+                                in_choff, reinterpret_cast<_Float16*>(out), out_cs, out_choff, c / vn, B, H, W);
+    else hipLaunchKernelGGL(maxpool2_kernel<f32x4>, grid, dim3(256), 0, s, in, in_cs, in_choff, out, out_cs, out_choff,
+                            c / vn, B, H, W);
     return hipGetLastError();
 }
 

@@ -43,7 +43,7 @@ class pa_model_desc(C.Structure):
     _fields_ = [("task", C.c_int32), ("nc", C.c_int32), ("nk", C.c_int32), ("kpt_dim", C.c_int32),
                 ("n_bufs", C.c_int32), ("bufs", C.POINTER(pa_buf_desc)),
                 ("n_ops", C.c_int32), ("ops", C.POINTER(pa_op_desc)),
-                ("head_buf", C.c_int32 * 3), ("in_channels", C.c_int32)]
+                ("head_buf", C.c_int32 * 3), ("in_channels", C.c_int32), ("dtype", C.c_int32)]
 
 
 class pa_yolo_params(C.Structure):
@@ -136,7 +136,7 @@ def load_library():
     lib.pa_bytetrack_reset.argtypes = [vp]
     lib.pa_bytetrack_reset.restype = None
     lib.pa_bytetrack_update_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp]
-    if lib.pa_abi_version() != 1:
+    if lib.pa_abi_version() != 2:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -273,7 +273,8 @@ class Model:
             for k, v in o.items():
                 setattr(ops[i], k, int(v))
         d = pa_model_desc(task=graph.task, nc=graph.nc, nk=graph.nk, kpt_dim=graph.kpt_dim, n_bufs=len(graph.bufs),
-                          bufs=bufs, n_ops=len(graph.ops), ops=ops, in_channels=graph.in_channels)
+                          bufs=bufs, n_ops=len(graph.ops), ops=ops, in_channels=graph.in_channels,
+                          dtype=getattr(graph, "dtype", 0))
         for i in range(3):
             d.head_buf[i] = graph.head_buf[i] if i < len(graph.head_buf) else -1
         h = C.c_void_p()
@@ -338,8 +339,8 @@ class Model:
         return a.value, l.value
 
     def tracknet_infer(self, x: np.ndarray) -> np.ndarray:
-        """x: (n, H, W, C_in) fp32 NHWC -> (n, H, W, C_out) fp32."""
-        x = np.ascontiguousarray(x, np.float32)
+        """x: (n, H, W, C_in) NHWC (fp32; fp16 for a graph with dtype f16) -> (n, H, W, C_out) fp32."""
+        x = np.ascontiguousarray(x, np.float16 if getattr(self.graph, "dtype", 0) == G.DTYPE_F16 else np.float32)
         n, h, w, c = x.shape
         assert c == self.graph.bufs[0][1], (c, self.graph.bufs[0])
         lvl, cout = self.graph.bufs[self.graph.head_buf[0]]

@@ -26,34 +26,36 @@ from . import yolo_arch
 OP_STEM, OP_CONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_MAXPOOL2 = 1, 2, 3, 4, 5
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 TASK_DETECT, TASK_POSE, TASK_TRACKNET = 0, 1, 2
+DTYPE_F32, DTYPE_F16 = 0, 1
 
 
 def pad16(c: int) -> int:
     return (c + 15) // 16 * 16
 
 
-def kstep_order(cin: int, ksize: int):
-    """[(tap, c0)] in the order conv_igemm.hip walks K (cin must be a multiple of 16)."""
+def kstep_order(cin: int, ksize: int, kc: int = 16):
+    """[(tap, c0)] in the order the conv kernels walk K: k-steps of ``kc`` channels (one 64-byte run: 16 fp32 or
+    32 fp16), grouped (2*kc-channel chunk, tap, half); cin must be a multiple of kc."""
     taps = ksize * ksize
     steps = []
-    for c32 in range(cin // 32):
+    for c in range(cin // (2 * kc)):
         for tap in range(taps):
             for half in (0, 1):
-                steps.append((tap, c32 * 32 + half * 16))
-    if cin % 32:
+                steps.append((tap, c * 2 * kc + half * kc))
+    if cin % (2 * kc):
         for tap in range(taps):
-            steps.append((tap, (cin // 32) * 32))
+            steps.append((tap, (cin // (2 * kc)) * 2 * kc))
     return steps
 
 
-def pack_conv_weight(w: np.ndarray) -> np.ndarray:
-    """(Cout, Cin, k, k) fp32 with Cout, Cin multiples of 16 -> [Cout][Ktot] in kernel K order."""
+def pack_conv_weight(w: np.ndarray, kc: int = 16) -> np.ndarray:
+    """(Cout, Cin, k, k) fp32 with Cout multiple of 16, Cin multiple of kc -> [Cout][Ktot] in kernel K order."""
     cout, cin, k, _ = w.shape
-    assert cout % 16 == 0 and cin % 16 == 0
-    steps = kstep_order(cin, k)
-    out = np.empty((cout, len(steps) * 16), np.float32)
+    assert cout % 16 == 0 and cin % kc == 0
+    steps = kstep_order(cin, k, kc)
+    out = np.empty((cout, len(steps) * kc), np.float32)
     for i, (tap, c0) in enumerate(steps):
-        out[:, i * 16:(i + 1) * 16] = w[:, c0:c0 + 16, tap // k, tap % k]
+        out[:, i * kc:(i + 1) * kc] = w[:, c0:c0 + kc, tap // k, tap % k]
     return out
 
 
@@ -83,6 +85,15 @@ class Graph:
     head_buf: tuple = (-1, -1, -1)
     in_channels: int = 0
     out_channels: int = 0
+    dtype: int = DTYPE_F32                        # storage type of activations / conv weights (pa_dtype)
+
+    @property
+    def kalign(self) -> int:
+        """Channel granularity of a conv's input slice: one 64-byte k-step (16 fp32 / 32 fp16 channels)."""
+        return 32 if self.dtype == DTYPE_F16 else 16
+
+    def padk(self, c: int) -> int:
+        return (c + self.kalign - 1) // self.kalign * self.kalign
 
     # ---- construction helpers
     def buf(self, level: int, channels: int) -> int:
@@ -105,14 +116,25 @@ class Graph:
         to ``out_width`` (those rows are zero, so the kernel writes act(0) there)."""
         sb, so, sw = src
         cout, cin = w.shape[:2]
-        assert sw % 16 == 0 and sw >= cin, (sw, cin)
+        if sw % self.kalign:
+            # the slice is narrower than a whole number of k-steps: read on into the neighbouring channels of the
+            # same buffer under ZERO weights (they hold finite activations, or the buffer is widened with pad
+            # channels that stay zero / finite) — fp16 k-steps are 32 channels wide, yolov8's C2f halves are not
+            sw = self.padk(sw)
+            lvl, ch = self.bufs[sb]
+            if so + sw > ch:
+                self.bufs[sb] = (lvl, so + sw)
+        assert sw % self.kalign == 0 and sw >= cin, (sw, cin)
         ow = cout if out_width is None else out_width
         npad = pad16(ow)
         wp = np.zeros((npad, sw, k, k), np.float32)
         wp[:cout, :cin] = w
         bp = np.zeros(npad, np.float32)
         bp[:cout] = b
-        w_off = self._add(pack_conv_weight(wp))
+        if self.dtype == DTYPE_F16:
+            w_off = self._add(np.ascontiguousarray(pack_conv_weight(wp, 32).astype(np.float16)).view(np.float32))
+        else:
+            w_off = self._add(pack_conv_weight(wp))
         b_off = self._add(bp)
         self.ops.append(dict(kind=OP_CONV, in_buf=sb, in_choff=so, cin=sw, out_buf=dst[0], out_choff=dst[1],
                              cout=ow, ksize=k, stride=s, act=act, res_buf=-1 if res is None else res[0],
@@ -134,14 +156,19 @@ class Graph:
         return total
 
 
-def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None) -> Graph:
-    """YOLOv8 detect / pose graph (SURVEY.md Appendix A layer table) over the engine's op set."""
+def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f32") -> Graph:
+    """YOLOv8 detect / pose graph (SURVEY.md Appendix A layer table) over the engine's op set.
+
+    ``dtype="f16"`` (BASELINE configs[4]): same graph with fp16 activations and conv weights (fp32 accumulate, fp32
+    biases, fp32 Detect/Pose head maps); BatchNorm is folded in fp32 first, then the folded weights are rounded to
+    fp16 once — what ``model.half()`` after ``fuse()`` does upstream."""
     info = yolo_arch.infer_arch_from_state_dict(sd)
     d = yolo_arch.arch_dims(info["scale"])
     assert info["nc"] == nc, (info, nc)
     c2h, c3h, c4h, nk = yolo_arch.head_dims(d, nc, kpt_shape)
     assert nk == info["nk"], (nk, info)
-    g = Graph(task=TASK_POSE if kpt_shape else TASK_DETECT, nc=nc, nk=nk, kpt_dim=int(kpt_shape[1]) if kpt_shape else 0)
+    g = Graph(task=TASK_POSE if kpt_shape else TASK_DETECT, nc=nc, nk=nk, kpt_dim=int(kpt_shape[1]) if kpt_shape else 0,
+              dtype={"f32": DTYPE_F32, "f16": DTYPE_F16}[dtype])
     eps = yolo_arch.BN_EPS
     fuse = lambda p: fold_bn(sd, p, eps)
 
@@ -160,24 +187,30 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None) -> Graph:
         c = cout // 2
         assert c % 16 == 0
         cat = g.buf(level, (2 + n) * c)
-        tmp = g.buf(level, c)
+        ct = g.padk(c)                  # the scratch between a bottleneck's two convs is written at k-step width
+        tmp = g.buf(level, ct)
         cbs(f"model.{i}.cv1", src, (cat, 0), 1, 1)
         for j in range(n):
-            cbs(f"model.{i}.m.{j}.cv1", (cat, (1 + j) * c, c), (tmp, 0), 3, 1)
-            cbs(f"model.{i}.m.{j}.cv2", (tmp, 0, c), (cat, (2 + j) * c), 3, 1,
+            cbs(f"model.{i}.m.{j}.cv1", (cat, (1 + j) * c, c), (tmp, 0), 3, 1, out_width=ct if ct != c else None)
+            cbs(f"model.{i}.m.{j}.cv2", (tmp, 0, ct), (cat, (2 + j) * c), 3, 1,
                 res=(cat, (1 + j) * c) if shortcut else None)
         cbs(f"model.{i}.cv2", (cat, 0, (2 + n) * c), dst, 1, 1)
 
     c1, c2, c3, c4, c5 = d.c1, d.c2, d.c3, d.c4, d.c5
     # stem: straight from the u8 network input
-    b0 = g.buf(1, c1)
+    c1p = g.padk(c1)               # stem output at k-step width: zero rows -> SiLU(0) = 0 in the pad channels
+    b0 = g.buf(1, c1p)
     w0, bias0 = fuse("model.0")
-    w_off = g._add(np.ascontiguousarray(w0.transpose(0, 2, 3, 1)).reshape(c1, 27))   # [cout][ky][kx][c]
-    b_off = g._add(bias0)
-    g.ops.append(dict(kind=OP_STEM, in_buf=0, in_choff=0, cin=3, out_buf=b0, out_choff=0, cout=c1, ksize=3, stride=2,
-                      act=ACT_SILU, res_buf=-1, res_choff=0, npad=c1, w_off=w_off, b_off=b_off))
+    w0p = np.zeros((c1p, 27), np.float32)
+    w0p[:c1] = np.ascontiguousarray(w0.transpose(0, 2, 3, 1)).reshape(c1, 27)          # [cout][ky][kx][c]
+    b0p = np.zeros(c1p, np.float32)
+    b0p[:c1] = bias0
+    w_off = g._add(w0p)
+    b_off = g._add(b0p)
+    g.ops.append(dict(kind=OP_STEM, in_buf=0, in_choff=0, cin=3, out_buf=b0, out_choff=0, cout=c1p, ksize=3, stride=2,
+                      act=ACT_SILU, res_buf=-1, res_choff=0, npad=c1p, w_off=w_off, b_off=b_off))
     b1 = g.buf(2, c2)
-    cbs("model.1", (b0, 0, c1), (b1, 0), 3, 2)
+    cbs("model.1", (b0, 0, c1p), (b1, 0), 3, 2)
     b2 = g.buf(2, c2)
     c2f(2, (b1, 0, c2), c2, True, 2, (b2, 0))
     b3 = g.buf(3, c3)
@@ -226,7 +259,7 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None) -> Graph:
     if kpt_shape:
         branches.append(("cv4", c4h, nk, 64 + nc))
     for l, (feat, chn, lvl) in enumerate(((b15, c3, 3), (b18, c4, 4), (b21, c5, 5))):
-        widths = [pad16(wd) for (_, wd, _, _) in branches]
+        widths = [g.padk(wd) for (_, wd, _, _) in branches]
         tot = sum(widths)
         wcat = np.zeros((tot, chn, 3, 3), np.float32)
         bcat = np.zeros(tot, np.float32)

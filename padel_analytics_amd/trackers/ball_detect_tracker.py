@@ -27,9 +27,9 @@ class BallDetectTracker(Tracker):
     streams = False
 
     def __init__(self, model_path: str, batch_size: int, conf: Optional[float] = None,
-                 load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None):
+                 load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None, half: bool = False):
         super().__init__(load_path=load_path, save_path=save_path)
-        self.model = YOLO(model_path)
+        self.model = YOLO(model_path, half=half)
         if self.model.task != "detect":
             raise ValueError(f"{model_path}: BallDetectTracker needs a YOLOv8 detect checkpoint")
         self.batch_size = batch_size

@@ -110,9 +110,9 @@ class PlayerKeypointsTracker(Tracker):
     streams = False
 
     def __init__(self, model_path: str, train_image_size: int, batch_size: int,
-                 load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None):
+                 load_path: Optional[str | Path] = None, save_path: Optional[str | Path] = None, half: bool = False):
         super().__init__(load_path=load_path, save_path=save_path)
-        self.model = YOLO(model_path)
+        self.model = YOLO(model_path, half=half)
         assert train_image_size in (640, 1280)
         self.train_image_size = train_image_size
         self.batch_size = batch_size

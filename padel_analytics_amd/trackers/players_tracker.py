@@ -115,9 +115,9 @@ class PlayerTracker(Tracker):
 
     def __init__(self, model_path: str, polygon_zone, batch_size: int, annotator: str = "rectangle_bounding_box",
                  show_confidence: bool = True, load_path: Optional[str | Path] = None,
-                 save_path: Optional[str | Path] = None):
+                 save_path: Optional[str | Path] = None, half: bool = False):
         super().__init__(load_path=load_path, save_path=save_path)
-        self.model = YOLO(model_path)
+        self.model = YOLO(model_path, half=half)
         self.polygon_zone = polygon_zone
         self.batch_size = batch_size
         self.annotator = annotator

@@ -25,7 +25,7 @@ def frame_seed(f) -> int:
 class FakeYOLO:
     """Stands in for padel_analytics_amd.yolo.YOLO: same infer_frames contract, outputs keyed on frame content."""
 
-    def __init__(self, model_path, engine=None):
+    def __init__(self, model_path, engine=None, half=False):
         self.task = "pose" if "pose" in str(model_path) else "detect"
         self.kpt_shape = (13, 3) if self.task == "pose" else None
         self.names = {0: "person"}

@@ -12,13 +12,20 @@ import torch.nn.functional as F
 from padel_analytics_amd import graph as G
 
 
-def unpack_conv(blob, o):
+def unpack_conv(blob, o, f16: bool = False):
+    """Weights of a conv op back in (npad, cin, k, k) order; fp16 graphs keep them as halves inside the fp32 blob
+    words, 32 channels per k-step (csrc/conv_tap16.hip)."""
     k, cin, npad = o["ksize"], o["cin"], o["npad"]
-    steps = G.kstep_order(cin, k)
-    wp = blob[o["w_off"]:o["w_off"] + npad * len(steps) * 16].reshape(npad, len(steps) * 16)
+    kc = 32 if f16 else 16
+    steps = G.kstep_order(cin, k, kc)
+    n = npad * len(steps) * kc
+    if f16:
+        wp = blob[o["w_off"]:o["w_off"] + n // 2].view(np.float16).astype(np.float32).reshape(npad, len(steps) * kc)
+    else:
+        wp = blob[o["w_off"]:o["w_off"] + n].reshape(npad, len(steps) * kc)
     w = np.zeros((npad, cin, k, k), np.float32)
     for i, (tap, c0) in enumerate(steps):
-        w[:, c0:c0 + 16, tap // k, tap % k] = wp[:, i * 16:(i + 1) * 16]
+        w[:, c0:c0 + kc, tap // k, tap % k] = wp[:, i * kc:(i + 1) * kc]
     b = blob[o["b_off"]:o["b_off"] + npad]
     return w, b
 
@@ -34,29 +41,40 @@ def act(x, a):
 
 
 @torch.no_grad()
-def run(graph: G.Graph, net_in: torch.Tensor = None, buf0: torch.Tensor = None):
+def run(graph: G.Graph, net_in: torch.Tensor = None, buf0: torch.Tensor = None, stale: float = 0.0):
     """net_in: (B,3,H,W) fp32 in [0,1] for YOLO graphs; buf0: (B,C,H,W) for TrackNet graphs.
     Returns the list of buffers as NCHW tensors."""
     blob = graph.blob()
     ref = net_in if net_in is not None else buf0
     B, _, H, W = ref.shape
-    bufs = [torch.zeros(B, c, H >> l, W >> l) for (l, c) in graph.bufs]
+    f16 = getattr(graph, "dtype", 0) == G.DTYPE_F16
+    heads = set(graph.head_buf)
+    # fp16 graphs: what is written to a non-head buffer is rounded to fp16 (storage), arithmetic stays fp32 —
+    # the engine's fp16 path up to the order of the fp32 accumulation.  `stale` fills the buffers first, to prove
+    # that pad channels read under zero weights / never-written channels cannot leak into results.
+    bufs = [torch.full((B, c, H >> l, W >> l), float(stale)) for (l, c) in graph.bufs]
     if buf0 is not None:
         bufs[0][:] = buf0
+
+    def store(bi, lo, val):
+        if f16 and bi not in heads:
+            val = val.half().float()
+        bufs[bi][:, lo:lo + val.shape[1]] = val
+
     for o in graph.ops:
         kd = o["kind"]
         if kd == G.OP_STEM:
             w = torch.from_numpy(blob[o["w_off"]:o["w_off"] + o["cout"] * 27].reshape(o["cout"], 3, 3, 3).transpose(0, 3, 1, 2).copy())
             b = torch.from_numpy(blob[o["b_off"]:o["b_off"] + o["cout"]].copy())
-            bufs[o["out_buf"]][:, o["out_choff"]:o["out_choff"] + o["cout"]] = F.silu(F.conv2d(net_in, w, b, stride=2, padding=1))
+            store(o["out_buf"], o["out_choff"], F.silu(F.conv2d(net_in, w, b, stride=2, padding=1)))
         elif kd == G.OP_CONV:
-            w, b = unpack_conv(blob, o)
+            w, b = unpack_conv(blob, o, f16)
             x = bufs[o["in_buf"]][:, o["in_choff"]:o["in_choff"] + o["cin"]]
             y = act(F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b.copy()), stride=o["stride"], padding=o["ksize"] // 2), o["act"])
             y = y[:, :o["cout"]]
             if o["res_buf"] >= 0:
                 y = y + bufs[o["res_buf"]][:, o["res_choff"]:o["res_choff"] + o["cout"]]
-            bufs[o["out_buf"]][:, o["out_choff"]:o["out_choff"] + o["cout"]] = y
+            store(o["out_buf"], o["out_choff"], y)
         elif kd == G.OP_SPPF_POOL:
             c = o["cin"]
             t = bufs[o["in_buf"]]

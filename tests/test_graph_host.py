@@ -56,3 +56,42 @@ def test_graph_layout_is_weight_independent():
         b = G.build_yolov8(yolo_arch.synth_state_dict(scale, nc, kpt, seed=9, cls_bias=1.5, gain=0.7), nc, kpt)
         assert a.n_floats == b.n_floats and a.bufs == b.bufs and a.ops == b.ops and a.head_buf == b.head_buf
         assert not np.array_equal(a.blob(), b.blob())
+
+
+# ---- fp16 graphs (BASELINE configs[4]): 32-channel k-steps, padded slices, fp16 weight words inside the fp32 blob
+def test_fp16_pack_roundtrip():
+    for cin, k in ((32, 3), (64, 3), (96, 3), (160, 1)):
+        steps = G.kstep_order(cin, k, 32)
+        assert sorted(steps) == sorted((t, c) for t in range(k * k) for c in range(0, cin, 32))
+        w = np.random.default_rng(0).normal(size=(16, cin, k, k)).astype(np.float16).astype(np.float32)
+        g = G.Graph(task=G.TASK_DETECT, dtype=G.DTYPE_F16)
+        b0, b1 = g.buf(0, cin), g.buf(0, 16)
+        g.conv((b0, 0, cin), (b1, 0), w, np.zeros(16, np.float32), k, 1, G.ACT_NONE)
+        wu, _ = graph_interp.unpack_conv(g.blob(), g.ops[0], f16=True)
+        assert np.array_equal(wu, w)
+
+
+@pytest.mark.parametrize("scale,nc,kpt", [("n", 80, None), ("m", 1, (13, 3)), ("s", 1, None)])
+def test_fp16_graph_wiring(scale, nc, kpt):
+    """The fp16 op list computes the same network: interpreted on CPU with fp16 storage rounding it agrees with the
+    fp32 oracle to fp16 accuracy, every conv slice obeys the fp16 kernel's contract, and garbage in pad / not yet
+    written channels (buffers pre-filled with a large finite value) does not reach any result."""
+    sd = yolo_arch.synth_state_dict(scale, nc, kpt, seed=1, gain=1.0)
+    g = G.build_yolov8(sd, nc, kpt, dtype="f16")
+    x = torch.rand(1, 3, 64, 96)
+    bufs = graph_interp.run(g, net_in=x)
+    dirty = graph_interp.run(g, net_in=x, stale=1000.0)
+    m = ref.YoloV8Ref(sd, nc, kpt)
+    with torch.no_grad():
+        det, kp = m.head_raw(m.features(x))
+    for l in range(3):
+        want = det[l] if not kpt else torch.cat([det[l], kp[l]], 1)
+        got = bufs[g.head_buf[l]][:, :want.shape[1]]
+        assert float((got - want).abs().max()) <= 3e-2 * max(1.0, float(want.abs().max())), l
+        assert torch.equal(dirty[g.head_buf[l]][:, :want.shape[1]], got), "stale pad channels leaked into the head"
+    for o in g.ops:
+        if o["kind"] == G.OP_CONV:
+            lvl, ch = g.bufs[o["in_buf"]]
+            assert o["cin"] % 32 == 0 and o["in_choff"] % 8 == 0 and o["in_choff"] + o["cin"] <= ch and o["npad"] % 16 == 0
+        if o["kind"] in (G.OP_SPPF_POOL, G.OP_UPSAMPLE2X):
+            assert o["cin"] % 8 == 0 and o["in_choff"] % 8 == 0 and o["out_choff"] % 8 == 0
