@@ -37,6 +37,8 @@ sys.path.insert(0, str(ROOT))
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_FP16_MFMA_TFLOPS = 2500.0     # same guide: BF16/FP16 MFMA, dense (not the 2:1-sparsity headline)
+# default fp32 path = bf16x3 kernels: every fp32 multiply costs 6 bf16 products on the bf16 pipe
+PEAK_BX3_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 6.0, 1)
 
 # tracker table: name -> (scale, nc, kpt_shape, imgsz, conf, classes, pre_mode, channel_reverse)
 TRACKERS = {
@@ -76,6 +78,9 @@ def parse():
                     help="also time the runner with the clip in pageable host memory: sequential (one upload per "
                          "tracker, like the reference) and fan-out (one upload per batch) — PCIe-inclusive rates")
     ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the op lists (tuning; -1 = engine default)")
+    ap.add_argument("--impl", default="bx3", choices=["bx3", "tap", "lds"],
+                    help="fp32 conv kernels: bx3 (default: exact 3-way bf16 split, 6 products on the bf16 matrix pipe, fp32 "
+                         "accumulate), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the parity path (the reference runs half=False) — the headline; f16: fp16 activations / "
                          "weights with fp32 accumulation (BASELINE configs[4]), reports its own L-inf vs the fp32 oracle")
@@ -192,6 +197,8 @@ def main():
     eng = E.Engine(local)
     if a.graph >= 0:
         eng.set_tuning(graph=a.graph)
+    IMPL = {"tap": 0, "lds": 1, "bx3": 2}
+    eng.set_tuning(impl=IMPL[a.impl])
     # RCCL communicator owned by the library (also with one rank: the broadcast path is exercised at N=1)
     eng.comm_init(D.share_unique_id(E.comm_unique_id), world, rank)
     frames = synth.synthetic_frames(B, H, W, seed=1000 + rank)          # each rank its own shard
@@ -233,6 +240,11 @@ def main():
         "metric": "frames/sec (all trackers) on 1280x720", "value": None, "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "arithmetic": ("fp32 storage; conv products as an EXACT 3-way bf16 split of both operands, 6 of the 9 cross "
+                       "products (dropped: < 2^-24 relative) on v_mfma_f32_16x16x32_bf16, fp32 accumulation — per-conv RMS "
+                       "error vs fp64 <= the fp32-MFMA kernels' (tests/test_gpu_conv.py), same parity criteria" if a.impl == "bx3"
+                       else "fp32 storage, v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate)") if a.dtype == "f32"
+                      else "fp16 storage, v_mfma_f32_16x16x32_f16, fp32 accumulation, fp32 Detect/Pose heads",
         "config": {
             "workload": desc, "frames_per_gpu_per_step": B, "frame_hw": [H, W],
             "trackers": {n: {"graph": f"yolov8{TRACKERS[n]['scale']}-{'pose13x3' if TRACKERS[n]['kpt'] else 'detect'}"
@@ -258,6 +270,18 @@ def main():
         dt_e = eng.allreduce_max(time.perf_counter() - t0)
         out["engine_only"] = {"value": round(world * B * K / dt_e, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_e / K, 3),
                               "what": "the same K steps calling pa_yolo_infer directly: no Detections / PolygonZone / ByteTrack / objects"}
+        if a.dtype == "f32" and a.impl == "bx3":
+            # the same engine-only steps on round 1's fp32-input MFMA kernels, for reference
+            eng.set_tuning(impl=0)
+            engine_step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(K):
+                engine_step()
+            fence()
+            dt_m = eng.allreduce_max(time.perf_counter() - t0)
+            eng.set_tuning(impl=IMPL[a.impl])
+            out["engine_only"]["fp32_mfma_kernels"] = {"value": round(world * B * K / dt_m, 2), "ms_per_step": round(1e3 * dt_m / K, 3)}
         out["config"]["detections_per_step_rank0"] = ndet
         # ---- through the runner (the metric's path)
         if not a.engine_only:
@@ -304,19 +328,23 @@ def main():
         ms1, fl1 = sum(r["ms"] for r in c1), sum(r["flops"] for r in c1)
         ms_all = sum(r["ms"] for r in recs)
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
-        PEAK = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_FP16_MFMA_TFLOPS
+        PEAK = PEAK_FP16_MFMA_TFLOPS if a.dtype == "f16" else (PEAK_BX3_TFLOPS if a.impl == "bx3" else PEAK_FP32_MFMA_TFLOPS)
         traffic = None
         tpath = ROOT / "profiles" / "r2_traffic.json"          # PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc_bench_traffic.sh)
         if tpath.exists():
-            tj = json.loads(tpath.read_text()).get(a.workload)
+            tj = json.loads(tpath.read_text()).get(f"{a.workload}-{a.impl}" if a.dtype == "f32" else "none")
             if tj:
                 traffic = {"bytes_per_launch": tj["bytes_per_launch"], "fetch_bytes_per_launch": tj["fetch_bytes_per_launch"],
                            "write_bytes_per_launch": tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"], "source": tj["source"]}
         out["roofline"] = {
-            "kernel": "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)"
-                      if a.dtype == "f32" else
-                      "conv_tap16_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x32_f16)",
+            "kernel": ("conv_tap16_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x32_f16)"
+                       if a.dtype == "f16" else
+                       "conv_bx3_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, exact bf16x3 split, "
+                       "6 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block)" if a.impl == "bx3" else
+                       "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)"),
+            "peak_note": ("fp32-equivalent TFLOP/s: bf16 MFMA dense peak 2500 / 6 products per multiply; the fp32-input MFMA "
+                          "peak this replaces is 157.3" if (a.dtype == "f32" and a.impl == "bx3") else None),
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
             "frac": round(ach / PEAK, 4), "traffic": traffic if a.dtype == "f32" else None,
             "launches": len(c3), "avg_launch_ms": round(ms3 / max(len(c3), 1), 4),

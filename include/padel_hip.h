@@ -56,7 +56,9 @@ typedef struct pa_op_desc {
     int32_t ksize, stride, act;
     int32_t res_buf, res_choff;         /* residual slice added after the activation; res_buf < 0: none */
     int32_t npad;                       /* PA_OP_CONV: rows of the packed weight matrix (multiple of 16) */
-    int32_t reserved;
+    int32_t reserved;                   /* PA_OP_CONV, fp32 models: offset (in floats, > 0) of the same weights pre-split
+                                           into three bf16 planes for the bf16x3 kernels, [npad][k-step][hi|mid|lo][32];
+                                           0: not provided                                                      */
     int64_t w_off, b_off;               /* offsets (in floats) of packed weights / bias in the blob */
 } pa_op_desc;
 
@@ -104,7 +106,8 @@ int pa_upload(pa_engine* eng, void* dst_dev, const void* src_host, size_t nbytes
 
 /* tuning knobs (tests / tools only).  Defaults come from the environment ONCE at pa_engine_create
  * (PADEL_CONV_IMPL=tap|lds, PADEL_CONV_VARIANT, PADEL_CONV_TUNE, PADEL_CONV_TAP_PD, PADEL_GRAPH, PADEL_ALIAS).
- * keys: "impl" (0 tap kernels, 1 LDS cross-check kernel), "variant" (forced tile id, -1 auto), "tune",
+ * keys: "impl" (2 bf16x3 kernels = default, 0 fp32-MFMA tap kernels, 1 fp32-MFMA LDS cross-check kernel),
+ * "variant" (forced tile id, -1 auto), "tune",
  * "tap_pd" (2|3), "graph" (hipGraph replay of the op list), "alias" (liveness-shared activation arena),
  * "timeline" (s_memtime-instrumented 3x3 kernel, dump to pa_engine_set_timeline_path)                 */
 int pa_engine_set_tuning(pa_engine* eng, const char* key, int value);

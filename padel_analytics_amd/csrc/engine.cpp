@@ -23,7 +23,9 @@ static thread_local std::string g_err;
 // PADEL_CONV_TUNE, PADEL_CONV_TAP_PD, PADEL_GRAPH, PADEL_ALIAS), changed afterwards only through
 // pa_engine_set_tuning — the replay loop never touches getenv.
 struct Tuning {
-    int impl = 0;        // 0: tap-unrolled LDS-DMA kernels (default), 1: LDS kernel (the bitwise cross-check)
+    int impl = 2;        // 2 (default): bf16x3 kernels — fp32 values split exactly into 3 bf16, 6 products on the bf16
+                         // pipe, fp32 accumulate (admitted by the same parity criteria as the fp32-MFMA kernels);
+                         // 0: tap-unrolled LDS-DMA fp32-MFMA kernels, 1: LDS kernel (their bitwise cross-check)
     int variant = -1;    // forced tile id (tests / tools), -1: per-layer heuristic
     int tune = 1;        // bit 0: s_setprio around MFMA clusters
     int tap_pd = 2;      // prefetch distance of the 1x1 tap kernel
@@ -127,7 +129,7 @@ int pa_engine_create(int device_id, pa_engine** out) {
     r = hipMalloc((void**)&e->zeros, 256);
     if (r == hipSuccess) r = hipMemset(e->zeros, 0, 256);
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "zero page: %s", hipGetErrorString(r)); }
-    if (const char* v = getenv("PADEL_CONV_IMPL")) e->t.impl = (v[0] == 'l') ? 1 : 0;
+    if (const char* v = getenv("PADEL_CONV_IMPL")) e->t.impl = (v[0] == 'l') ? 1 : (v[0] == 'b') ? 2 : 0;   // tap | lds | bx3
     e->t.variant = env_int("PADEL_CONV_VARIANT", -1);
     e->t.tune = env_int("PADEL_CONV_TUNE", 1);
     e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
@@ -140,7 +142,7 @@ int pa_engine_create(int device_id, pa_engine** out) {
 int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     if (!e || !key) return 1;
     const std::string k = key;
-    if (k == "impl") e->t.impl = value ? 1 : 0;
+    if (k == "impl") e->t.impl = (value >= 0 && value <= 2) ? value : 2;
     else if (k == "variant") e->t.variant = value;
     else if (k == "tune") e->t.tune = value;
     else if (k == "tap_pd") e->t.tap_pd = (value == 3) ? 3 : 2;
@@ -231,6 +233,9 @@ static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) 
                 (size_t)o.b_off + o.npad > n_floats)
                 PA_FAIL(e, "op %d: weights outside the blob", i);
             if (o.res_buf >= 0 && !okslice(o.res_buf, o.res_choff, o.cout)) PA_FAIL(e, "op %d: bad residual slice", i);
+            if (o.reserved < 0 || (o.reserved & 3) ||
+                (o.reserved > 0 && (size_t)o.reserved + (size_t)o.npad * ((o.cin + 31) / 32) * o.ksize * o.ksize * 48 > n_floats))
+                PA_FAIL(e, "op %d: bf16x3 weights outside the blob", i);
             const int lin = d->bufs[o.in_buf].level, lout = d->bufs[o.out_buf].level;
             if (lout != lin + (o.stride == 2 ? 1 : 0)) PA_FAIL(e, "op %d: level mismatch", i);
         } else if (o.kind == PA_OP_STEM) {
@@ -563,9 +568,12 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             // variant picks the tile of whichever kernel is selected
             const bool f16 = m->d.dtype == PA_DTYPE_F16;
             const bool use_tap = e->t.impl == 0 || f16;
+            const bool use_bx3 = !f16 && e->t.impl == 2 && o.reserved > 0;
+            a.w3 = use_bx3 ? (const void*)(m->d_w + o.reserved) : nullptr;
             a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
             const int lv = e->t.variant >= 0 ? e->t.variant
                            : f16 ? choose_conv_tap16_variant(a.M, a.n16)
+                           : use_bx3 ? choose_conv_bx3_variant(a.M, a.n16, o.ksize)
                                  : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
             int bm = 0, bn = 0;
             if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
@@ -583,6 +591,8 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             }
             if (f16) {
                 r = launch_conv_tap16(a, lv, s);
+            } else if (use_bx3) {
+                r = launch_conv_bx3(a, lv, s);
             } else if (use_tap) {
                 r = launch_conv_tap(a, lv, s);
                 if (r == hipErrorNotSupported && e->t.variant < 0) r = launch_conv_lds(a, choose_conv_lds_variant(a.M, a.n16), s);

@@ -14,6 +14,7 @@ enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 struct ConvArgs {
     const float* in;      // input buffer base
     const float* w;       // packed weights [Npad][Ktot], K order = (c32 chunk, tap, c16 half)
+    const void* w3;       // bf16x3 kernels: the same weights pre-split, [Npad][k-step][hi|mid|lo][32 bf16] (or nullptr)
     const float* bias;    // [Npad]
     const float* res;     // optional residual buffer base (added AFTER the activation) or nullptr
     const float* zeros;   // >= 64 bytes of zeros in HBM (source of padded taps)
@@ -60,6 +61,9 @@ bool conv_variant_shape(int variant, int* bm, int* bn);                         
 hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s);      // ids 6,7,9..15,20
 constexpr size_t kConvReadSlack = 512;
 int choose_conv_tap_variant(int M, int n16);
+// fp32 convolutions on the bf16 matrix pipe (conv_tap_bx3.hip): exact 3-way bf16 split, 6 products, fp32 accumulate
+hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s);      // ids 6,7,9,11,12,13,14,20
+int choose_conv_bx3_variant(int M, int n16, int ksize);
 // fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and
 // choff count elements); cin % 32 == 0; weights packed [Npad][Ktot] with K order (64-channel chunk, tap, 32-channel half)
 hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s);

@@ -8,6 +8,7 @@
 //   pool5_kernel          : MaxPool2d(5,1,2) on a channel slice (SPPF, chained 3x like upstream)
 //   upsample2x / maxpool2 : nearest x2 into a concat slice; MaxPool2d(2,2) (TrackNet models.py:60-64)
 #include "kernels.h"
+#include <algorithm>
 
 namespace padel {
 
@@ -113,62 +114,109 @@ hipError_t launch_resample_pass(const ResamplePassArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------ stem conv
-// one thread = one output pixel x 16 output channels; blockIdx.y = channel group
-__global__ void __launch_bounds__(256) stem_kernel(const StemArgs a) {
-    __shared__ float lut[256];          // u8 -> u8/255 exactly as `im.float() /= 255`
-    __shared__ float ws[16 * 27 + 16];
-    const int cg = blockIdx.y;
+// model.0: Conv(3, c, 3, 2) + BN + SiLU straight from the u8 NHWC4 network input, on the matrix pipe: an implicit
+// GEMM with K = 27 (ky, kx, c) padded to 32 = 8 x v_mfma_f32_16x16x4_f32 per 16 pixels x 16 channels.  One wave owns
+// 16 output pixels x all channels per iteration of a grid-stride loop; its weight fragments (NF x 8 floats per lane)
+// and the tap decode of its 8 K-slots stay in registers across iterations.  Operands are swapped (weights = A), so a
+// lane ends up with 4 consecutive channels of one pixel: one 16-byte (fp32) / 8-byte (fp16) store per fragment.
+// Input values are u8 -> float(u8)/255 through a 256-entry LDS table (bit-identical to `im.float() /= 255`);
+// out-of-image taps contribute exact zeros.  The layer is HBM-write-bound (48-64 output floats per 4 input bytes):
+// round 1's VALU kernel needed 4.1 ms for the 64 x 1280^2 pose batch, the output alone is 1.0 ms at 5 TB/s.
+template <int NF, bool F16>
+__global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
+    __shared__ float lut[256];
     lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
-    for (int i = threadIdx.x; i < 16 * 27; i += 256) ws[i] = a.w[cg * 16 * 27 + i];
-    if (threadIdx.x < 16) ws[16 * 27 + threadIdx.x] = a.bias[cg * 16 + threadIdx.x];
     __syncthreads();
-    const long long total = (long long)a.B * a.Ho * a.Wo;
-    const long long p = blockIdx.x * 256ll + threadIdx.x;
-    if (p >= total) return;
-    const int ox = (int)(p % a.Wo);
-    const long long t = p / a.Wo;
-    const int oy = (int)(t % a.Ho);
-    const int n = (int)(t / a.Ho);
-    const uint32_t* img = reinterpret_cast<const uint32_t*>(a.in) + (long long)n * a.H * a.W;
-    float x[27];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 15, lq = lane >> 4;
+    // K slot kk of this lane: k = 4*kk + lq  ->  tap (dy, dx) and colour byte
+    int dy[8], dx[8], sh[8];
+    bool kv[8];
+    float wreg[NF][8];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
+    for (int kk = 0; kk < 8; ++kk) {
+        const int k = 4 * kk + lq;
+        kv[kk] = k < 27;
+        const int t = k / 3;
+        sh[kk] = 8 * (k - 3 * t);
+        dy[kk] = t / 3;
+        dx[kk] = t - 3 * dy[kk];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int iy = oy * 2 - 1 + ky, ix = ox * 2 - 1 + kx;
-            const bool v = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const uint32_t px = v ? img[(long long)iy * a.W + ix] : 0u;
-            x[(ky * 3 + kx) * 3 + 0] = v ? lut[px & 255u] : 0.0f;
-            x[(ky * 3 + kx) * 3 + 1] = v ? lut[(px >> 8) & 255u] : 0.0f;
-            x[(ky * 3 + kx) * 3 + 2] = v ? lut[(px >> 16) & 255u] : 0.0f;
-        }
+        for (int j = 0; j < NF; ++j) wreg[j][kk] = kv[kk] ? a.w[(j * 16 + lr) * 27 + k] : 0.0f;
     }
-    float* o = a.out + p * a.out_cs + a.out_choff + cg * 16;
-    _Float16* oh = reinterpret_cast<_Float16*>(a.out) + p * a.out_cs + a.out_choff + cg * 16;
+    f32x4 bias4[NF];
 #pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) {
-        f32x4 r;
+    for (int j = 0; j < NF; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + j * 16 + lq * 4);
+    const long long P = (long long)a.B * a.Ho * a.Wo;
+    const long long ntiles = (P + 15) / 16;
+    const int HoWo = a.Ho * a.Wo;
+    const uint32_t* const img0 = reinterpret_cast<const uint32_t*>(a.in);
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
+        const long long p = tile * 16 + lr;
+        const bool pv = p < P;
+        const long long pc = pv ? p : 0;
+        const int n = (int)(pc / HoWo);
+        const int rem = (int)(pc - (long long)n * HoWo);
+        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const uint32_t* img = img0 + (long long)n * a.H * a.W;
+        float av[8];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int c = c4 * 4 + cc;
-            float acc = ws[16 * 27 + c];
-#pragma unroll
-            for (int k = 0; k < 27; ++k) acc = fmaf(x[k], ws[c * 27 + k], acc);
-            r[cc] = acc / (1.0f + expf(-acc));
+        for (int kk = 0; kk < 8; ++kk) {
+            const int iy = oy * 2 - 1 + dy[kk], ix = ox * 2 - 1 + dx[kk];
+            const bool ok = pv && kv[kk] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const uint32_t px = ok ? img[(long long)iy * a.W + ix] : 0u;
+            av[kk] = ok ? lut[(px >> sh[kk]) & 255u] : 0.0f;
         }
-        if (a.out_f16) {
+        f32x4 acc[NF];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc) oh[c4 * 4 + cc] = (_Float16)r[cc];
-        } else {
-            *reinterpret_cast<f32x4*>(o + c4 * 4) = r;
+        for (int j = 0; j < NF; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[j][kk], av[kk], acc[j], 0, 0, 0);
+        if (pv) {
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float x = acc[j][r] + bias4[j][r];
+                    v[r] = x / (1.0f + expf(-x));
+                }
+                const long long o = p * a.out_cs + a.out_choff + j * 16 + lq * 4;
+                if (F16) {
+                    _Float16* oh = reinterpret_cast<_Float16*>(a.out) + o;
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 hv;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+                    *reinterpret_cast<h4*>(oh) = hv;
+                } else {
+                    *reinterpret_cast<f32x4*>(a.out + o) = v;
+                }
+            }
         }
     }
 }
 
+template <int NF>
+static void launch_stem_nf(const StemArgs& a, unsigned grid, hipStream_t s) {
+    if (a.out_f16) hipLaunchKernelGGL((stem_mfma_kernel<NF, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((stem_mfma_kernel<NF, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
 hipError_t launch_stem(const StemArgs& a, hipStream_t s) {
-    const long long total = (long long)a.B * a.Ho * a.Wo;
-    dim3 grid((unsigned)((total + 255) / 256), a.cout / 16, 1);
-    hipLaunchKernelGGL(stem_kernel, grid, dim3(256), 0, s, a);
+    const long long ntiles = ((long long)a.B * a.Ho * a.Wo + 15) / 16;
+    const unsigned grid = (unsigned)std::min<long long>((ntiles + 3) / 4, 256 * 16);
+    if ((a.out_choff | a.out_cs) & 3) return hipErrorInvalidValue;     // 4-channel vector stores
+    switch (a.cout / 16) {
+        case 1: launch_stem_nf<1>(a, grid, s); break;
+        case 2: launch_stem_nf<2>(a, grid, s); break;
+        case 3: launch_stem_nf<3>(a, grid, s); break;
+        case 4: launch_stem_nf<4>(a, grid, s); break;
+        case 5: launch_stem_nf<5>(a, grid, s); break;     // yolov8x: c1 = 80
+        default: return hipErrorNotSupported;
+    }
     return hipGetLastError();
 }
 

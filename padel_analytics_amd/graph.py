@@ -59,6 +59,42 @@ def pack_conv_weight(w: np.ndarray, kc: int = 16) -> np.ndarray:
     return out
 
 
+def split_bf16x3(w: np.ndarray):
+    """fp32 -> three uint16 arrays (hi, mid, lo bf16 bit patterns) with hi + mid + lo == w EXACTLY: each part is the
+    truncation of what the previous parts left (8 + 8 + 8 significand bits)."""
+    w = np.ascontiguousarray(w, np.float32)
+    b = w.view(np.uint32)
+    hi = b & np.uint32(0xFFFF0000)
+    r = w - hi.view(np.float32)
+    mid = r.view(np.uint32) & np.uint32(0xFFFF0000)
+    lo = (r - mid.view(np.float32)).view(np.uint32)
+    assert not (lo & np.uint32(0xFFFF)).any(), "the third part of an fp32 value always fits bf16"
+    return (hi >> 16).astype(np.uint16), (mid >> 16).astype(np.uint16), (lo >> 16).astype(np.uint16)
+
+
+# k-slot order of one 32-channel k-step of the bf16x3 kernels: lane group q holds channels 4q..4q+3 of the first
+# 16-channel sub-row and 16+4q..16+4q+3 of the second (what two 16-byte fragment reads give it; csrc/conv_tap_bx3.hip)
+BX3_PERM = np.array([4 * (s // 8) + (s % 8) if s % 8 < 4 else 16 + 4 * (s // 8) + (s % 8 - 4) for s in range(32)])
+
+
+def pack_conv_weight_bx3(w: np.ndarray) -> np.ndarray:
+    """(Cout, Cin, k, k) fp32, Cout % 16 == 0, Cin % 16 == 0 -> uint16 [Cout][k-step][hi|mid|lo][32] for the bf16x3
+    kernels: k-steps ordered (32-channel chunk, tap), Cin zero-padded to a multiple of 32."""
+    cout, cin, k, _ = w.shape
+    assert cout % 16 == 0 and cin % 16 == 0
+    c32 = (cin + 31) // 32 * 32
+    wp = np.zeros((cout, c32, k, k), np.float32)
+    wp[:, :cin] = w
+    out = np.empty((cout, (c32 // 32) * k * k, 3, 32), np.uint16)
+    for c in range(c32 // 32):
+        for tap in range(k * k):
+            blk = wp[:, c * 32:(c + 1) * 32, tap // k, tap % k][:, BX3_PERM]
+            hi, mid, lo = split_bf16x3(blk)
+            s = c * k * k + tap
+            out[:, s, 0], out[:, s, 1], out[:, s, 2] = hi, mid, lo
+    return out
+
+
 def fold_bn(sd, prefix: str, eps: float):
     """Conv+BN fold in fp32, same operation order as ultralytics' fuse_conv_and_bn."""
     w = np.asarray(sd[f"{prefix}.conv.weight"], np.float32)
@@ -86,6 +122,7 @@ class Graph:
     in_channels: int = 0
     out_channels: int = 0
     dtype: int = DTYPE_F32                        # storage type of activations / conv weights (pa_dtype)
+    bx3: bool = True                              # fp32 graphs: also pack the bf16x3 (3-way split) weight planes
 
     @property
     def kalign(self) -> int:
@@ -131,14 +168,17 @@ class Graph:
         wp[:cout, :cin] = w
         bp = np.zeros(npad, np.float32)
         bp[:cout] = b
+        w3_off = 0
         if self.dtype == DTYPE_F16:
             w_off = self._add(np.ascontiguousarray(pack_conv_weight(wp, 32).astype(np.float16)).view(np.float32))
         else:
             w_off = self._add(pack_conv_weight(wp))
+            if self.bx3:            # the same weights pre-split for the bf16x3 kernels (engine tuning impl=2)
+                w3_off = self._add(np.ascontiguousarray(pack_conv_weight_bx3(wp)).view(np.float32))
         b_off = self._add(bp)
         self.ops.append(dict(kind=OP_CONV, in_buf=sb, in_choff=so, cin=sw, out_buf=dst[0], out_choff=dst[1],
                              cout=ow, ksize=k, stride=s, act=act, res_buf=-1 if res is None else res[0],
-                             res_choff=0 if res is None else res[1], npad=npad, w_off=w_off, b_off=b_off))
+                             res_choff=0 if res is None else res[1], npad=npad, w_off=w_off, b_off=b_off, reserved=w3_off))
 
     def blob(self) -> np.ndarray:
         return np.concatenate(self.chunks) if self.chunks else np.zeros(0, np.float32)

@@ -30,6 +30,7 @@ CASES = [
 
 LDS_VARIANTS = tuple(range(13))
 TAP_VARIANTS = (6, 7, 9, 10, 11, 12, 13, 14, 15, 20)
+BX3_VARIANTS = (6, 7, 9, 11, 12, 13, 14, 20)      # bf16x3 kernels (conv_tap_bx3.hip): fp32 accuracy, own rounding
 
 
 def _run(eng, case, x, w, b, wr):
@@ -86,10 +87,31 @@ def test_conv_variants(gpu_engine, case):
         gpu_engine.set_tuning(graph=0, alias=0)
         outs["auto.noalias"] = _run(gpu_engine, case, x, w, b, wr)
     finally:
-        gpu_engine.set_tuning(impl=0, variant=-1, tap_pd=2, graph=0, alias=1)
+        gpu_engine.set_tuning(impl=2, variant=-1, tap_pd=2, graph=0, alias=1)
     ref_name, ref = next(iter(outs.items()))
     for name, y in outs.items():
         assert y.shape == want.shape
         err = float(np.abs(y - want).max()) / scale
         assert err < 3e-6, f"{name}: rel err {err:.2e} vs fp64 conv2d"
         assert np.array_equal(y, ref), f"{name} differs bitwise from {ref_name} (max {np.abs(y - ref).max():.3e})"
+    # ---- bf16x3: same accuracy bar against fp64, bitwise equal among its own tiles, and its RMS error not worse
+    # than the fp32 MFMA kernels' (the admission criterion for making it the default)
+    outs3 = {}
+    try:
+        for v in BX3_VARIANTS:
+            gpu_engine.set_tuning(impl=2, variant=v)
+            for rep in range(2):
+                outs3[f"B{v}.{rep}"] = _run(gpu_engine, case, x, w, b, wr)
+        gpu_engine.set_tuning(impl=2, variant=-1)
+        outs3["B.auto"] = _run(gpu_engine, case, x, w, b, wr)
+    finally:
+        gpu_engine.set_tuning(impl=2, variant=-1)
+    n3, r3 = next(iter(outs3.items()))
+    for name, y in outs3.items():
+        err = float(np.abs(y - want).max()) / scale
+        assert err < 3e-6, f"{name}: rel err {err:.2e} vs fp64 conv2d"
+        assert np.array_equal(y, r3), f"{name} differs bitwise from {n3} (max {np.abs(y - r3).max():.3e})"
+    rms32 = float(np.sqrt(np.mean((ref - want) ** 2)))
+    rms3 = float(np.sqrt(np.mean((r3 - want) ** 2)))
+    print(f"case {case}: RMS error vs fp64  fp32-MFMA {rms32:.3e}  bf16x3 {rms3:.3e}")
+    assert rms3 <= 1.25 * rms32 + 1e-9, (rms3, rms32)

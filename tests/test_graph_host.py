@@ -95,3 +95,21 @@ def test_fp16_graph_wiring(scale, nc, kpt):
             assert o["cin"] % 32 == 0 and o["in_choff"] % 8 == 0 and o["in_choff"] + o["cin"] <= ch and o["npad"] % 16 == 0
         if o["kind"] in (G.OP_SPPF_POOL, G.OP_UPSAMPLE2X):
             assert o["cin"] % 8 == 0 and o["in_choff"] % 8 == 0 and o["out_choff"] % 8 == 0
+
+
+def test_bf16x3_split_is_exact_and_packed_in_lane_order():
+    rng = np.random.default_rng(3)
+    w = (rng.normal(size=(16, 48, 3, 3)) * 10.0 ** rng.integers(-6, 3, (16, 48, 3, 3))).astype(np.float32)
+    hi, mid, lo = G.split_bf16x3(w)
+    back = sum((p.astype(np.uint32) << 16).view(np.float32).astype(np.float64) for p in (hi, mid, lo))
+    assert np.array_equal(back.astype(np.float32), w) and np.array_equal(back, w.astype(np.float64))
+    packed = G.pack_conv_weight_bx3(w)                       # cin 48 -> 2 chunks (the second half empty), 9 taps each
+    assert packed.shape == (16, 18, 3, 32)
+    val = sum((packed[:, :, p].astype(np.uint32) << 16).view(np.float32).astype(np.float64) for p in range(3))   # (16, 18, 32)
+    for c in range(2):
+        for tap in range(9):
+            for s in range(32):
+                ch = c * 32 + G.BX3_PERM[s]
+                want = w[:, ch, tap // 3, tap % 3] if ch < 48 else np.zeros(16, np.float32)
+                assert np.array_equal(val[:, c * 9 + tap, s], want.astype(np.float64)), (c, tap, s)
+    assert sorted(G.BX3_PERM.tolist()) == list(range(32))

@@ -76,11 +76,13 @@ def main():
         m.set_max_batch(B)
         x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32)
         for t in tiles:
-            kw = dict(impl=0, variant=-1, tap_pd=2)
+            kw = dict(impl=0, variant=-1, tap_pd=2)        # "auto" / Tn / Apn: the fp32-MFMA tap kernels
             if t.startswith("T"):
                 kw.update(variant=int(t[1:]))
             elif t.startswith("L"):
                 kw.update(impl=1, variant=int(t[1:]))
+            elif t.startswith("B"):                       # bf16x3 kernels: B = auto tile, Bn = tile n
+                kw.update(impl=2, variant=int(t[1:]) if len(t) > 1 else -1)
             elif t.startswith("Ap"):
                 kw.update(tap_pd=int(t[2:]))
             eng.set_tuning(**kw)
@@ -94,7 +96,7 @@ def main():
             except E.EngineError:
                 pass
         m.close()
-    eng.set_tuning(impl=0, variant=-1, tap_pd=2)
+    eng.set_tuning(impl=2, variant=-1, tap_pd=2)
     print("%-30s" % "shape" + "".join("%9s" % t for t in tiles))
     for name, row in table.items():
         print("%-30s" % name + "".join("%9s" % (("%.1f" % row[t][0]) if t in row else "-") for t in tiles))

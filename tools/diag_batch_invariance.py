@@ -16,7 +16,7 @@ g = G.build_yolov8(sd, cfg["nc"], cfg["kpt"])
 
 
 def heads(B, fr, **tune):
-    eng.set_tuning(impl=0, variant=-1, alias=1, graph=0)
+    eng.set_tuning(impl=2, variant=-1, alias=1, graph=0)
     eng.set_tuning(**tune)
     m = E.Model(eng, g)
     m.set_max_batch(B)

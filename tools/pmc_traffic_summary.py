@@ -12,34 +12,40 @@ import sys
 from pathlib import Path
 
 
+KERNEL = "conv_tap_kernel"
+
+
 def per_kernel(pmc_dir, counter):
     files = glob.glob(f"{pmc_dir}/**/*counter_collection.csv", recursive=True)
     tot, disp = 0.0, set()
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "conv_tap_kernel" in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and KERNEL in r["Kernel_Name"]:
                 tot += float(r["Counter_Value"])
                 disp.add((f, r["Dispatch_Id"]))
     return tot, len(disp)
 
 
 def main():
+    global KERNEL
     wl, ops_csv, d_fetch, d_write = sys.argv[1:5]
+    impl = sys.argv[5] if len(sys.argv) > 5 else "tap"
+    KERNEL = {"tap": "conv_tap_kernel", "bx3": "conv_bx3_kernel"}[impl]
     fetch_kib, n_f = per_kernel(d_fetch, "FETCH_SIZE")
     write_kib, n_w = per_kernel(d_write, "WRITE_SIZE")
     alg, n_ops = 0.0, 0
     for r in csv.DictReader(open(ops_csv)):
         if r["kind"] == "2" and r["ksize"] == "3":
             M, cout, cin, s = int(r["M"]), int(r["cout"]), int(r["cin"]), int(r["stride"])
-            alg += M * s * s * cin * 4 + M * cout * 4 + 9 * cin * cout * 4
+            alg += M * s * s * cin * 4 + M * cout * 4 + 9 * cin * cout * (6 if impl == "bx3" else 4)
             n_ops += 1
     assert n_f and n_w and n_ops, (n_f, n_w, n_ops)
     fetch = fetch_kib * 1024 * 2 / n_f
     write = write_kib * 1024 / n_w
     out_path = Path("profiles/r2_traffic.json")
     doc = json.loads(out_path.read_text()) if out_path.exists() else {}
-    doc[wl] = {
-        "kernel": "conv_tap_kernel (all 3x3 convs of the workload)",
+    doc[f"{wl}-{impl}"] = {
+        "kernel": f"{KERNEL} (all 3x3 convs of the workload)",
         "launches_counted": {"FETCH_SIZE": n_f, "WRITE_SIZE": n_w, "ops_per_step": n_ops},
         "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
         "bytes_per_launch": round(fetch + write), "algorithmic_bytes_per_launch": round(alg / n_ops),
@@ -49,7 +55,7 @@ def main():
                   "tools/pmc_bench_traffic.sh",
     }
     out_path.write_text(json.dumps(doc, indent=1))
-    print(json.dumps(doc[wl], indent=1))
+    print(json.dumps(doc[f"{wl}-{impl}"], indent=1))
 
 
 if __name__ == "__main__":
