@@ -44,6 +44,7 @@ struct pa_engine {
     bool profiling = false;
     float* zeros = nullptr;   // 256 B of zeros: source of padded conv taps
     Tuning t;
+    int tuning_epoch = 0;     // bumped by pa_engine_set_tuning: captured graphs of an older epoch are discarded
     std::string timeline_path;
     pa_comm* comm = nullptr;  // RCCL communicator (pa_engine_comm_init), optional
 };
@@ -84,6 +85,7 @@ struct pa_model {
     void* arena = nullptr;                 // what bptr points into
     size_t arena_bytes = 0, logical_bytes = 0;   // bytes of the plan with / without liveness aliasing
     std::map<int, hipGraphExec_t> graphs;  // op-list replay per batch size (tuning "graph")
+    int graph_epoch = -1;                  // engine tuning epoch the graphs were captured under
     uint8_t* d_frames = nullptr; size_t frames_cap = 0;
     uint8_t* d_netin = nullptr;
     uint8_t* d_tmp = nullptr;
@@ -150,6 +152,7 @@ int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     else if (k == "timeline") e->t.timeline = value ? 1 : 0;
     else if (k == "alias") e->t.alias = value ? 1 : 0;
     else PA_FAIL(e, "pa_engine_set_tuning: unknown key '%s'", key);
+    e->tuning_epoch++;
     return 0;
 }
 
@@ -638,6 +641,12 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
 static int run_graph(pa_model* m, int n, size_t* pi) {
     pa_engine* e = m->e;
     if (!e->t.graph || e->profiling || e->t.timeline) return run_ops(m, n, pi);
+    if (m->graph_epoch != e->tuning_epoch) {            // kernel choice may have changed since the capture
+        PA_HIP(e, hipStreamSynchronize(e->stream));
+        for (auto& g : m->graphs) hipGraphExecDestroy(g.second);
+        m->graphs.clear();
+        m->graph_epoch = e->tuning_epoch;
+    }
     auto it = m->graphs.find(n);
     if (it == m->graphs.end()) {
         hipGraph_t g = nullptr;
