@@ -72,6 +72,7 @@ def parse():
     ap.add_argument("--no-fp64", action="store_true", help="parity leg: skip the fp64 oracle (noise floor)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--engine-only", action="store_true", help="skip the runner-level measurement (profiling runs)")
+    ap.add_argument("--no-compare", action="store_true", help="skip the fp32-MFMA comparison leg of engine_only (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile (CSV) of the roofline pass here")
     ap.add_argument("--host-frames", action="store_true",
@@ -176,6 +177,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line (the JSON): everything else that writes to fd 1 — the trackers' prints, but also
+    # librccl's C-level start-up banner — is pointed at stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     from padel_analytics_amd import dist as D, engine as E, synth, video
     from padel_analytics_amd.trackers import TrackingRunner
@@ -270,7 +276,7 @@ def main():
         dt_e = eng.allreduce_max(time.perf_counter() - t0)
         out["engine_only"] = {"value": round(world * B * K / dt_e, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_e / K, 3),
                               "what": "the same K steps calling pa_yolo_infer directly: no Detections / PolygonZone / ByteTrack / objects"}
-        if a.dtype == "f32" and a.impl == "bx3":
+        if a.dtype == "f32" and a.impl == "bx3" and not a.no_compare:
             # the same engine-only steps on round 1's fp32-input MFMA kernels, for reference
             eng.set_tuning(impl=0)
             engine_step()
@@ -456,7 +462,8 @@ def main():
                                          f"(oracle/yolov8_ref.py), all {len(names)} trackers, torch threads={ncores}"}
 
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        with os.fdopen(json_fd, "w") as f:
+            f.write(json.dumps(out) + "\n")
     for t in trackers.values():
         t.model.close()
     clip.free()

@@ -10,5 +10,5 @@ timeout 600 python bench.py --workload c2 --steps 20 --warmup 5 --no-cpu-baselin
 timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --host-frames --no-roofline > gpurun_out/bench_c3_host.json 2>> gpurun_out/bench_c3.err; cat gpurun_out/bench_c3_host.json
 timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --graph 1 > gpurun_out/bench_c3_graph.json 2>> gpurun_out/bench_c3.err; cat gpurun_out/bench_c3_graph.json
 bash tools/pmc_bench_traffic.sh c3 bx3 2>&1 | tail -16
-cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -o c3 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --engine-only > $R/gpurun_out/prof_c3.log 2>&1
+cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_c3 -o c3 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --engine-only --no-compare > $R/gpurun_out/prof_c3.log 2>&1
 head -12 $R/gpurun_out/prof_c3/c3_kernel_stats.csv

@@ -9,11 +9,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp
 cd /tmp
-python $R/bench.py --workload $WL --impl $IMPL --steps 1 --warmup 1 --no-cpu-baseline --engine-only --dump-ops $R/gpurun_out/ops_$WL.csv > $R/gpurun_out/bench_ops_$WL.json 2> $R/gpurun_out/bench_ops_$WL.err
+python $R/bench.py --workload $WL --impl $IMPL --steps 1 --warmup 1 --no-cpu-baseline --engine-only --no-compare --dump-ops $R/gpurun_out/ops_$WL.csv > $R/gpurun_out/bench_ops_$WL.json 2> $R/gpurun_out/bench_ops_$WL.err
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_bench_$C
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/pmc_bench_$C -o p -- \
-      python $R/bench.py --workload $WL --impl $IMPL --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --engine-only > $R/gpurun_out/pmc_bench_$C.log 2>&1
+      python $R/bench.py --workload $WL --impl $IMPL --steps 1 --warmup 1 --no-cpu-baseline --no-roofline --engine-only --no-compare > $R/gpurun_out/pmc_bench_$C.log 2>&1
   echo "pass $C rc=$?"
 done
 cd $R
