@@ -333,6 +333,7 @@ static const LdsVariant lds_variants[] = {
     {14, 4, 2, 2, 4},  // 128 x 128
     {15, 4, 2, 2, 2},  // 128 x  64
     {20, 4, 1, 2, 3},  // 128 x  48
+    {25, 4, 1, 1, 5},  //  64 x  80 (bf16x3 kernels only)
 };
 constexpr int kNumLdsVariants = 13;      // ids 0..12 are instantiated for the LDS kernel
 

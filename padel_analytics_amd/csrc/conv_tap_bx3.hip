@@ -21,8 +21,9 @@
 //     planes (hi | mid | lo, 32 bf16 each) in the lane order the A operand ends up with;
 //   * accumulation keeps the two-level scheme (one partial set per 32-channel chunk x 9 taps, flushed into the main
 //     accumulators), products are issued smallest first (lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi).
-// cin % 32 == 16 (yolov8m's 48-channel layers): the last chunk runs with its A1 sub-row switched off (out-of-range lane
-// offsets -> zeros) against zero-padded weights.
+// cin % 32 == 16 (yolov8m's 48-channel layers, n-scale's 16): the 3x3 kernel's tail block pairs TAPS instead of channel
+// halves (A0 = the 16 channels at tap 2t, A1 = at tap 2t+1: 5 k-steps instead of 9 half-empty ones); the 1x1 kernel runs
+// its last k-step with A1 switched off (out-of-range lane offsets -> zeros) against zero-padded weights.
 #include "kernels.h"
 #include <cmath>
 #include <cstdint>
@@ -122,15 +123,15 @@ constexpr int min_waves3(int frags) { return frags <= 6 ? 2 : 1; }
             _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
     } while (0)
 
-// requests of one k-step into ring stage SR_: A0 / A1 sub-rows (lane offsets VA_, VB_; SGPR offset SA_, +64 for A1),
+// requests of one k-step into ring stage SR_: A0 / A1 sub-rows (lane offsets VA_ / VB_, SGPR offsets SA0_ / SA1_),
 // three weight planes (SGPR offset SB_ + 64 * plane)
-#define PADEL_BX3_DMA(SR_, SA_, SB_, VA0_, VA1_, VB0_, VB1_)                                                      \
+#define PADEL_BX3_DMA(SR_, SA0_, SA1_, SB_, VA0_, VA1_, VB0_, VB1_)                                               \
     do {                                                                                                          \
-        const unsigned sa_ = (SA_), sb_ = (SB_);                                                                  \
-        dma3<(SR_) * STAGE_B>((VA0_), rsrcA, sa_, lds_wave);                                                      \
-        if constexpr (AP >= 2) dma3<(SR_) * STAGE_B + RP * 64>((VA1_), rsrcA, sa_, lds_wave);                     \
-        dma3<(SR_) * STAGE_B + BM * 64>((VB0_), rsrcA, sa_ + 64u, lds_wave);                                      \
-        if constexpr (AP >= 2) dma3<(SR_) * STAGE_B + BM * 64 + RP * 64>((VB1_), rsrcA, sa_ + 64u, lds_wave);     \
+        const unsigned sa0_ = (SA0_), sa1_ = (SA1_), sb_ = (SB_);                                                 \
+        dma3<(SR_) * STAGE_B>((VA0_), rsrcA, sa0_, lds_wave);                                                     \
+        if constexpr (AP >= 2) dma3<(SR_) * STAGE_B + RP * 64>((VA1_), rsrcA, sa0_, lds_wave);                    \
+        dma3<(SR_) * STAGE_B + BM * 64>((VB0_), rsrcA, sa1_, lds_wave);                                           \
+        if constexpr (AP >= 2) dma3<(SR_) * STAGE_B + BM * 64 + RP * 64>((VB1_), rsrcA, sa1_, lds_wave);          \
         PADEL_BX3_DMAB(SR_, 0, sb_);                                                                              \
         PADEL_BX3_DMAB(SR_, 1, sb_ + 64u);                                                                        \
         PADEL_BX3_DMAB(SR_, 2, sb_ + 128u);                                                                       \
@@ -288,45 +289,73 @@ __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF)) conv_bx3_ke
     unsigned tapoff[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((unsigned)((((t / 3) * a.W + (t % 3)) * a.in_cs) * 4));
-    PADEL_BX3_WEIGHTS(nch * 9)
+    // K walk: nfull 32-channel chunks x 9 taps, then — for cin % 32 == 16 (yolov8m's 48-channel layers, n-scale's 16) —
+    // a TAIL block that pairs TAPS instead of channel halves: tail step t covers the last 16 channels at taps 2t (as
+    // sub-row A0) and 2t+1 (as A1), 5 steps instead of 9 half-empty ones
+    const int nfull = a.cin >> 5;
+    PADEL_BX3_WEIGHTS(nfull * 9 + (half_tail ? 5 : 0))
 
     unsigned s_chunk = 0, s_kb = 0;
-    // A1 (channels 16..31 of a chunk) does not exist in the half-empty last chunk: its requests use out-of-range
-    // lane offsets.  `cur1` / `nxt1` say whether the chunk being computed / the next one has an A1.
-    bool cur1 = !(half_tail && nch == 1), nxt1 = !(half_tail && nch <= 2);
+#define PADEL_BX3_REQ_FULL(SR_, CH_, KB_, T_)                                                                      \
+    PADEL_BX3_DMA(SR_, (CH_) + tapoff[T_], (CH_) + tapoff[T_] + 64u, KB_, voffA[0][T_], voffA[AP - 1][T_], voffA[0][T_], voffA[AP - 1][T_])
+#define PADEL_BX3_REQ_TAIL(SR_, CH_, KB_, JT_)                                                                     \
+    PADEL_BX3_DMA(SR_, (CH_) + tapoff[2 * (JT_)], (CH_) + tapoff[2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8], KB_,    \
+                  voffA[0][2 * (JT_)], voffA[AP - 1][2 * (JT_)],                                                  \
+                  2 * (JT_) + 1 < 9 ? voffA[0][2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] : kOOR3,                    \
+                  2 * (JT_) + 1 < 9 ? voffA[AP - 1][2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] : kOOR3)
+    bool nxt_tail = false;       // the block after the current full chunk is the tail block
 
 #define PADEL_BX3_STEP(J)                                                                                         \
     do {                                                                                                          \
         wait_vm3<NREQ>();                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                             \
         if constexpr ((J) + 2 < 9) {                                                                              \
-            PADEL_BX3_DMA(((J) + 2) % 3, s_chunk + tapoff[(J) + 2 < 9 ? (J) + 2 : 0], s_kb + ((J) + 2) * 192u,    \
-                          voffA[0][(J) + 2 < 9 ? (J) + 2 : 0], voffA[AP - 1][(J) + 2 < 9 ? (J) + 2 : 0],          \
-                          cur1 ? voffA[0][(J) + 2 < 9 ? (J) + 2 : 0] : kOOR3, cur1 ? voffA[AP - 1][(J) + 2 < 9 ? (J) + 2 : 0] : kOOR3); \
+            PADEL_BX3_REQ_FULL(((J) + 2) % 3, s_chunk, s_kb + ((J) + 2) * 192u, (J) + 2 < 9 ? (J) + 2 : 0);      \
         } else {                                                                                                  \
-            PADEL_BX3_DMA(((J) + 2) % 3, s_chunk + 128u + tapoff[((J) + 2) % 9], s_kb + ((J) + 2) * 192u,         \
-                          voffA[0][((J) + 2) % 9], voffA[AP - 1][((J) + 2) % 9],                                  \
-                          nxt1 ? voffA[0][((J) + 2) % 9] : kOOR3, nxt1 ? voffA[AP - 1][((J) + 2) % 9] : kOOR3);   \
+            if (nxt_tail) { PADEL_BX3_REQ_TAIL(((J) + 2) % 3, s_chunk + 128u, s_kb + ((J) + 2) * 192u, ((J) + 2) % 9); } \
+            else { PADEL_BX3_REQ_FULL(((J) + 2) % 3, s_chunk + 128u, s_kb + ((J) + 2) * 192u, ((J) + 2) % 9); }   \
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_BX3_COMPUTE((J) % 3);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
+    // tail step JT (0..4): nothing is requested past step 4, so step 4 drains the queue
+#define PADEL_BX3_TSTEP(JT)                                                                                       \
+    do {                                                                                                          \
+        if constexpr ((JT) == 4) wait_vm3<0>(); else wait_vm3<NREQ>();                                            \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        if constexpr ((JT) + 2 < 5) { PADEL_BX3_REQ_TAIL(((JT) + 2) % 3, s_chunk, s_kb + ((JT) + 2) * 192u, (JT) + 2 < 5 ? (JT) + 2 : 0); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_BX3_COMPUTE((JT) % 3);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
 
-    PADEL_BX3_DMA(0, tapoff[0], 0u, voffA[0][0], voffA[AP - 1][0], cur1 ? voffA[0][0] : kOOR3, cur1 ? voffA[AP - 1][0] : kOOR3);
-    PADEL_BX3_DMA(1, tapoff[1], 192u, voffA[0][1], voffA[AP - 1][1], cur1 ? voffA[0][1] : kOOR3, cur1 ? voffA[AP - 1][1] : kOOR3);
-    for (int c = 0; c < nch; ++c) {
-        cur1 = !(half_tail && c == nch - 1);
-        nxt1 = !(half_tail && c + 1 >= nch - 1);
+    if (nfull > 0) {
+        PADEL_BX3_REQ_FULL(0, 0u, 0u, 0);
+        PADEL_BX3_REQ_FULL(1, 0u, 192u, 1);
+    } else {
+        PADEL_BX3_REQ_TAIL(0, 0u, 0u, 0);
+        PADEL_BX3_REQ_TAIL(1, 0u, 192u, 1);
+    }
+    for (int c = 0; c < nfull; ++c) {
+        nxt_tail = half_tail && c == nfull - 1;
         PADEL_BX3_STEP(0); PADEL_BX3_STEP(1); PADEL_BX3_STEP(2); PADEL_BX3_STEP(3); PADEL_BX3_STEP(4);
         PADEL_BX3_STEP(5); PADEL_BX3_STEP(6); PADEL_BX3_STEP(7); PADEL_BX3_STEP(8);
         PADEL_BX3_FLUSH();
         s_chunk += 128u;
         s_kb += 9u * 192u;
     }
-    wait_vm3<0>();          // the two trailing requests (past the last chunk: slack bytes) must land before LDS is released
+    if (half_tail) {
+        PADEL_BX3_TSTEP(0); PADEL_BX3_TSTEP(1); PADEL_BX3_TSTEP(2); PADEL_BX3_TSTEP(3); PADEL_BX3_TSTEP(4);
+        PADEL_BX3_FLUSH();
+    } else {
+        wait_vm3<0>();      // the two trailing requests (past the last chunk: slack bytes) must land before LDS is released
+    }
     PADEL_BX3_FINISH()
 #undef PADEL_BX3_STEP
+#undef PADEL_BX3_TSTEP
+#undef PADEL_BX3_REQ_FULL
+#undef PADEL_BX3_REQ_TAIL
 }
 
 // =====================================================================================================  1x1
@@ -356,14 +385,14 @@ __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF)) conv_bx3_1_
     if ((J) < nb) {                                                                                               \
         wait_vm3<NREQ>();                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                             \
-        PADEL_BX3_DMA(((J) + 2) % 3, (s_k + (J) + 2) * 128u, (s_k + (J) + 2) * 192u, voffA[0], voffA[AP - 1],     \
-                      PADEL_BX3_A1(s_k + (J) + 2, 0), PADEL_BX3_A1(s_k + (J) + 2, AP - 1));                       \
+        PADEL_BX3_DMA(((J) + 2) % 3, (s_k + (J) + 2) * 128u, (s_k + (J) + 2) * 128u + 64u, (s_k + (J) + 2) * 192u, \
+                      voffA[0], voffA[AP - 1], PADEL_BX3_A1(s_k + (J) + 2, 0), PADEL_BX3_A1(s_k + (J) + 2, AP - 1)); \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_BX3_COMPUTE((J) % 3);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     }
-    PADEL_BX3_DMA(0, 0u, 0u, voffA[0], voffA[AP - 1], PADEL_BX3_A1(0, 0), PADEL_BX3_A1(0, AP - 1));
-    PADEL_BX3_DMA(1, 128u, 192u, voffA[0], voffA[AP - 1], PADEL_BX3_A1(1, 0), PADEL_BX3_A1(1, AP - 1));
+    PADEL_BX3_DMA(0, 0u, 64u, 0u, voffA[0], voffA[AP - 1], PADEL_BX3_A1(0, 0), PADEL_BX3_A1(0, AP - 1));
+    PADEL_BX3_DMA(1, 128u, 192u, 192u, voffA[0], voffA[AP - 1], PADEL_BX3_A1(1, 0), PADEL_BX3_A1(1, AP - 1));
     for (int k = 0; k < nch; k += 9) {
         const int nb = min(9, nch - k);
         PADEL_BX3_1STEP(0) PADEL_BX3_1STEP(1) PADEL_BX3_1STEP(2) PADEL_BX3_1STEP(3) PADEL_BX3_1STEP(4)
@@ -400,6 +429,7 @@ hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s) {
         case 12: return launch_b3<4, 1, 2, 1>(a, s);   // 128 x  16
         case 13: return launch_b3<4, 2, 2, 3>(a, s);   // 128 x  96, 8 waves
         case 14: return launch_b3<4, 2, 2, 4>(a, s);   // 128 x 128, 8 waves
+        case 25: return launch_b3<4, 1, 1, 5>(a, s);   //  64 x  80, 4 waves of 16 x 80: the 19-fragment (304-channel) fused pose heads
     }
     return hipErrorNotSupported;
 }
@@ -411,6 +441,7 @@ hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s) {
 int choose_conv_bx3_variant(int M, int n16, int ksize) {
     struct V { int id, bm, nf; float s3, s1; };
     static const V vs[] = {{7, 64, 6, 1.00f, 0.92f},  {20, 128, 3, 1.00f, 0.72f}, {13, 128, 6, 0.92f, 1.00f}, {14, 128, 8, 0.90f, 1.00f},
+                           {25, 64, 5, 0.97f, 0.85f},
                            {11, 128, 2, 0.86f, 0.50f}, {9, 128, 4, 0.70f, 0.80f},  {6, 64, 8, 0.55f, 0.56f},  {12, 128, 1, 0.45f, 0.30f}};
     float best = -1.f;
     int bv = 7;

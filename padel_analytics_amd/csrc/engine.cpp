@@ -237,7 +237,8 @@ static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) 
                 PA_FAIL(e, "op %d: weights outside the blob", i);
             if (o.res_buf >= 0 && !okslice(o.res_buf, o.res_choff, o.cout)) PA_FAIL(e, "op %d: bad residual slice", i);
             if (o.reserved < 0 || (o.reserved & 3) ||
-                (o.reserved > 0 && (size_t)o.reserved + (size_t)o.npad * ((o.cin + 31) / 32) * o.ksize * o.ksize * 48 > n_floats))
+                (o.reserved > 0 && (size_t)o.reserved + (size_t)o.npad * 48 *
+                     (o.ksize == 3 ? (size_t)(o.cin / 32) * 9 + ((o.cin & 16) ? 5 : 0) : (size_t)(o.cin + 31) / 32) > n_floats))
                 PA_FAIL(e, "op %d: bf16x3 weights outside the blob", i);
             const int lin = d->bufs[o.in_buf].level, lout = d->bufs[o.out_buf].level;
             if (lout != lin + (o.stride == 2 ? 1 : 0)) PA_FAIL(e, "op %d: level mismatch", i);

@@ -77,21 +77,41 @@ def split_bf16x3(w: np.ndarray):
 BX3_PERM = np.array([4 * (s // 8) + (s % 8) if s % 8 < 4 else 16 + 4 * (s // 8) + (s % 8 - 4) for s in range(32)])
 
 
+def bx3_ksteps(cin: int, k: int):
+    """K-steps of the bf16x3 kernels: each is a list of 32 (channel, tap) slots in sub-row order (16 + 16), None =
+    zero padding.  Full 32-channel chunks walk their taps; the last 16 channels of a cin % 32 == 16 layer pair TAPS in
+    a 3x3 conv (tap 2t | tap 2t+1: 5 steps instead of 9 half-empty ones) and stay half-empty in a 1x1."""
+    steps = []
+    nfull = cin // 32
+    for c in range(nfull):
+        for tap in range(k * k):
+            steps.append([(c * 32 + i, tap) for i in range(32)])
+    if cin % 32:
+        c0 = nfull * 32
+        if k == 3:
+            for t in range(5):
+                steps.append([(c0 + i, 2 * t) for i in range(16)] +
+                             [((c0 + i, 2 * t + 1) if 2 * t + 1 < 9 else None) for i in range(16)])
+        else:
+            for tap in range(k * k):
+                steps.append([(c0 + i, tap) for i in range(16)] + [None] * 16)
+    return steps
+
+
 def pack_conv_weight_bx3(w: np.ndarray) -> np.ndarray:
     """(Cout, Cin, k, k) fp32, Cout % 16 == 0, Cin % 16 == 0 -> uint16 [Cout][k-step][hi|mid|lo][32] for the bf16x3
-    kernels: k-steps ordered (32-channel chunk, tap), Cin zero-padded to a multiple of 32."""
+    kernels (k-steps: ``bx3_ksteps``; the 32 slots of a step are stored in the lane order BX3_PERM)."""
     cout, cin, k, _ = w.shape
     assert cout % 16 == 0 and cin % 16 == 0
-    c32 = (cin + 31) // 32 * 32
-    wp = np.zeros((cout, c32, k, k), np.float32)
-    wp[:, :cin] = w
-    out = np.empty((cout, (c32 // 32) * k * k, 3, 32), np.uint16)
-    for c in range(c32 // 32):
-        for tap in range(k * k):
-            blk = wp[:, c * 32:(c + 1) * 32, tap // k, tap % k][:, BX3_PERM]
-            hi, mid, lo = split_bf16x3(blk)
-            s = c * k * k + tap
-            out[:, s, 0], out[:, s, 1], out[:, s, 2] = hi, mid, lo
+    steps = bx3_ksteps(cin, k)
+    out = np.empty((cout, len(steps), 3, 32), np.uint16)
+    for s, slots in enumerate(steps):
+        blk = np.zeros((cout, 32), np.float32)
+        for i, sl in enumerate(slots):
+            if sl is not None:
+                blk[:, i] = w[:, sl[0], sl[1] // k, sl[1] % k]
+        hi, mid, lo = split_bf16x3(blk[:, BX3_PERM])
+        out[:, s, 0], out[:, s, 1], out[:, s, 2] = hi, mid, lo
     return out
 
 

@@ -103,13 +103,20 @@ def test_bf16x3_split_is_exact_and_packed_in_lane_order():
     hi, mid, lo = G.split_bf16x3(w)
     back = sum((p.astype(np.uint32) << 16).view(np.float32).astype(np.float64) for p in (hi, mid, lo))
     assert np.array_equal(back.astype(np.float32), w) and np.array_equal(back, w.astype(np.float64))
-    packed = G.pack_conv_weight_bx3(w)                       # cin 48 -> 2 chunks (the second half empty), 9 taps each
-    assert packed.shape == (16, 18, 3, 32)
-    val = sum((packed[:, :, p].astype(np.uint32) << 16).view(np.float32).astype(np.float64) for p in range(3))   # (16, 18, 32)
-    for c in range(2):
-        for tap in range(9):
-            for s in range(32):
-                ch = c * 32 + G.BX3_PERM[s]
-                want = w[:, ch, tap // 3, tap % 3] if ch < 48 else np.zeros(16, np.float32)
-                assert np.array_equal(val[:, c * 9 + tap, s], want.astype(np.float64)), (c, tap, s)
+    packed = G.pack_conv_weight_bx3(w)          # cin 48 -> one full chunk x 9 taps + 5 tap-paired tail steps
+    steps = G.bx3_ksteps(48, 3)
+    assert packed.shape == (16, 14, 3, 32) and len(steps) == 14
+    val = sum((packed[:, :, p].astype(np.uint32) << 16).view(np.float32).astype(np.float64) for p in range(3))   # (16, 14, 32)
+    seen = set()
+    for si, slots in enumerate(steps):
+        for pos in range(32):
+            sl = slots[G.BX3_PERM[pos]]
+            want = np.zeros(16, np.float32) if sl is None else w[:, sl[0], sl[1] // 3, sl[1] % 3]
+            assert np.array_equal(val[:, si, pos], want.astype(np.float64)), (si, pos)
+            if sl is not None:
+                seen.add(sl)
+    assert seen == {(c, t) for c in range(48) for t in range(9)}          # every (channel, tap) exactly once
+    assert steps[9][:16] == [(32 + i, 0) for i in range(16)] and steps[9][16:] == [(32 + i, 1) for i in range(16)]
+    assert steps[13][16:] == [None] * 16
+    assert len(G.bx3_ksteps(48, 1)) == 2 and len(G.bx3_ksteps(16, 3)) == 5 and len(G.bx3_ksteps(96, 3)) == 27
     assert sorted(G.BX3_PERM.tolist()) == list(range(32))
