@@ -365,6 +365,243 @@ __global__ void __launch_bounds__(64 * WM * WN, tap16_1_min_waves(WM * WN, MF * 
 #undef PADEL_T16_1STEP
 }
 
+// ===================================================================================================== double steps
+// The same kernels with 64-channel k-steps: two 64-byte sub-rows per tile row and step (A0 | A1 | B0 | B1), i.e. two
+// MFMAs per fragment pair between consecutive barriers.  The fp16 MFMAs are so short (16 cycles) that the fixed cost
+// of a k-step — counted wait, barrier, DMA issue — dominates the single-step kernels; doubling the work per step
+// amortises it.  No repacking: the two halves of a (chunk, tap) are adjacent 64-byte runs in pixels and weight rows
+// alike.  cin % 64 == 32: the 3x3 kernel's tail block pairs taps (A0 = tap 2t, A1 = tap 2t+1 of the last 32
+// channels; its weight rows are already tap-major), the 1x1 kernel switches the last step's second sub-row off —
+// for A AND for the weights (the bytes behind a weight row are not weights: 0 x NaN-pattern would poison the sum).
+#define PADEL_T16D_DMA(SR_, SA0_, SA1_, SB0_, SB1_, VA00_, VA01_, VA10_, VA11_, VBX_)                             \
+    do {                                                                                                          \
+        const unsigned sa0_ = (SA0_), sa1_ = (SA1_), sb0_ = (SB0_), sb1_ = (SB1_);                                \
+        dma16h<(SR_) * STAGE_B>((VA00_), rsrcA, sa0_, lds_wave);                                                  \
+        if constexpr (AP >= 2) dma16h<(SR_) * STAGE_B + RP * 64>((VA01_), rsrcA, sa0_, lds_wave);                 \
+        dma16h<(SR_) * STAGE_B + BM * 64>((VA10_), rsrcA, sa1_, lds_wave);                                        \
+        if constexpr (AP >= 2) dma16h<(SR_) * STAGE_B + BM * 64 + RP * 64>((VA11_), rsrcA, sa1_, lds_wave);       \
+        if constexpr (BFULL >= 1) dma16h<(SR_) * STAGE_B + 2 * BM * 64>(voffB[0], rsrcB, sb0_, lds_wave);         \
+        if constexpr (BFULL >= 2) dma16h<(SR_) * STAGE_B + 2 * BM * 64 + RP * 64>(voffB[1], rsrcB, sb0_, lds_wave); \
+        if constexpr (BP > BFULL) { if (b_last) dma16h<(SR_) * STAGE_B + 2 * BM * 64 + BFULL * RP * 64>(voffB[BP - 1], rsrcB, sb0_, lds_wave); } \
+        if constexpr (BFULL >= 1) dma16h<(SR_) * STAGE_B + (2 * BM + BN) * 64>((VBX_) ? kOutOfRange16 : voffB[0], rsrcB, sb1_, lds_wave); \
+        if constexpr (BFULL >= 2) dma16h<(SR_) * STAGE_B + (2 * BM + BN) * 64 + RP * 64>((VBX_) ? kOutOfRange16 : voffB[1], rsrcB, sb1_, lds_wave); \
+        if constexpr (BP > BFULL) { if (b_last) dma16h<(SR_) * STAGE_B + (2 * BM + BN) * 64 + BFULL * RP * 64>((VBX_) ? kOutOfRange16 : voffB[BP - 1], rsrcB, sb1_, lds_wave); } \
+    } while (0)
+
+#define PADEL_T16D_COMPUTE(ST_)                                                                                   \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int sub = 0; sub < 2; ++sub) {                                                     \
+            f32x4 A_[MF], B_[NF];                                                                                 \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) A_[f] = *reinterpret_cast<const f32x4*>(a_rd + (ST_) * STAGE + sub * BM * 16 + f * 256); \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j) B_[j] = *reinterpret_cast<const f32x4*>(b_rd + (ST_) * STAGE + sub * BN * 16 + j * 256); \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
+                _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                    \
+                    acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, B_[j]), __builtin_bit_cast(h8, A_[f]), acc[f][j], 0, 0, 0); \
+        }                                                                                                         \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+
+#define PADEL_T16D_GEOMETRY()                                                                                     \
+    constexpr int NW = WM * WN;                                                                                   \
+    constexpr int RP = NW * 16;                                                                                   \
+    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;                                                           \
+    constexpr int AP = BM / RP, BP = (BN + RP - 1) / RP, BFULL = BN / RP;                                         \
+    constexpr int STAGE = 2 * (BM + BN) * 16;      /* 4-byte words per ring stage: A0 | A1 | B0 | B1 */           \
+    constexpr int STAGE_B = STAGE * 4;                                                                            \
+    constexpr int NREQ = 2 * AP + 2 * BFULL;                                                                      \
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");                                              \
+    static_assert(BM % RP == 0 && AP <= 2 && BFULL <= 2, "A in 1-2 full passes, B in at most 2 full + 1 partial"); \
+    static_assert(3 * STAGE_B <= 160 * 1024, "ring must fit the LDS");                                            \
+    __shared__ __attribute__((aligned(16))) float lds[3 * STAGE];                                                 \
+    const int tid = threadIdx.x;                                                                                  \
+    const int lane = tid & 63;                                                                                    \
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                    \
+    const int lr = lane & 15, lq = lane >> 4;                                                                     \
+    const int wm = wave / WN, wn = wave % WN;                                                                     \
+    const int nmt = a.n_mtiles;                                                                                   \
+    const int bid = blockIdx.x;                                                                                   \
+    const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;                                           \
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                 \
+    const int m0 = mt * BM;                                                                                       \
+    const int f0 = blockIdx.y * (WN * NF);                                                                        \
+    const int HoWo = a.Ho * a.Wo;                                                                                 \
+    const int srow = tid >> 2;                                                                                    \
+    const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);                                                     \
+    const int n0 = fastdiv16(m0, a.howo_magic, a.howo_shift), rem0 = m0 - n0 * HoWo;                              \
+    const int oy0 = fastdiv16(rem0, a.wo_magic, a.wo_shift), ox0 = rem0 - oy0 * a.Wo;                             \
+    const long long lin0 = ((long long)n0 * a.H + oy0 * a.stride) * a.W + ox0 * a.stride;                         \
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + wave * 1024u);            \
+    const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);                                       \
+    const float* const a_rd = lds + (wm * MF * 16) * 16 + ld_off;                                                 \
+    const float* const b_rd = lds + 2 * BM * 16 + (wn * NF * 16) * 16 + ld_off;                                   \
+    const bool b_last = BP > BFULL && (BFULL * RP + wave * 16 < BN);                                              \
+    const _Float16* const in16 = reinterpret_cast<const _Float16*>(a.in);                                         \
+    const _Float16* const w16 = reinterpret_cast<const _Float16*>(a.w);                                           \
+    f32x4 acc[MF][NF];                                                                                            \
+    _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                                \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+constexpr int min_waves16d(int nw, int frags) { return nw == 4 ? (frags <= 6 ? 3 : 2) : 2; }
+
+template <int WM, int WN, int MF, int NF>
+__global__ void __launch_bounds__(64 * WM * WN, min_waves16d(WM * WN, MF * NF)) conv_tap16d_kernel(const ConvArgs a) {
+    PADEL_T16D_GEOMETRY()
+    const int nfull = a.cin >> 6;
+    const bool has_tail = (a.cin & 32) != 0;
+    const int Ktot = (nfull * 18 + (has_tail ? 9 : 0)) * 32;      // halves per weight row (same packing as the single-step kernel)
+
+    unsigned voffA[AP][9];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        int m = m0 + srow + RP * p;
+        const bool rv = m < a.M;
+        if (!rv) m = m0;
+        const int n = fastdiv16(m, a.howo_magic, a.howo_shift);
+        const int rem = m - n * HoWo;
+        const int oy = fastdiv16(rem, a.wo_magic, a.wo_shift);
+        const int ox = rem - oy * a.Wo;
+        const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
+        const unsigned off = (unsigned)((lin - lin0) * a.in_cs * 2 + sc * 16);
+        bool vy[3], vx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            vy[d] = rv && (unsigned)(oy * a.stride - 1 + d) < (unsigned)a.H;
+            vx[d] = (unsigned)(ox * a.stride - 1 + d) < (unsigned)a.W;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) voffA[p][t] = (vy[t / 3] && vx[t % 3]) ? off : kOutOfRange16;
+    }
+    const i32x4 rsrcA = make_rsrc16(in16 + ((lin0 - (a.W + 1)) * a.in_cs + a.in_choff));
+    unsigned tapoff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((unsigned)(((t / 3) * a.W + (t % 3)) * a.in_cs * 2));
+    PADEL_T16_WEIGHTS()
+
+    unsigned s_chunk = 0, s_kb = 0;
+#define PADEL_T16D_REQ_FULL(SR_, CH_, KB_, T_)                                                                    \
+    PADEL_T16D_DMA(SR_, (CH_) + tapoff[T_], (CH_) + tapoff[T_] + 64u, KB_, (KB_) + 64u,                           \
+                   voffA[0][T_], voffA[AP - 1][T_], voffA[0][T_], voffA[AP - 1][T_], false)
+#define PADEL_T16D_REQ_TAIL(SR_, CH_, KB_, JT_)                                                                   \
+    PADEL_T16D_DMA(SR_, (CH_) + tapoff[2 * (JT_)], (CH_) + tapoff[2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8], KB_, (KB_) + 64u, \
+                   voffA[0][2 * (JT_)], voffA[AP - 1][2 * (JT_)],                                                 \
+                   2 * (JT_) + 1 < 9 ? voffA[0][2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] : kOutOfRange16,           \
+                   2 * (JT_) + 1 < 9 ? voffA[AP - 1][2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] : kOutOfRange16,      \
+                   2 * (JT_) + 1 >= 9)
+    bool nxt_tail = false;
+#define PADEL_T16D_STEP(J)                                                                                        \
+    do {                                                                                                          \
+        wait_vm16<NREQ>();                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        if constexpr ((J) + 2 < 9) {                                                                              \
+            PADEL_T16D_REQ_FULL(((J) + 2) % 3, s_chunk, s_kb + ((J) + 2) * 128u, (J) + 2 < 9 ? (J) + 2 : 0);      \
+        } else {                                                                                                  \
+            if (nxt_tail) { PADEL_T16D_REQ_TAIL(((J) + 2) % 3, s_chunk + 128u, s_kb + ((J) + 2) * 128u, ((J) + 2) % 9); } \
+            else { PADEL_T16D_REQ_FULL(((J) + 2) % 3, s_chunk + 128u, s_kb + ((J) + 2) * 128u, ((J) + 2) % 9); }  \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_T16D_COMPUTE((J) % 3);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define PADEL_T16D_TSTEP(JT)                                                                                      \
+    do {                                                                                                          \
+        if constexpr ((JT) == 4) wait_vm16<0>(); else wait_vm16<NREQ>();                                          \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        if constexpr ((JT) + 2 < 5) { PADEL_T16D_REQ_TAIL(((JT) + 2) % 3, s_chunk, s_kb + ((JT) + 2) * 128u, (JT) + 2 < 5 ? (JT) + 2 : 0); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_T16D_COMPUTE((JT) % 3);                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+
+    if (nfull > 0) {
+        PADEL_T16D_REQ_FULL(0, 0u, 0u, 0);
+        PADEL_T16D_REQ_FULL(1, 0u, 128u, 1);
+    } else {
+        PADEL_T16D_REQ_TAIL(0, 0u, 0u, 0);
+        PADEL_T16D_REQ_TAIL(1, 0u, 128u, 1);
+    }
+    for (int c = 0; c < nfull; ++c) {
+        nxt_tail = has_tail && c == nfull - 1;
+        PADEL_T16D_STEP(0); PADEL_T16D_STEP(1); PADEL_T16D_STEP(2); PADEL_T16D_STEP(3); PADEL_T16D_STEP(4);
+        PADEL_T16D_STEP(5); PADEL_T16D_STEP(6); PADEL_T16D_STEP(7); PADEL_T16D_STEP(8);
+        s_chunk += 128u;
+        s_kb += 9u * 128u;
+    }
+    if (has_tail) {
+        PADEL_T16D_TSTEP(0); PADEL_T16D_TSTEP(1); PADEL_T16D_TSTEP(2); PADEL_T16D_TSTEP(3); PADEL_T16D_TSTEP(4);
+    } else {
+        wait_vm16<0>();
+    }
+    PADEL_T16_FINISH()
+#undef PADEL_T16D_STEP
+#undef PADEL_T16D_TSTEP
+#undef PADEL_T16D_REQ_FULL
+#undef PADEL_T16D_REQ_TAIL
+}
+
+template <int WM, int WN, int MF, int NF>
+__global__ void __launch_bounds__(64 * WM * WN, min_waves16d(WM * WN, MF * NF)) conv_tap16d_1_kernel(const ConvArgs a) {
+    PADEL_T16D_GEOMETRY()
+    const int nks = (a.cin + 63) >> 6;            // 64 channels per k-step; the last one half empty if cin & 32
+    const bool half_tail = (a.cin & 32) != 0;
+    const int Ktot = (a.cin >> 5) * 32;
+
+    unsigned voffA[AP];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        int m = m0 + srow + RP * p;
+        const bool rv = m < a.M;
+        if (!rv) m = m0;
+        const int n = fastdiv16(m, a.howo_magic, a.howo_shift);
+        const int rem = m - n * HoWo;
+        const int oy = fastdiv16(rem, a.wo_magic, a.wo_shift);
+        const int ox = rem - oy * a.Wo;
+        const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
+        voffA[p] = rv ? (unsigned)((lin - lin0) * a.in_cs * 2 + sc * 16) : kOutOfRange16;
+    }
+    const i32x4 rsrcA = make_rsrc16(in16 + (lin0 * a.in_cs + a.in_choff));
+    PADEL_T16_WEIGHTS()
+
+    unsigned s_k = 0;
+#define PADEL_T16D_OFF1(K_) (half_tail && (int)(K_) >= nks - 1)
+#define PADEL_T16D_REQ1(SR_, K_)                                                                                  \
+    PADEL_T16D_DMA(SR_, (K_) * 128u, (K_) * 128u + 64u, (K_) * 128u, (K_) * 128u + 64u, voffA[0], voffA[AP - 1],  \
+                   PADEL_T16D_OFF1(K_) ? kOutOfRange16 : voffA[0], PADEL_T16D_OFF1(K_) ? kOutOfRange16 : voffA[AP - 1], PADEL_T16D_OFF1(K_))
+#define PADEL_T16D_1STEP(J)                                                                                       \
+    if ((J) < nb) {                                                                                               \
+        wait_vm16<NREQ>();                                                                                        \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        PADEL_T16D_REQ1(((J) + 2) % 3, s_k + (J) + 2);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_T16D_COMPUTE((J) % 3);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }
+    PADEL_T16D_REQ1(0, 0u);
+    PADEL_T16D_REQ1(1, 1u);
+    for (int k = 0; k < nks; k += 9) {
+        const int nb = min(9, nks - k);
+        PADEL_T16D_1STEP(0) PADEL_T16D_1STEP(1) PADEL_T16D_1STEP(2) PADEL_T16D_1STEP(3) PADEL_T16D_1STEP(4)
+        PADEL_T16D_1STEP(5) PADEL_T16D_1STEP(6) PADEL_T16D_1STEP(7) PADEL_T16D_1STEP(8)
+        s_k += 9u;
+    }
+    wait_vm16<0>();
+    PADEL_T16_FINISH()
+#undef PADEL_T16D_1STEP
+#undef PADEL_T16D_REQ1
+#undef PADEL_T16D_OFF1
+}
+
+template <int WM, int WN, int MF, int NF>
+static hipError_t launch_t16d(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    constexpr int BM = WM * MF * 16;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
+    if (a.ksize == 3) hipLaunchKernelGGL((conv_tap16d_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+    else hipLaunchKernelGGL((conv_tap16d_1_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int WM, int WN, int MF, int NF>
 static hipError_t launch_t16(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
@@ -389,13 +626,23 @@ hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s) {
         case 30: return launch_t16<2, 2, 4, 4>(a, s);   // 128 x 128, 4 waves of 64 x 64
         case 31: return launch_t16<2, 2, 4, 3>(a, s);   // 128 x  96
         case 32: return launch_t16<2, 2, 4, 2>(a, s);   // 128 x  64
+        // + 40: the same tile with 64-channel (double) k-steps
+        case 46: return launch_t16d<2, 2, 2, 4>(a, s);  //  64 x 128
+        case 47: return launch_t16d<2, 2, 2, 3>(a, s);  //  64 x  96
+        case 49: return launch_t16d<4, 1, 2, 4>(a, s);  // 128 x  64
+        case 51: return launch_t16d<4, 1, 2, 2>(a, s);  // 128 x  32
+        case 60: return launch_t16d<4, 1, 2, 3>(a, s);  // 128 x  48
+        case 70: return launch_t16d<2, 2, 4, 4>(a, s);  // 128 x 128
+        case 71: return launch_t16d<2, 2, 4, 3>(a, s);  // 128 x  96
+        case 72: return launch_t16d<2, 2, 4, 2>(a, s);  // 128 x  64
     }
     return hipErrorNotSupported;
 }
 
 bool conv_tap16_variant_shape(int variant, int* bm, int* bn) {
     static const int t[][3] = {{6, 64, 128}, {7, 64, 96}, {9, 128, 64}, {11, 128, 32}, {12, 128, 16}, {20, 128, 48},
-                               {30, 128, 128}, {31, 128, 96}, {32, 128, 64}};
+                               {30, 128, 128}, {31, 128, 96}, {32, 128, 64},
+                               {46, 64, 128}, {47, 64, 96}, {49, 128, 64}, {51, 128, 32}, {60, 128, 48}, {70, 128, 128}, {71, 128, 96}, {72, 128, 64}};
     for (const auto& v : t)
         if (v[0] == variant) { *bm = v[1]; *bn = v[2]; return true; }
     return false;
@@ -404,13 +651,19 @@ bool conv_tap16_variant_shape(int variant, int* bm, int* bn) {
 // Tile choice: these kernels are issue- / HBM-bound, not MFMA-bound, so (a) the channel tile should cover all of
 // cout when it can (every extra channel tile re-reads the whole input from L2 / HBM), (b) bigger per-wave tiles
 // amortise the fixed per-k-step instruction cost, (c) the grid still has to fill 256 CUs.
-int choose_conv_tap16_variant(int M, int n16) {
-    struct V { int id, bm, nf; float speed; };
-    static const V vs[] = {{30, 128, 8, 1.30f}, {31, 128, 6, 1.25f}, {32, 128, 4, 1.10f}, {6, 64, 8, 1.05f},
-                           {7, 64, 6, 1.00f},   {9, 128, 4, 1.00f},  {20, 128, 3, 0.95f}, {11, 128, 2, 0.85f}, {12, 128, 1, 0.60f}};
+int choose_conv_tap16_variant(int M, int n16, int ksize, int cin) {
+    struct V { int id, bm, nf; float speed; bool dbl; };
+    // double-step tiles (ids + 40) win where K is a whole number of 64-channel steps and long enough to matter:
+    // 3x3 with cin % 64 == 0 (yolov8m 192 -> 192 / 304: 684-696 vs 626 TFLOP/s, profiles/conv_tap16_sweep_r2i.txt);
+    // with a 32-channel tail or on the short-K 1x1 layers the single-step tiles stay ahead
+    static const V vs[] = {{30, 128, 8, 1.30f, false}, {31, 128, 6, 1.25f, false}, {32, 128, 4, 1.10f, false}, {6, 64, 8, 1.05f, false},
+                           {7, 64, 6, 1.00f, false},   {9, 128, 4, 1.00f, false},  {20, 128, 3, 0.95f, false}, {11, 128, 2, 0.85f, false},
+                           {12, 128, 1, 0.60f, false}, {49, 128, 4, 1.40f, true},  {72, 128, 4, 1.40f, true}};
+    const bool dbl_ok = ksize == 3 && (cin & 63) == 0 && cin >= 128;
     float best = -1.f;
     int bv = 7;
     for (const V& v : vs) {
+        if (v.dbl && !dbl_ok) continue;
         const int ntiles = (n16 + v.nf - 1) / v.nf;
         const long long mtiles = (M + v.bm - 1) / v.bm;
         const float fill = (float)n16 / (float)(ntiles * v.nf) * (float)M / (float)(mtiles * v.bm);
@@ -418,7 +671,7 @@ int choose_conv_tap16_variant(int M, int n16) {
         const long long per_cu = (blocks + 255) / 256;
         const float occ = (float)blocks / (256.f * (float)per_cu);
         const float reread = 1.0f / (1.0f + 0.25f * (float)(ntiles - 1));        // input re-read per extra channel tile
-        const float sc = v.speed * fill * occ * reread;
+        const float sc = v.speed * fill * occ * (v.dbl ? 1.0f : reread);
         if (sc > best) { best = sc; bv = v.id; }
     }
     return bv;

@@ -576,7 +576,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.w3 = use_bx3 ? (const void*)(m->d_w + o.reserved) : nullptr;
             a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
             const int lv = e->t.variant >= 0 ? e->t.variant
-                           : f16 ? choose_conv_tap16_variant(a.M, a.n16)
+                           : f16 ? choose_conv_tap16_variant(a.M, a.n16, o.ksize, o.cin)
                            : use_bx3 ? choose_conv_bx3_variant(a.M, a.n16, o.ksize)
                                  : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
             int bm = 0, bn = 0;

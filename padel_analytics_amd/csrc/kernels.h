@@ -67,7 +67,7 @@ int choose_conv_bx3_variant(int M, int n16, int ksize);
 // fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and
 // choff count elements); cin % 32 == 0; weights packed [Npad][Ktot] with K order (64-channel chunk, tap, 32-channel half)
 hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s);
-int choose_conv_tap16_variant(int M, int n16);
+int choose_conv_tap16_variant(int M, int n16, int ksize, int cin);
 bool conv_tap16_variant_shape(int variant, int* bm, int* bn);
 
 struct StemArgs {

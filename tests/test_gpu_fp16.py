@@ -35,7 +35,7 @@ CASES = [
     (3, 17, 23, 160, 96, 3, 1, G.ACT_SILU, True),     # two chunks + tail, odd spatial size
     (2, 16, 16, 64, 39, 1, 1, G.ACT_NONE, False),     # cout not a multiple of 4: element-wise epilogue
 ]
-VARIANTS = (6, 7, 9, 11, 12, 20, 30, 31, 32)
+VARIANTS = (6, 7, 9, 11, 12, 20, 30, 31, 32, 46, 47, 49, 51, 60, 70, 71, 72)
 
 
 def _run(eng, case, x16, w, b, wr):
