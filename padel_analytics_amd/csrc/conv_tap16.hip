@@ -176,12 +176,17 @@ __device__ __forceinline__ void t16_epilogue(const ConvArgs& a, const f32x4 (&ac
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                    \
     const int lr = lane & 15, lq = lane >> 4;                                                                     \
     const int wm = wave / WN, wn = wave % WN;                                                                     \
-    const int nmt = a.n_mtiles;                                                                                   \
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;                                                                 \
     const int bid = blockIdx.x;                                                                                   \
+    /* XCD-aware 1-D tile map: XCD x (= bid % 8, how the hardware deals out workgroups) owns a contiguous range of  \
+       pixel tiles, and inside an XCD consecutive workgroups are the CHANNEL tiles of one pixel tile — they run    \
+       concurrently on that XCD, so the input tile is fetched from HBM once and re-read from its L2 */             \
     const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;                                           \
-    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                 \
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;                                                            \
+    if (mloc >= q + (xcd < r ? 1 : 0)) return;       /* grid is padded to 8 x max tiles per XCD */                \
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + mloc;                                \
     const int m0 = mt * BM;                                                                                       \
-    const int f0 = blockIdx.y * (WN * NF);                                                                        \
+    const int f0 = nt * (WN * NF);                                                                                \
     const int HoWo = a.Ho * a.Wo;                                                                                 \
     const int srow = tid >> 2;                                                                                    \
     const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);                                                     \
@@ -419,12 +424,17 @@ __global__ void __launch_bounds__(64 * WM * WN, tap16_1_min_waves(WM * WN, MF * 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                    \
     const int lr = lane & 15, lq = lane >> 4;                                                                     \
     const int wm = wave / WN, wn = wave % WN;                                                                     \
-    const int nmt = a.n_mtiles;                                                                                   \
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;                                                                 \
     const int bid = blockIdx.x;                                                                                   \
+    /* XCD-aware 1-D tile map: XCD x (= bid % 8, how the hardware deals out workgroups) owns a contiguous range of  \
+       pixel tiles, and inside an XCD consecutive workgroups are the CHANNEL tiles of one pixel tile — they run    \
+       concurrently on that XCD, so the input tile is fetched from HBM once and re-read from its L2 */             \
     const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;                                           \
-    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                 \
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;                                                            \
+    if (mloc >= q + (xcd < r ? 1 : 0)) return;       /* grid is padded to 8 x max tiles per XCD */                \
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + mloc;                                \
     const int m0 = mt * BM;                                                                                       \
-    const int f0 = blockIdx.y * (WN * NF);                                                                        \
+    const int f0 = nt * (WN * NF);                                                                                \
     const int HoWo = a.Ho * a.Wo;                                                                                 \
     const int srow = tid >> 2;                                                                                    \
     const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);                                                     \
@@ -596,7 +606,8 @@ static hipError_t launch_t16d(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
-    dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
+    a.n_ntiles = (a.n16 + WN * NF - 1) / (WN * NF);
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
     if (a.ksize == 3) hipLaunchKernelGGL((conv_tap16d_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     else hipLaunchKernelGGL((conv_tap16d_1_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     return hipGetLastError();
@@ -607,7 +618,8 @@ static hipError_t launch_t16(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
-    dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
+    a.n_ntiles = (a.n16 + WN * NF - 1) / (WN * NF);
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
     if (a.ksize == 3) hipLaunchKernelGGL((conv_tap16_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     else hipLaunchKernelGGL((conv_tap16_1_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     return hipGetLastError();

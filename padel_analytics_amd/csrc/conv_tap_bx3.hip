@@ -221,12 +221,17 @@ __device__ __forceinline__ void bx3_epilogue(const ConvArgs& a, const f32x4 (&ac
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                    \
     const int lr = lane & 15, lq = lane >> 4;                                                                     \
     const int wm = wave / WN, wn = wave % WN;                                                                     \
-    const int nmt = a.n_mtiles;                                                                                   \
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;                                                                 \
     const int bid = blockIdx.x;                                                                                   \
+    /* XCD-aware 1-D tile map: XCD x (= bid % 8, how the hardware deals out workgroups) owns a contiguous range of  \
+       pixel tiles, and inside an XCD consecutive workgroups are the CHANNEL tiles of one pixel tile — they run    \
+       concurrently on that XCD, so the input tile is fetched from HBM once and re-read from its L2 */             \
     const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;                                           \
-    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;                                 \
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;                                                            \
+    if (mloc >= q + (xcd < r ? 1 : 0)) return;       /* grid is padded to 8 x max tiles per XCD */                \
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + mloc;                                \
     const int m0 = mt * BM;                                                                                       \
-    const int f0 = blockIdx.y * (WN * NF);                                                                        \
+    const int f0 = nt * (WN * NF);                                                                                \
     const int HoWo = a.Ho * a.Wo;                                                                                 \
     const int srow = tid >> 2;                                                                                    \
     const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);                                                     \
@@ -411,7 +416,8 @@ static hipError_t launch_b3(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     constexpr int BM = WM * MF * 16;
     a.n_mtiles = (a.M + BM - 1) / BM;
-    dim3 grid(a.n_mtiles, (a.n16 + WN * NF - 1) / (WN * NF), 1);
+    a.n_ntiles = (a.n16 + WN * NF - 1) / (WN * NF);
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
     if (a.ksize == 3) hipLaunchKernelGGL((conv_bx3_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     else hipLaunchKernelGGL((conv_bx3_1_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     return hipGetLastError();
@@ -434,15 +440,16 @@ hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s) {
     return hipErrorNotSupported;
 }
 
-// Relative tile speeds measured on MI355X (profiles/conv_bx3_sweep_r2d.txt): 3x3 — 64x96 and 128x48 (4 waves, 2
-// workgroups per CU) lead at 173-189 TFLOP/s on the yolov8m bottlenecks, the 8-wave tiles follow at ~0.9; 1x1 — the
-// 8-wave tiles lead (138-160 on the wide C2f cv2 layers).  As for the fp32 kernels the rest is padding waste and the
-// fill of the last round of workgroups.
+// Relative tile speeds measured on MI355X (profiles/conv_bx3_sweep_r2d.txt, ..._r2j.txt): 3x3 — 64x96 and 128x48 (4
+// waves, 2 workgroups per CU) lead at 173-189 TFLOP/s on the yolov8m bottlenecks, the 8-wave tiles follow at ~0.9;
+// 1x1 — since the channel tiles of a pixel tile run side by side on one XCD (the input is fetched from HBM once) the
+// same two tiles lead there too (147-169 on the wide C2f cv2 layers).  The rest is padding waste and the fill of the
+// last round of workgroups.
 int choose_conv_bx3_variant(int M, int n16, int ksize) {
     struct V { int id, bm, nf; float s3, s1; };
-    static const V vs[] = {{7, 64, 6, 1.00f, 0.92f},  {20, 128, 3, 1.00f, 0.72f}, {13, 128, 6, 0.92f, 1.00f}, {14, 128, 8, 0.90f, 1.00f},
-                           {25, 64, 5, 0.97f, 0.85f},
-                           {11, 128, 2, 0.86f, 0.50f}, {9, 128, 4, 0.70f, 0.80f},  {6, 64, 8, 0.55f, 0.56f},  {12, 128, 1, 0.45f, 0.30f}};
+    static const V vs[] = {{7, 64, 6, 1.00f, 0.97f},  {20, 128, 3, 1.00f, 1.00f}, {13, 128, 6, 0.92f, 0.94f}, {14, 128, 8, 0.90f, 0.98f},
+                           {25, 64, 5, 0.97f, 0.90f},
+                           {11, 128, 2, 0.86f, 0.70f}, {9, 128, 4, 0.70f, 0.80f},  {6, 64, 8, 0.55f, 0.56f},  {12, 128, 1, 0.45f, 0.30f}};
     float best = -1.f;
     int bv = 7;
     for (const V& v : vs) {

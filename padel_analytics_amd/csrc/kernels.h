@@ -30,7 +30,8 @@ struct ConvArgs {
     int ksize, stride;    // 1 or 3 ; 1 or 2   (pad = ksize/2)
     int act;
     int M;                // batch * Ho * Wo
-    int n_mtiles;         // ceil(M / (4 * MF * 16))
+    int n_mtiles;         // ceil(M / BM)
+    int n_ntiles;         // bx3 / fp16 kernels (1-D grid): channel tiles per pixel tile
     int tune;             // bit 0: s_setprio(1) around MFMA clusters; bit 1: staggered workgroup start
     int tap_pd;           // 1x1 tap kernel: prefetch distance 2 or 3 (pa_engine_set_tuning "tap_pd")
     int out_f32;          // fp16 kernels only: 1 = `out` is an fp32 buffer (convs that feed the Detect/Pose decode)
