@@ -64,7 +64,11 @@ constexpr size_t kConvReadSlack = 512;
 int choose_conv_tap_variant(int M, int n16);
 // fp32 convolutions on the bf16 matrix pipe (conv_tap_bx3.hip): exact 3-way bf16 split, 6 products, fp32 accumulate
 hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s);      // ids 6,7,9,11,12,13,14,20
-int choose_conv_bx3_variant(int M, int n16, int ksize);
+int choose_conv_bx3_variant(const ConvArgs& a);      // per-layer tile heuristic (ids + 200: 2-stage ring, 30x: patch kernel)
+// stride-1 3x3, cin % 32 == 0: 8 x 16-pixel patch kernel (conv_patch_bx3.hip), the input patch is split once per chunk;
+// nf = channel fragments per workgroup (3, 4, 6); reached through launch_conv_bx3 ids 303 / 304 / 306
+bool conv_bx3p_supported(const ConvArgs& a);
+hipError_t launch_conv_bx3p(const ConvArgs& a, int nf, hipStream_t s);
 // fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and
 // choff count elements); cin % 32 == 0; weights packed [Npad][Ktot] with K order (64-channel chunk, tap, 32-channel half)
 hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s);

@@ -30,7 +30,7 @@ CASES = [
 
 LDS_VARIANTS = tuple(range(13))
 TAP_VARIANTS = (6, 7, 9, 10, 11, 12, 13, 14, 15, 20)
-BX3_VARIANTS = (6, 7, 9, 11, 12, 13, 14, 20, 25)      # bf16x3 kernels (conv_tap_bx3.hip): fp32 accuracy, own rounding
+BX3_VARIANTS = (6, 7, 9, 11, 12, 13, 14, 20, 25, 206, 207, 209, 211, 220, 225, 303, 304, 306)      # bf16x3 kernels (conv_tap_bx3.hip): fp32 accuracy, own rounding
 
 
 def _run(eng, case, x, w, b, wr):

@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
+cd $R
+timeout 900 python -m pytest tests/test_gpu_conv.py tests/test_gpu_bench_config.py -m gpu -q -rf --tb=short -x 2>&1 | tail -6
+timeout 300 python tools/conv_bench.py --reps 3 --tiles B,B7,B207,B20,B220,B14,B206,B13,B209,B211 --shapes "1x1,n.P" > gpurun_out/conv_sweep_bx3_r2l.txt 2>&1; cat gpurun_out/conv_sweep_bx3_r2l.txt
+timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r2l_bench_c3.json 2> gpurun_out/r2l_bench_c3.err; cat gpurun_out/r2l_bench_c3.json
