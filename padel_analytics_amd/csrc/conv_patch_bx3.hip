@@ -17,7 +17,7 @@
 // kernel, so results are bitwise identical to it (tests/test_gpu_conv.py).
 //
 // LDS: 3 planes x 180 pixels x 64 B = 34 560 B + 2 weight stages of 3 x BN x 64 B: 52 992 B for BN = 48 -> 3 workgroups
-// per CU.  Scope: ksize 3, stride 1, cin % 32 == 0 (launch_conv_bx3p reports anything else as not supported and the
+// per CU.  Scope: ksize 3, stride 1, cin % 16 == 0 (launch_conv_bx3p reports anything else as not supported and the
 // dispatcher keeps the tap kernel for it).
 #include "bx3_common.h"
 
@@ -53,11 +53,18 @@ __device__ __forceinline__ void split4(const u32x4 x, u32x2& hi, u32x2& mid, u32
     }
 }
 
+// tail planes: 32 bytes per pixel, 8-byte slot q (4 channels)
+__device__ __forceinline__ unsigned tail_off(int p, int q) { return (unsigned)(p * 32 + ((q ^ (((p >> 3) & 1) << 1)) << 3)); }
+constexpr int kTailPasses = (kNPix * 4 + 255) / 256;     // 3
+
 __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 }  // namespace
 
-template <int NF>
+// TAIL: cin % 32 == 16 — after the full chunks a 16-channel patch (32 bytes per pixel and plane) is walked in 5 k-steps
+// that pair TAPS like the tap kernel's tail block: K slots 0-3 of a lane = its 4 channels at tap 2t, slots 4-7 = at tap
+// 2t + 1 (two ds_read_b64 per operand; 8-byte slot q of pixel p lives at q ^ 2 * ((p >> 3) & 1): conflict-free)
+template <int NF, bool TAIL>
 __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const ConvArgs a) {
     constexpr int MF = 2;
     constexpr int BN = NF * 16;
@@ -103,7 +110,7 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
 
     // ---- weights: rows of (cin / 32) * 9 k-steps x 192 bytes (hi | mid | lo), k-step = chunk * 9 + tap
     const int nch = a.cin >> 5;
-    const unsigned rowb = (unsigned)(nch * 9) * 192u;
+    const unsigned rowb = (unsigned)(nch * 9 + (TAIL ? 5 : 0)) * 192u;
     const int srow = tid >> 2;
     const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);
     unsigned voffB[BP];
@@ -155,6 +162,28 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
             am[f] = *reinterpret_cast<const bf8*>(p_ + kPlaneB);                                                  \
             al[f] = *reinterpret_cast<const bf8*>(p_ + 2 * kPlaneB);                                              \
         }                                                                                                         \
+        PADEL_P_MFMA(T_);                                                                                         \
+    } while (0)
+    // tail step JT: taps 2 JT and 2 JT + 1 (the 10th "tap" has zero weights: any finite data, tap 8 again)
+#define PADEL_P_TCOMPUTE(JT_)                                                                                     \
+    do {                                                                                                          \
+        bf8 ah[MF], am[MF], al[MF];                                                                               \
+        constexpr int ta_ = 2 * (JT_), tb_ = 2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8;                               \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
+            const char* pa_ = ldsb + tail_off(rd_pix + (f + ta_ / 3) * kPW + ta_ % 3, lq);                        \
+            const char* pb_ = ldsb + tail_off(rd_pix + (f + tb_ / 3) * kPW + tb_ % 3, lq);                        \
+            u32x4 v_;                                                                                             \
+            { const u32x2 x_ = *reinterpret_cast<const u32x2*>(pa_), y_ = *reinterpret_cast<const u32x2*>(pb_);    \
+              v_ = (u32x4){x_[0], x_[1], y_[0], y_[1]}; ah[f] = __builtin_bit_cast(bf8, v_); }                    \
+            { const u32x2 x_ = *reinterpret_cast<const u32x2*>(pa_ + kPlaneB), y_ = *reinterpret_cast<const u32x2*>(pb_ + kPlaneB); \
+              v_ = (u32x4){x_[0], x_[1], y_[0], y_[1]}; am[f] = __builtin_bit_cast(bf8, v_); }                    \
+            { const u32x2 x_ = *reinterpret_cast<const u32x2*>(pa_ + 2 * kPlaneB), y_ = *reinterpret_cast<const u32x2*>(pb_ + 2 * kPlaneB); \
+              v_ = (u32x4){x_[0], x_[1], y_[0], y_[1]}; al[f] = __builtin_bit_cast(bf8, v_); }                    \
+        }                                                                                                         \
+        PADEL_P_MFMA(JT_);                                                                                        \
+    } while (0)
+#define PADEL_P_MFMA(T_)                                                                                          \
+    do {                                                                                                          \
         const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
         bf8 wh[NF], wm[NF], wl[NF];                                                                               \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
@@ -186,16 +215,41 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
         lds_fence();                                                                                              \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
-        if ((T_) < 8 || c + 1 < nch) PADEL_P_DMAB((T_) + 1, s_kb + ((T_) + 1) * 192u);                            \
-        if ((T_) == 0 && c + 1 < nch) PADEL_P_LOAD(c + 1);                                                        \
+        if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_P_DMAB((T_) + 1, s_kb + ((T_) + 1) * 192u);                    \
+        if ((T_) == 0 && c + 1 < nch) PADEL_P_LOAD(c + 1);    /* one request per tap step instead: measured -1 % */ \
+        if constexpr (TAIL) { if ((T_) == 0 && c + 1 == nch) PADEL_P_TLOAD(); }                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_P_COMPUTE(T_);                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 
+    // tail patch: 180 pixels x 4 pieces of 4 channels
+#define PADEL_P_TLOAD()                                                                                           \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < kTailPasses; ++i) {                                                 \
+            const int item = i * 256 + tid;                                                                       \
+            const int pp = item >> 2, c4 = item & 3;                                                              \
+            const int py = pp / kPW, px = pp - py * kPW;                                                          \
+            const bool ok = item < kNPix * 4 && (unsigned)(y0 - 1 + py) < (unsigned)a.H && (unsigned)(x0 - 1 + px) < (unsigned)a.W; \
+            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, ok ? (unsigned)(((py * a.W + px) * a.in_cs + c4 * 4) * 4) : kOOR3, \
+                                                           (unsigned)nch * 128u, 0);                              \
+        }                                                                                                         \
+    } while (0)
+#define PADEL_P_TSTEP(JT_)                                                                                        \
+    do {                                                                                                          \
+        wait_vm3<0>();                                                                                            \
+        lds_fence();                                                                                              \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        asm volatile("" ::: "memory");                                                                            \
+        if constexpr ((JT_) < 4) PADEL_P_DMAB((JT_) + 1, s_kb + ((JT_) + 1) * 192u);                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_P_TCOMPUTE(JT_);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+
     u32x4 pre[kPasses];
     unsigned s_kb = 0;
-    PADEL_P_LOAD(0);
+    if (!TAIL || nch > 0) PADEL_P_LOAD(0); else PADEL_P_TLOAD();
     PADEL_P_DMAB(0, 0u);
     for (int c = 0; c < nch; ++c) {
         if (c > 0) {                          // every wave is done with the taps of chunk c - 1: the planes may be overwritten
@@ -221,7 +275,35 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
         { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; }
         s_kb += 9u * 192u;
     }
+    if constexpr (TAIL) {
+        if (nch > 0) {
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < kTailPasses; ++i) {
+            const int item = i * 256 + tid;
+            const int pp = item >> 2, c4 = item & 3;
+            u32x2 h, m, l;
+            split4(pre[i], h, m, l);
+            if (item < kNPix * 4) {
+                char* const w_ = ldsb + tail_off(pp, c4);
+                *reinterpret_cast<u32x2*>(w_) = h;
+                *reinterpret_cast<u32x2*>(w_ + kPlaneB) = m;
+                *reinterpret_cast<u32x2*>(w_ + 2 * kPlaneB) = l;
+            }
+        }
+        PADEL_P_TSTEP(0); PADEL_P_TSTEP(1); PADEL_P_TSTEP(2); PADEL_P_TSTEP(3); PADEL_P_TSTEP(4);
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];
+    }
     wait_vm3<0>();
+#undef PADEL_P_TSTEP
+#undef PADEL_P_TLOAD
+#undef PADEL_P_TCOMPUTE
+#undef PADEL_P_MFMA
 #undef PADEL_P_STEP
 #undef PADEL_P_COMPUTE
 #undef PADEL_P_LOAD
@@ -239,19 +321,25 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
     bx3_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
 }
 
-template <int NF>
-static hipError_t launch_p(const ConvArgs& a_in, hipStream_t s) {
+template <int NF, bool TAIL>
+static hipError_t launch_pt(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const int batch = a.M / (a.Ho * a.Wo);
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + NF - 1) / NF;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    hipLaunchKernelGGL((conv_bx3p_kernel<NF>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_bx3p_kernel<NF, TAIL>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
+template <int NF>
+static hipError_t launch_p(const ConvArgs& a_in, hipStream_t s) {
+    if (a_in.cin & 16) return launch_pt<NF, true>(a_in, s);
+    return launch_pt<NF, false>(a_in, s);
+}
+
 bool conv_bx3p_supported(const ConvArgs& a) {
-    return a.ksize == 3 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 32 && a.Ho == a.H && a.Wo == a.W && a.w3 != nullptr;
+    return a.ksize == 3 && a.stride == 1 && (a.cin & 15) == 0 && a.cin >= 16 && a.Ho == a.H && a.Wo == a.W && a.w3 != nullptr;
 }
 
 // nf = channel fragments (of 16) per workgroup: 3 (8x16 pixels x 48 channels, 3 workgroups per CU), 4, 6

@@ -430,6 +430,7 @@ hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s) {
         case 209: return launch_b3<4, 1, 2, 4, 2>(a, s);
         case 211: return launch_b3<4, 1, 2, 2, 2>(a, s);
         case 225: return launch_b3<4, 1, 1, 5, 2>(a, s);
+        case 213: return launch_b3<4, 1, 2, 6, 2>(a, s);   // 128 x 96 with 4 waves (2 x 6 fragments each), 2 workgroups per CU
 #ifdef PADEL_BX3_PROBES      // ceiling probes of tile 220 (WRONG results; tools/conv_bench.py only), DBG bits: 1 no split VALU, 2 one of the 6 MFMA groups, 4 / 8 no activation / weight requests
         case 420: return a.ksize == 3 ? launch_b3<4, 1, 2, 3, 2, 1>(a, s) : hipErrorNotSupported;
         case 520: return a.ksize == 3 ? launch_b3<4, 1, 2, 3, 2, 2>(a, s) : hipErrorNotSupported;
@@ -455,7 +456,8 @@ int choose_conv_bx3_variant(const ConvArgs& a) {
     struct V { int id, bm, nf; float s3, s1; };
     // ids + 200 = the 2-stage ring: 51-53 KB of LDS instead of 77-80 -> 3 workgroups per CU, measured +5..12 % on every
     // yolov8m 3x3 layer shape and +4..20 % on the 1x1 ones (profiles/conv_bx3_sweep_r2k.txt, ..._r2l.txt)
-    static const V vs[] = {{220, 128, 3, 1.00f, 1.00f}, {207, 64, 6, 0.98f, 0.95f}, {209, 128, 4, 1.00f, 1.00f}, {206, 64, 8, 0.90f, 0.70f},
+    static const V vs[] = {{213, 128, 6, 1.07f, 1.08f},     // 128 x 96 with 4 waves of 2 x 6 fragments, 2 workgroups per CU (..._r2p.txt)
+                           {220, 128, 3, 1.00f, 1.00f}, {207, 64, 6, 0.98f, 0.95f}, {209, 128, 4, 1.00f, 1.00f}, {206, 64, 8, 0.90f, 0.70f},
                            {211, 128, 2, 0.85f, 0.87f}, {225, 64, 5, 0.95f, 0.90f},
                            {7, 64, 6, 0.93f, 0.84f},    {20, 128, 3, 0.93f, 0.87f}, {13, 128, 6, 0.85f, 0.82f}, {14, 128, 8, 0.83f, 0.85f},
                            {25, 64, 5, 0.90f, 0.78f},
@@ -479,7 +481,7 @@ int choose_conv_bx3_variant(const ConvArgs& a) {
     // (profiles/conv_bx3_sweep_r2n.txt); its fill counts the pixels of partial patches at the right / bottom edge
     if (conv_bx3p_supported(a)) {
         struct P { int nf; float sp; };
-        static const P ps[] = {{3, 1.18f}, {4, 1.15f}};
+        static const P ps[] = {{3, 1.17f}, {4, 1.14f}};
         const long long patches = (long long)(M / (a.Ho * a.Wo)) * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
         for (const P& v : ps) {
             const int ntiles = (n16 + v.nf - 1) / v.nf;

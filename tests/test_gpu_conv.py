@@ -26,11 +26,12 @@ CASES = [
     (2, 32, 48, 64, 96, 3, 2, G.ACT_SILU, True),      # stride 2 with cin % 32 == 0, residual at the output resolution
     (3, 17, 23, 96, 96, 3, 1, G.ACT_SILU, True),      # odd spatial size: M tail + borders in every tile, residual
     (2, 16, 20, 80, 48, 3, 1, G.ACT_SILU, False),     # two full chunks + tail (cin 80), 48 outputs (128x48 tile)
+    (2, 18, 26, 16, 32, 3, 1, G.ACT_SILU, False),     # stride 1 with the tail block only (n-scale's 16 channels), partial patches
 ]
 
 LDS_VARIANTS = tuple(range(13))
 TAP_VARIANTS = (6, 7, 9, 10, 11, 12, 13, 14, 15, 20)
-BX3_VARIANTS = (6, 7, 9, 11, 12, 13, 14, 20, 25, 206, 207, 209, 211, 220, 225, 303, 304, 306)      # bf16x3 kernels (conv_tap_bx3.hip): fp32 accuracy, own rounding
+BX3_VARIANTS = (6, 7, 9, 11, 12, 13, 14, 20, 25, 206, 207, 209, 211, 220, 225, 213, 303, 304, 306)      # bf16x3 kernels (conv_tap_bx3.hip): fp32 accuracy, own rounding
 
 
 def _run(eng, case, x, w, b, wr):
