@@ -12,8 +12,8 @@
 //   3. walks the 9 taps: a tap is a SHIFTED 16-pixel window of the same planes, read as ready-made MFMA operands
 //      (ds_read_b128, conflict-free for every shift: 16-byte chunk q of pixel p lives at q ^ 2 * ((p >> 2) & 1));
 //      only the weights of the tap still travel through a 2-stage LDS-DMA ring.
-// Per k-step and wave that is 15 ds_read_b128 + 36 MFMAs + <= 3 requests and no VALU beyond addresses, against 13 reads
-// + 88 split VALU + 7 requests before.  Products, their order and the two-level accumulation are those of the tap
+// Per k-step and wave that is 15 ds_read_b128 + 36 MFMAs + <= 3 requests and no VALU, against 13 reads + 88 split VALU
+// + 7 requests before.  Products, their order and the two-level accumulation are those of the tap
 // kernel, so results are bitwise identical to it (tests/test_gpu_conv.py).
 //
 // LDS: 3 planes x 180 pixels x 64 B = 34 560 B + 2 weight stages of 3 x BN x 64 B: 52 992 B for BN = 48 -> 3 workgroups
@@ -153,21 +153,18 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
         const unsigned so_ = (unsigned)(CH_) * 128u;                                                              \
         _Pragma("unroll") for (int i = 0; i < kPasses; ++i) pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, voffP[i], so_, 0); \
     } while (0)
-#define PADEL_P_COMPUTE(T_)                                                                                       \
+#define PADEL_P_READA(T_)                                                                                         \
     do {                                                                                                          \
-        bf8 ah[MF], am[MF], al[MF];                                                                               \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
             const char* p_ = ldsb + patch_off(rd_pix + (f + (T_) / 3) * kPW + (T_) % 3, lq);                      \
             ah[f] = *reinterpret_cast<const bf8*>(p_);                                                            \
             am[f] = *reinterpret_cast<const bf8*>(p_ + kPlaneB);                                                  \
             al[f] = *reinterpret_cast<const bf8*>(p_ + 2 * kPlaneB);                                              \
         }                                                                                                         \
-        PADEL_P_MFMA(T_);                                                                                         \
     } while (0)
     // tail step JT: taps 2 JT and 2 JT + 1 (the 10th "tap" has zero weights: any finite data, tap 8 again)
-#define PADEL_P_TCOMPUTE(JT_)                                                                                     \
+#define PADEL_P_TREADA(JT_)                                                                                       \
     do {                                                                                                          \
-        bf8 ah[MF], am[MF], al[MF];                                                                               \
         constexpr int ta_ = 2 * (JT_), tb_ = 2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8;                               \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
             const char* pa_ = ldsb + tail_off(rd_pix + (f + ta_ / 3) * kPW + ta_ % 3, lq);                        \
@@ -180,17 +177,18 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
             { const u32x2 x_ = *reinterpret_cast<const u32x2*>(pa_ + 2 * kPlaneB), y_ = *reinterpret_cast<const u32x2*>(pb_ + 2 * kPlaneB); \
               v_ = (u32x4){x_[0], x_[1], y_[0], y_[1]}; al[f] = __builtin_bit_cast(bf8, v_); }                    \
         }                                                                                                         \
-        PADEL_P_MFMA(JT_);                                                                                        \
     } while (0)
-#define PADEL_P_MFMA(T_)                                                                                          \
+#define PADEL_P_READB(T_)                                                                                         \
     do {                                                                                                          \
         const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
-        bf8 wh[NF], wm[NF], wl[NF];                                                                               \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(bf8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                      \
             wm[j] = __builtin_bit_cast(bf8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256));            \
             wl[j] = __builtin_bit_cast(bf8, *reinterpret_cast<const f32x4*>(br_ + 2 * BN * 16 + j * 256));        \
         }                                                                                                         \
+    } while (0)
+#define PADEL_P_MFMA()                                                                                            \
+    do {                                                                                                          \
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], al[f], part[f][j], 0, 0, 0);              \
@@ -211,15 +209,23 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
     // additionally publishes the freshly written planes and requests the next chunk's patch
 #define PADEL_P_STEP(T_)                                                                                          \
     do {                                                                                                          \
+        bf8 ah[MF], am[MF], al[MF], wh[NF], wm[NF], wl[NF];                                                       \
+        /* the planes do not change inside a chunk, so from tap 1 on the activation operands are requested BEFORE   \
+           the barrier (their LDS latency runs under the wait), and the weight operands before the next step's      \
+           LDS-DMA requests are issued: +1..2.5 % (profiles/conv_bx3_sweep_r2r_read_order.txt) */                 \
+        if constexpr ((T_) > 0) PADEL_P_READA(T_);                                                                \
         wait_vm3<0>();                                                                                            \
-        lds_fence();                                                                                              \
+        if constexpr ((T_) == 0) lds_fence();          /* this wave's plane writes have reached the LDS */         \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
+        PADEL_P_READB(T_);                                                                                        \
+        if constexpr ((T_) == 0) PADEL_P_READA(T_);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
         if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_P_DMAB((T_) + 1, s_kb + ((T_) + 1) * 192u);                    \
         if ((T_) == 0 && c + 1 < nch) PADEL_P_LOAD(c + 1);    /* one request per tap step instead: measured -1 % */ \
         if constexpr (TAIL) { if ((T_) == 0 && c + 1 == nch) PADEL_P_TLOAD(); }                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_P_COMPUTE(T_);                                                                                      \
+        PADEL_P_MFMA();                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 
@@ -237,13 +243,16 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
     } while (0)
 #define PADEL_P_TSTEP(JT_)                                                                                        \
     do {                                                                                                          \
+        bf8 ah[MF], am[MF], al[MF], wh[NF], wm[NF], wl[NF];                                                       \
         wait_vm3<0>();                                                                                            \
         lds_fence();                                                                                              \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
         if constexpr ((JT_) < 4) PADEL_P_DMAB((JT_) + 1, s_kb + ((JT_) + 1) * 192u);                              \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_P_TCOMPUTE(JT_);                                                                                    \
+        PADEL_P_TREADA(JT_);                                                                                      \
+        PADEL_P_READB(JT_);                                                                                       \
+        PADEL_P_MFMA();                                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 
@@ -302,10 +311,11 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
     wait_vm3<0>();
 #undef PADEL_P_TSTEP
 #undef PADEL_P_TLOAD
-#undef PADEL_P_TCOMPUTE
+#undef PADEL_P_TREADA
+#undef PADEL_P_READA
+#undef PADEL_P_READB
 #undef PADEL_P_MFMA
 #undef PADEL_P_STEP
-#undef PADEL_P_COMPUTE
 #undef PADEL_P_LOAD
 #undef PADEL_P_DMAB
 #undef PADEL_P_DMAB1
