@@ -84,7 +84,8 @@ namespace padel {
 
 // requests of one k-step into ring stage SR_: A0 / A1 sub-rows (lane offsets VA_ / VB_, SGPR offsets SA0_ / SA1_),
 // three weight planes (SGPR offset SB_ + 64 * plane)
-#define PADEL_BX3_DMA(SR_, SA0_, SA1_, SB_, VA0_, VA1_, VB0_, VB1_)                                               \
+#define PADEL_BX3_DMA(SR_, SA0_, SA1_, SB_, VA0_, VA1_, VB0_, VB1_) PADEL_BX3_DMA_R(rsrcA, SR_, SA0_, SA1_, SB_, VA0_, VA1_, VB0_, VB1_)
+#define PADEL_BX3_DMA_R(rsrcA, SR_, SA0_, SA1_, SB_, VA0_, VA1_, VB0_, VB1_)                                      \
     do {                                                                                                          \
         const unsigned sa0_ = (SA0_), sa1_ = (SA1_), sb_ = (SB_);                                                 \
         if constexpr (!(DBG & 4)) {        /* probe bit 4: no activation requests */                              \
@@ -322,11 +323,16 @@ __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF) + (NSTG == 2
 }
 
 // =====================================================================================================  1x1
-template <int WM, int WN, int MF, int NF, int NSTG>
+// UP: the first a.up_c channels (whole 32-channel chunks) are read from a.in2, a map of half the spatial size, at
+// [y >> 1][x >> 1] — an nn.Upsample(2) + torch.cat in front of this conv that is never materialised
+template <int WM, int WN, int MF, int NF, int NSTG, bool UP>
 __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF) + (NSTG == 2 ? 1 : 0)) conv_bx3_1_kernel(const ConvArgs a) {
     constexpr int DBG = 0;
     PADEL_BX3_GEOMETRY()
     unsigned voffA[AP];
+    unsigned voffU[AP];
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    const long long linU0 = ((long long)n0 * H2 + (oy0 >> 1)) * W2;      // first coarse pixel of the coarse row of m0: every pixel of the tile is at or after it
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
         int m = m0 + srow + RP * p;
@@ -338,9 +344,27 @@ __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF) + (NSTG == 2
         const int ox = rem - oy * a.Wo;
         const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
         voffA[p] = rv ? (unsigned)(((lin - lin0) * a.in_cs + sc * 4) * 4) : kOOR3;
+        if constexpr (UP) {
+            const long long linU = ((long long)n * H2 + (oy >> 1)) * W2 + (ox >> 1);
+            voffU[p] = rv ? (unsigned)(((linU - linU0) * a.in2_cs + sc * 4) * 4) : kOOR3;
+        }
     }
+    (void)voffU; (void)linU0;
     const i32x4 rsrcA = make_rsrc3(a.in + (lin0 * a.in_cs + a.in_choff));
+    const i32x4 rsrcU = make_rsrc3(UP ? a.in2 + (linU0 * a.in2_cs + a.in2_choff) : a.in);
+    const unsigned nup = UP ? (unsigned)(a.up_c >> 5) : 0u;
+    (void)rsrcU; (void)nup;
     PADEL_BX3_WEIGHTS(nch)
+    // requests of chunk K_ into stage SR_: from the coarse map while K_ < nup
+#define PADEL_BX3_1REQ(SR_, K_)                                                                                   \
+    do {                                                                                                          \
+        const unsigned k_ = (K_);                                                                                 \
+        if (UP && k_ < nup) {                                                                                     \
+            PADEL_BX3_DMA_R(rsrcU, SR_, k_ * 128u, k_ * 128u + 64u, k_ * 192u, voffU[0], voffU[AP - 1], voffU[0], voffU[AP - 1]); \
+        } else {                                                                                                  \
+            PADEL_BX3_DMA_R(rsrcA, SR_, k_ * 128u, k_ * 128u + 64u, k_ * 192u, voffA[0], voffA[AP - 1], PADEL_BX3_A1(k_, 0), PADEL_BX3_A1(k_, AP - 1)); \
+        }                                                                                                         \
+    } while (0)
 
     unsigned s_k = 0;                         // index of the first k-step of the current 9-step accumulation block
     // step J of a block: chunk s_k + J; its A1 exists unless it is the half-empty last chunk
@@ -349,8 +373,7 @@ __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF) + (NSTG == 2
     if ((J) < nb) {                                                                                               \
         wait_vm3<NREQ>();                                                                                         \
         __builtin_amdgcn_s_barrier();                                                                             \
-        PADEL_BX3_DMA(((J) + 2) % 3, (s_k + (J) + 2) * 128u, (s_k + (J) + 2) * 128u + 64u, (s_k + (J) + 2) * 192u, \
-                      voffA[0], voffA[AP - 1], PADEL_BX3_A1(s_k + (J) + 2, 0), PADEL_BX3_A1(s_k + (J) + 2, AP - 1)); \
+        PADEL_BX3_1REQ(((J) + 2) % 3, s_k + (J) + 2);                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_BX3_COMPUTE((J) % 3);                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -360,15 +383,14 @@ __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF) + (NSTG == 2
     if ((J) < nb) {                                                                                               \
         wait_vm3<0>();                                                                                            \
         __builtin_amdgcn_s_barrier();                                                                             \
-        PADEL_BX3_DMA((J) + 1, (s_k + (J) + 1) * 128u, (s_k + (J) + 1) * 128u + 64u, (s_k + (J) + 1) * 192u,      \
-                      voffA[0], voffA[AP - 1], PADEL_BX3_A1(s_k + (J) + 1, 0), PADEL_BX3_A1(s_k + (J) + 1, AP - 1)); \
+        PADEL_BX3_1REQ((J) + 1, s_k + (J) + 1);                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_BX3_COMPUTE(J);                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     }
-    PADEL_BX3_DMA(0, 0u, 64u, 0u, voffA[0], voffA[AP - 1], PADEL_BX3_A1(0, 0), PADEL_BX3_A1(0, AP - 1));
+    PADEL_BX3_1REQ(0, 0u);
     if constexpr (NSTG == 3) {
-        PADEL_BX3_DMA(1, 128u, 192u, 192u, voffA[0], voffA[AP - 1], PADEL_BX3_A1(1, 0), PADEL_BX3_A1(1, AP - 1));
+        PADEL_BX3_1REQ(1, 1u);
         for (int k = 0; k < nch; k += 9) {
             const int nb = min(9, nch - k);
             PADEL_BX3_1STEP(0) PADEL_BX3_1STEP(1) PADEL_BX3_1STEP(2) PADEL_BX3_1STEP(3) PADEL_BX3_1STEP(4)
@@ -391,6 +413,7 @@ __global__ void __launch_bounds__(64 * WM * WN, min_waves3(MF * NF) + (NSTG == 2
     PADEL_BX3_FINISH()
 #undef PADEL_BX3_1STEP
 #undef PADEL_BX3_1STEP2
+#undef PADEL_BX3_1REQ
 #undef PADEL_BX3_A1
 }
 
@@ -402,13 +425,32 @@ static hipError_t launch_b3(const ConvArgs& a_in, hipStream_t s) {
     a.n_ntiles = (a.n16 + WN * NF - 1) / (WN * NF);
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
     if (a.ksize == 3) hipLaunchKernelGGL((conv_bx3_kernel<WM, WN, MF, NF, NSTG, DBG>), grid, dim3(64 * WM * WN), 0, s, a);
-    else hipLaunchKernelGGL((conv_bx3_1_kernel<WM, WN, MF, NF, NSTG>), grid, dim3(64 * WM * WN), 0, s, a);
+    else if (a.in2) return hipErrorNotSupported;                // absorbed upsample: launch_b3u tiles only
+    else hipLaunchKernelGGL((conv_bx3_1_kernel<WM, WN, MF, NF, NSTG, false>), grid, dim3(64 * WM * WN), 0, s, a);
+    return hipGetLastError();
+}
+// 1x1 with an absorbed upsample (a.in2): 2-stage ring tiles 213 / 220 / 209
+template <int WM, int WN, int MF, int NF>
+static hipError_t launch_b3u(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    constexpr int BM = WM * MF * 16;
+    if (a.ksize != 1 || a.stride != 1 || (a.up_c & 31) || a.up_c <= 0 || a.up_c > a.cin || ((a.H | a.W) & 1)) return hipErrorNotSupported;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.n_ntiles = (a.n16 + WN * NF - 1) / (WN * NF);
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    hipLaunchKernelGGL((conv_bx3_1_kernel<WM, WN, MF, NF, 2, true>), grid, dim3(64 * WM * WN), 0, s, a);
     return hipGetLastError();
 }
 
 // tile ids of the fp32 id space (conv_variant_shape); the ring holds 2 BM + 3 BN rows per stage
 hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s) {
     if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16 || !a.w3) return hipErrorNotSupported;
+    if (a.in2) {                                                // absorbed upsample: the three tiles instantiated for it
+        if (a.ksize != 1) return hipErrorNotSupported;
+        if (variant == 209 || variant == 9 || variant == 304) return launch_b3u<4, 1, 2, 4>(a, s);
+        if (variant == 213 || variant == 13 || variant == 14 || variant == 306 || variant == 206 || variant == 6) return launch_b3u<4, 1, 2, 6>(a, s);
+        return launch_b3u<4, 1, 2, 3>(a, s);
+    }
     if (variant >= 300 && variant < 400) {                      // patch kernel, or its tap-kernel sibling where it does not apply
         const int nf = variant - 300;
         if (conv_bx3p_supported(a)) return launch_conv_bx3p(a, nf, s);

@@ -32,6 +32,8 @@ struct Tuning {
     int graph = 0;       // 1: replay the op list of a (model, batch) from a captured hipGraph
     int timeline = 0;    // 1: 3x3 tap launches of the 64x96 tile run the s_memtime-instrumented instantiation
     int alias = 1;       // 1: activation buffers share one arena by liveness, 0: disjoint ranges
+    int fold_up = 1;     // 1: an nn.Upsample(2) whose only reader is a bf16x3 1x1 conv is never materialised (the conv
+                         // fetches those channels at [y >> 1][x >> 1] of the coarse map), 0: run the upsample kernel
 };
 
 struct pa_comm;
@@ -72,6 +74,8 @@ struct pa_model {
     pa_model_desc d{};
     std::vector<pa_buf_desc> bufs;
     std::vector<pa_op_desc> ops;
+    std::vector<int> fold_src;             // conv op i -> index of the upsample op it can absorb (-1: none), find_upsample_folds
+    std::vector<int> fold_dst;             // upsample op j -> its absorbing conv (-1: none)
     float* d_w = nullptr;
     size_t n_w = 0;
     int max_batch = 64;
@@ -103,6 +107,8 @@ struct pa_model {
     std::vector<ProfRec> prof;
     size_t n_prof = 0;
 };
+
+static void find_upsample_folds(pa_model* m);
 
 extern "C" {
 
@@ -137,6 +143,7 @@ int pa_engine_create(int device_id, pa_engine** out) {
     e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
     e->t.graph = env_int("PADEL_GRAPH", 0);
     e->t.alias = env_int("PADEL_ALIAS", 1);
+    e->t.fold_up = env_int("PADEL_FOLD_UP", 1);
     *out = e;
     return 0;
 }
@@ -151,6 +158,7 @@ int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     else if (k == "graph") e->t.graph = value ? 1 : 0;
     else if (k == "timeline") e->t.timeline = value ? 1 : 0;
     else if (k == "alias") e->t.alias = value ? 1 : 0;
+    else if (k == "fold_up") e->t.fold_up = value ? 1 : 0;
     else PA_FAIL(e, "pa_engine_set_tuning: unknown key '%s'", key);
     e->tuning_epoch++;
     return 0;
@@ -281,6 +289,7 @@ int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weight
     m->d = *desc;
     m->bufs.assign(desc->bufs, desc->bufs + desc->n_bufs);
     m->ops.assign(desc->ops, desc->ops + desc->n_ops);
+    find_upsample_folds(m);
     m->d.bufs = m->bufs.data();
     m->d.ops = m->ops.data();
     m->n_w = n_floats;
@@ -396,6 +405,57 @@ static hipError_t upload(pa_engine* e, int32_t** dptr, const std::vector<int32_t
 // live from the first op that touches it to the last one; the network input of a TrackNet graph (buffer 0) is
 // live from before op 0, head buffers stay live past the last op (decode / NMS / pa_yolo_read_head read them).
 // Aliased bytes always hold finite fp32 activations, so a zero-weighted pad channel still contributes exactly 0.
+// nn.Upsample(scale_factor=2) + torch.cat is never materialised where the consumer allows it.  Upsample op j
+// (coarse slice S[so, so + c) -> fine slice X[xo, xo + c)) is absorbed by conv i when: i is a 1x1 stride-1 conv with
+// bf16x3 weights whose input slice starts at X[xo] and covers the c channels (c % 32 == 0), nothing else reads those
+// channels of X, and nothing overwrites the source slice between j and i.  Whether the absorption is USED is decided
+// per launch (fp32 model, impl bx3, tuning fold_up); the liveness plan keeps S alive until i either way.
+static void find_upsample_folds(pa_model* m) {
+    const int nops = (int)m->ops.size();
+    m->fold_src.assign(nops, -1);
+    m->fold_dst.assign(nops, -1);
+    auto overlap = [](int a0, int an, int b0, int bn) { return a0 < b0 + bn && b0 < a0 + an; };
+    for (int j = 0; j < nops; ++j) {
+        const pa_op_desc& u = m->ops[j];
+        if (u.kind != PA_OP_UPSAMPLE2X || (u.cin & 31)) continue;
+        bool head = false;
+        for (int l = 0; l < 3; ++l) head |= m->d.head_buf[l] == u.out_buf;
+        if (head) continue;
+        int reader = -1, readers = 0;
+        for (int k = 0; k < nops; ++k) {
+            const pa_op_desc& o = m->ops[k];
+            if (k == j) continue;
+            bool reads = false;
+            if (o.kind == PA_OP_CONV) {
+                reads = (o.in_buf == u.out_buf && overlap(o.in_choff, o.cin, u.out_choff, u.cin)) ||
+                        (o.res_buf == u.out_buf && overlap(o.res_choff, o.cout, u.out_choff, u.cin));
+            } else if (o.kind == PA_OP_SPPF_POOL) {
+                reads = o.in_buf == u.out_buf && overlap(o.in_choff, 4 * o.cin, u.out_choff, u.cin);
+            } else if (o.kind != PA_OP_STEM) {
+                reads = o.in_buf == u.out_buf && overlap(o.in_choff, o.cin, u.out_choff, u.cin);
+            }
+            if (reads) { reader = k; ++readers; }
+        }
+        if (readers != 1 || reader < j) continue;
+        const pa_op_desc& c = m->ops[reader];
+        if (c.kind != PA_OP_CONV || c.ksize != 1 || c.stride != 1 || c.reserved <= 0 || c.in_buf != u.out_buf ||
+            c.in_choff != u.out_choff || c.cin < u.cin || m->fold_src[reader] >= 0)
+            continue;
+        bool clobbered = false;
+        for (int k = j + 1; k < reader && !clobbered; ++k) {
+            const pa_op_desc& o = m->ops[k];
+            const int wc = o.kind == PA_OP_SPPF_POOL ? 4 * o.cin : o.cout;
+            clobbered = o.out_buf == u.in_buf && overlap(o.out_choff, wc, u.in_choff, u.cin);
+        }
+        if (clobbered) continue;
+        m->fold_src[reader] = j;
+        m->fold_dst[j] = reader;
+    }
+}
+static bool fold_active(const pa_model* m, int conv_op) {
+    return m->e->t.fold_up && m->e->t.impl == 2 && m->d.dtype != PA_DTYPE_F16 && m->fold_src[conv_op] >= 0;
+}
+
 static int plan_buffers(pa_model* m, int batch) {
     pa_engine* e = m->e;
     int maxl = 0;
@@ -410,6 +470,7 @@ static int plan_buffers(pa_model* m, int batch) {
         if (o.kind != PA_OP_STEM) touch(o.in_buf, i);
         touch(o.out_buf, i);
         if (o.kind == PA_OP_CONV && o.res_buf >= 0) touch(o.res_buf, i);
+        if (o.kind == PA_OP_CONV && m->fold_src[i] >= 0) touch(m->ops[m->fold_src[i]].in_buf, i);   // an absorbed upsample's source
     }
     if (m->d.task == PA_TASK_TRACKNET) touch(0, -1);
     const bool f16 = m->d.dtype == PA_DTYPE_F16;
@@ -574,6 +635,10 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             const bool use_tap = e->t.impl == 0 || f16;
             const bool use_bx3 = !f16 && e->t.impl == 2 && o.reserved > 0;
             a.w3 = use_bx3 ? (const void*)(m->d_w + o.reserved) : nullptr;
+            if (use_bx3 && fold_active(m, (int)i)) {             // the first up_c channels come from the coarse map
+                const pa_op_desc& u = m->ops[m->fold_src[i]];
+                a.in2 = m->bptr[u.in_buf]; a.in2_cs = m->bufs[u.in_buf].channels; a.in2_choff = u.in_choff; a.up_c = u.cin;
+            }
             a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
             const int lv = e->t.variant >= 0 ? e->t.variant
                            : f16 ? choose_conv_tap16_variant(a.M, a.n16, o.ksize, o.cin)
@@ -624,6 +689,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s,
                                  m->d.dtype == PA_DTYPE_F16);
         } else if (o.kind == PA_OP_UPSAMPLE2X) {
+            if (m->fold_dst[i] >= 0 && fold_active(m, m->fold_dst[i])) continue;      // absorbed by its consumer conv
             pr = prof_begin(m, (*pi)++, o.kind, 0, 0.0);
             r = launch_upsample2x(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
                                   ob.channels, o.out_choff, o.cin, n, Ho / 2, Wo / 2, s, m->d.dtype == PA_DTYPE_F16);

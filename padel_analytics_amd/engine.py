@@ -206,7 +206,7 @@ class Engine:
         return DeviceBuffer(self, nbytes)
 
     def set_tuning(self, **kv):
-        """Tests / tools only: impl (0 tap, 1 lds), variant (tile id, -1 auto), tune, tap_pd, graph, alias, timeline."""
+        """Tests / tools only: impl (2 bx3, 0 tap, 1 lds), variant (tile id, -1 auto), tune, tap_pd, graph, alias, fold_up, timeline."""
         for k, v in kv.items():
             self._check(self.lib.pa_engine_set_tuning(self.handle, k.encode(), int(v)))
 
