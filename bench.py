@@ -14,7 +14,7 @@ it is already running under a launcher (RANK in the environment).  Frames shard 
 scaling); the only collective on the path is the one-time RCCL broadcast of the packed weight blobs, HBM to HBM,
 inside libpadel_hip.so (pa_engine_bcast_weights) — executed at N=1 too.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3] [--batch 64]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4] [--batch 64]
 
 Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`, `cpu_baseline` and `parity`.
 """
@@ -53,6 +53,9 @@ TRACKERS = {
 WORKLOADS = {
     "c2": ("BASELINE configs[1]: 1280x720 batch=64, players + ball YOLOv8 detect", ["players", "ball"]),
     "c3": ("BASELINE configs[2]: 1280x720 batch=64, players + ball detect + 13-kpt pose", ["players", "ball", "pose"]),
+    # configs[4] is 8 x 64 frames of 1920x1080 in fp16: one GPU's shard of it (forces --height 1080 --width 1920 --dtype f16)
+    "c4": ("BASELINE configs[4], one GPU's shard: 1920x1080 fp16 batch=64 (512 over 8 GPUs), all trackers + batched NMS",
+           ["players", "ball", "pose"]),
 }
 # court-like zone for the players tracker (main.py:108-119 builds it from court corners k1, k2, k12, k11)
 ZONE_720P = [[260, 170], [1020, 170], [1240, 700], [40, 700]]
@@ -198,6 +201,8 @@ def main():
         k, v = kv.split("=")
         TRACKERS[k]["scale"] = v
     desc, names = WORKLOADS[a.workload]
+    if a.workload == "c4":
+        a.height, a.width, a.dtype = 1080, 1920, "f16"
     H, W, B, K, Wm = a.height, a.width, a.batch, a.steps, a.warmup
 
     eng = E.Engine(local)
@@ -346,8 +351,9 @@ def main():
         out["roofline"] = {
             "kernel": ("conv_tap16_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x32_f16)"
                        if a.dtype == "f16" else
-                       "conv_bx3_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, exact bf16x3 split, "
-                       "6 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block)" if a.impl == "bx3" else
+                       "conv_bx3p_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch split once per 32-channel chunk into "
+                       "bf16 hi/mid/lo planes in LDS, 9 shifted-window taps) + conv_bx3_kernel<...> (stride-2 3x3: LDS-DMA ring, "
+                       "split in registers); exact bf16x3, 6 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block" if a.impl == "bx3" else
                        "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)"),
             "peak_note": ("fp32-equivalent TFLOP/s: bf16 MFMA dense peak 2500 / 6 products per multiply; the fp32-input MFMA "
                           "peak this replaces is 157.3" if (a.dtype == "f32" and a.impl == "bx3") else None),

@@ -85,6 +85,7 @@ struct StemArgs {
     int out_cs, out_choff;
     int H, W, Ho, Wo, cout, B;
     int out_f16;          // 1: `out` is a _Float16 buffer (fp16 models; the stem itself computes in fp32)
+    unsigned howo_magic, howo_shift, wo_magic, wo_shift;   // filled by launch_stem (fill_fastdiv): pixel index -> (n, oy, ox)
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
 

@@ -147,17 +147,18 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
     f32x4 bias4[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + j * 16 + lq * 4);
-    const long long P = (long long)a.B * a.Ho * a.Wo;
-    const long long ntiles = (P + 15) / 16;
+    const int P = a.B * a.Ho * a.Wo;                 // < 2^31 (launch_stem checks)
+    const int ntiles = (P + 15) / 16;
     const int HoWo = a.Ho * a.Wo;
     const uint32_t* const img0 = reinterpret_cast<const uint32_t*>(a.in);
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < ntiles; tile += (long long)gridDim.x * 4) {
-        const long long p = tile * 16 + lr;
+    for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+        const int p = tile * 16 + lr;
         const bool pv = p < P;
-        const long long pc = pv ? p : 0;
-        const int n = (int)(pc / HoWo);
-        const int rem = (int)(pc - (long long)n * HoWo);
-        const int oy = rem / a.Wo, ox = rem - oy * a.Wo;
+        const int pc = pv ? p : 0;
+        // (n, oy, ox) without integer-division sequences: q = (umulhi(x, magic) + x) >> shift (kernels.h:fill_fastdiv)
+        const int n = (int)((__umulhi((unsigned)pc, a.howo_magic) + (unsigned)pc) >> a.howo_shift);
+        const int rem = pc - n * HoWo;
+        const int oy = (int)((__umulhi((unsigned)rem, a.wo_magic) + (unsigned)rem) >> a.wo_shift), ox = rem - oy * a.Wo;
         const uint32_t* img = img0 + (long long)n * a.H * a.W;
         float av[8];
 #pragma unroll
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
                     const float x = acc[j][r] + bias4[j][r];
                     v[r] = x / (1.0f + expf(-x));
                 }
-                const long long o = p * a.out_cs + a.out_choff + j * 16 + lq * 4;
+                const long long o = (long long)p * a.out_cs + a.out_choff + j * 16 + lq * 4;
                 if (F16) {
                     _Float16* oh = reinterpret_cast<_Float16*>(a.out) + o;
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
@@ -205,7 +206,11 @@ static void launch_stem_nf(const StemArgs& a, unsigned grid, hipStream_t s) {
     else hipLaunchKernelGGL((stem_mfma_kernel<NF, false>), dim3(grid), dim3(256), 0, s, a);
 }
 
-hipError_t launch_stem(const StemArgs& a, hipStream_t s) {
+hipError_t launch_stem(const StemArgs& a_in, hipStream_t s) {
+    StemArgs a = a_in;
+    if ((long long)a.B * a.Ho * a.Wo >= (1ll << 31) - 16) return hipErrorInvalidValue;
+    fill_fastdiv((unsigned)(a.Ho * a.Wo), &a.howo_magic, &a.howo_shift);
+    fill_fastdiv((unsigned)a.Wo, &a.wo_magic, &a.wo_shift);
     const long long ntiles = ((long long)a.B * a.Ho * a.Wo + 15) / 16;
     const unsigned grid = (unsigned)std::min<long long>((ntiles + 3) / 4, 256 * 16);
     if ((a.out_choff | a.out_cs) & 3) return hipErrorInvalidValue;     // 4-channel vector stores

@@ -1,6 +1,6 @@
 """Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench_traffic.sh into profiles/r2_traffic.json.
 
-Per launch of the dominant kernel (conv_tap_kernel = every 3x3 conv): HBM bytes read = FETCH_SIZE (KiB) x 1024 x 2
+Per launch of the dominant kernels (every 3x3 conv: conv_bx3p_kernel + conv_bx3_kernel, or conv_tap_kernel for --impl tap): HBM bytes read = FETCH_SIZE (KiB) x 1024 x 2
 — MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B / lane) coalesced
 reads at 64 B, `buffer_load ... lds` included, which is how this kernel reads everything; WRITE_SIZE (KiB) x 1024 is
 taken as is (uncalibrated in the guide; it is 1.0-1.3x the algorithmic output here).  The algorithmic bytes of a
@@ -12,7 +12,7 @@ import sys
 from pathlib import Path
 
 
-KERNEL = "conv_tap_kernel"
+KERNEL = ("conv_tap_kernel",)
 
 
 def per_kernel(pmc_dir, counter):
@@ -20,7 +20,7 @@ def per_kernel(pmc_dir, counter):
     tot, disp = 0.0, set()
     for f in files:
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and KERNEL in r["Kernel_Name"]:
+            if r["Counter_Name"] == counter and any(k + "<" in r["Kernel_Name"] for k in KERNEL):
                 tot += float(r["Counter_Value"])
                 disp.add((f, r["Dispatch_Id"]))
     return tot, len(disp)
@@ -30,7 +30,8 @@ def main():
     global KERNEL
     wl, ops_csv, d_fetch, d_write = sys.argv[1:5]
     impl = sys.argv[5] if len(sys.argv) > 5 else "tap"
-    KERNEL = {"tap": "conv_tap_kernel", "bx3": "conv_bx3_kernel"}[impl]
+    # bx3: stride-1 layers run the patch kernel (conv_patch_bx3.hip), stride-2 layers the tap kernel
+    KERNEL = {"tap": ("conv_tap_kernel",), "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel")}[impl]
     fetch_kib, n_f = per_kernel(d_fetch, "FETCH_SIZE")
     write_kib, n_w = per_kernel(d_write, "WRITE_SIZE")
     alg, n_ops = 0.0, 0
@@ -45,7 +46,7 @@ def main():
     out_path = Path("profiles/r2_traffic.json")
     doc = json.loads(out_path.read_text()) if out_path.exists() else {}
     doc[f"{wl}-{impl}"] = {
-        "kernel": f"{KERNEL} (all 3x3 convs of the workload)",
+        "kernel": f"{' + '.join(KERNEL)} (all 3x3 convs of the workload)",
         "launches_counted": {"FETCH_SIZE": n_f, "WRITE_SIZE": n_w, "ops_per_step": n_ops},
         "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
         "bytes_per_launch": round(fetch + write), "algorithmic_bytes_per_launch": round(alg / n_ops),
