@@ -32,14 +32,15 @@ TOL_PX = 1e-3
 REPORT = {}
 
 
-def _calib(scale, nc, kpt, srcs, imgsz, conf, seed, dfl_scale=1.0):
+def _calib(scale, nc, kpt, srcs, imgsz, conf, seed, dfl_scale=1.0, kpt_scale=1.0):
     im = ref.preprocess(list(srcs), imgsz)
     sd = synth_weights.calibrated_state_dict(scale, nc, kpt, im, conf, seed)
-    if dfl_scale != 1.0:
-        for l in range(3):
-            for nm in ("weight", "bias"):
-                k = f"model.22.cv2.{l}.2.{nm}"
-                sd[k] = (sd[k] * np.float32(dfl_scale)).astype(np.float16).astype(np.float32)
+    for branch, f in (("cv2", dfl_scale), ("cv4", kpt_scale)):        # last conv of the box (DFL) / keypoint branch
+        if f != 1.0:
+            for l in range(3):
+                for nm in ("weight", "bias"):
+                    k = f"model.22.{branch}.{l}.2.{nm}"
+                    sd[k] = (sd[k] * np.float32(f)).astype(np.float16).astype(np.float32)
     return sd
 
 
@@ -116,14 +117,16 @@ def test_detect_parity(gpu_engine, scale, hw, nf):
     m.close()
 
 
-def test_detect_parity_tight(gpu_engine):
+@pytest.mark.parametrize("scale", ["n", "m"])
+def test_detect_parity_tight(gpu_engine, scale):
     """The literal north_star bar (<= 1e-3 px vs the fp32 CPU oracle AND vs fp64) on a head whose own
-    fp32 noise floor is below it: DFL logits scaled by 0.02 -> near-uniform bin distributions."""
+    fp32 noise floor is below it: DFL logits scaled by 0.02 -> near-uniform bin distributions.  scale m at 720p is
+    the bench's players graph."""
     frames = synth.synthetic_frames(3, 720, 1280, seed=13)
     srcs = [f[..., ::-1] for f in frames]
-    sd = _calib("n", 80, None, srcs, 640, 0.5, seed=17, dfl_scale=0.02)
+    sd = _calib(scale, 80, None, srcs, 640, 0.5, seed=17, dfl_scale=0.02)
     m, got = _engine_predict(gpu_engine, sd, 80, None, frames, imgsz=640, conf=0.5, iou=0.7, classes=[0])
-    _check("detect-n-tight", sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
+    _check("detect-n-tight" if scale == "n" else f"detect-{scale}-tight", sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
     m.close()
 
 
@@ -139,4 +142,21 @@ def test_pose_parity(gpu_engine, scale, S, kpt):
     m, got = _engine_predict(gpu_engine, sd, 1, kpt, frames, imgsz=S, conf=0.25, iou=0.7, classes=[0],
                              pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
     _check(f"pose-{scale}-{S}-{kpt[0]}x{kpt[1]}", sd, 1, kpt, srcs, got, 0.25, 0.7, S)
+    m.close()
+
+
+@pytest.mark.parametrize("scale,S,f", [("n", 640, 0.02), ("m", 1280, 0.004)], ids=["n-640", "m-1280-bench-graph"])
+def test_pose_parity_tight(gpu_engine, scale, S, f):
+    """The literal <= 1e-3 px bar for boxes AND the 13 keypoints, vs the fp32 CPU oracle and vs fp64, on pose heads
+    whose own fp32 noise floor is at the ulp of the coordinates (2.4e-4 px, measured on CPU): last conv of the DFL and
+    of the keypoint branch scaled by f.  m @ 1280 is the graph the bench times (85 % of its step)."""
+    from PIL import Image
+    frames = synth.synthetic_frames(2, 720, 1280, seed=7)
+    pil = [np.asarray(Image.fromarray(fr[..., ::-1].copy()).resize((S, S))) for fr in frames]
+    srcs = [p[..., ::-1] for p in pil]
+    kpt = (13, 3)
+    sd = _calib(scale, 1, kpt, srcs, S, 0.25, seed=11, dfl_scale=f, kpt_scale=f)
+    m, got = _engine_predict(gpu_engine, sd, 1, kpt, frames, imgsz=S, conf=0.25, iou=0.7, classes=[0],
+                             pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
+    _check(f"pose-{scale}-{S}-tight", sd, 1, kpt, srcs, got, 0.25, 0.7, S, tight=True)
     m.close()
