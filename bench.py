@@ -85,6 +85,7 @@ def parse():
     ap.add_argument("--impl", default="bx3", choices=["bx3", "tap", "lds"],
                     help="fp32 conv kernels: bx3 (default: exact 3-way bf16 split, 6 products on the bf16 matrix pipe, fp32 "
                          "accumulate), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
+    ap.add_argument("--no-tight", action="store_true", help="skip the low-noise-head parity leg of the CPU baseline section")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the parity path (the reference runs half=False) — the headline; f16: fp16 activations / "
                          "weights with fp32 accumulation (BASELINE configs[4]), reports its own L-inf vs the fp32 oracle")
@@ -121,6 +122,67 @@ def make_state_dict(name, cfg, frames):
                                              seed=sum(map(ord, name)))
     _SD_CACHE[key] = sd
     return sd
+
+
+def parity_low_noise_heads(eng, names, frames, sample, H, W, ref, parity):
+    """The literal north_star bar.  The same graphs, frames and weights as the timed run except for the LAST conv of the
+    DFL (and keypoint) branch of each head, scaled down until the fp32 CPU oracle itself is reproducible to the ulp of
+    the pixel coordinates: there `engine vs reference CPU path <= 1e-3 px` is a meaningful statement, and it is checked
+    (tests/test_gpu_yolo_parity.py::test_*_tight assert the same on the GPU box)."""
+    import torch
+    from padel_analytics_amd import engine as E, graph as G
+    ns = len(sample)
+    res = {"linf_px_vs_fp32_oracle": 0.0, "linf_px_vs_fp64": 0.0, "oracle_floor_px": 0.0, "detections": 0, "per_tracker": {},
+           "within_1e-3_px": True,
+           "what": "last conv of model.22.cv2 (DFL) and cv4 (keypoints) scaled by f; everything else as timed"}
+    for name in names:
+        cfg = TRACKERS[name]
+        f = 0.004 if cfg["imgsz"] > 640 else 0.02
+        sd = dict(make_state_dict(name, cfg, frames))
+        for branch in ("cv2", "cv4"):
+            for l in range(3):
+                for nm in ("weight", "bias"):
+                    k = f"model.22.{branch}.{l}.2.{nm}"
+                    if k in sd:
+                        sd[k] = (sd[k] * np.float32(f)).astype(np.float16).astype(np.float32)
+        srcs = source_for_oracle(cfg, sample)
+        r32 = ref.predict(ref.YoloV8Ref(sd, cfg["nc"], cfg["kpt"]), srcs, cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
+        r64 = ref.predict(ref.YoloV8Ref(sd, cfg["nc"], cfg["kpt"], dtype=torch.float64), srcs, cfg["conf"], 0.7,
+                          cfg["imgsz"], cfg["classes"])
+        m = E.Model(eng, G.build_yolov8(sd, cfg["nc"], cfg["kpt"]))
+        m.set_max_batch(ns)
+        boxes, kpts, counts = m.yolo_infer(np.ascontiguousarray(sample), ns, H, W, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7,
+                                           classes=cfg["classes"],
+                                           pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX,
+                                           channel_reverse=cfg["rev"])
+        m.close()
+        nk = 0 if cfg["kpt"] is None else cfg["kpt"][0] * cfg["kpt"][1]
+        b64 = np.zeros((ns, 300, 6), np.float32)
+        k64 = np.zeros((ns, 300, nk), np.float32) if nk else None
+        c64 = np.zeros(ns, np.int32)
+        for i, r in enumerate(r64):
+            c64[i] = len(r["boxes"])
+            b64[i, :c64[i]] = r["boxes"]
+            if nk and c64[i]:
+                k64[i, :c64[i]] = r["kpts"].reshape(c64[i], -1)
+        entry = {"f": f}
+        try:
+            floor = parity.compare_batch(r32, b64, k64, c64, cfg["conf"], 0.7, kpt_shape=cfg["kpt"])
+            g32 = parity.compare_batch(r32, boxes, kpts, counts, cfg["conf"], 0.7, kpt_shape=cfg["kpt"])
+            g64 = parity.compare_batch(r64, boxes, kpts, counts, cfg["conf"], 0.7, kpt_shape=cfg["kpt"])
+            entry.update(detections=g32["n"], linf_px_vs_fp32_oracle=round(g32["worst_px"], 6),
+                         linf_px_vs_fp64=round(g64["worst_px"], 6), oracle_floor_px=round(floor["worst_px"], 6))
+            res["detections"] += g32["n"]
+            for k, v in (("linf_px_vs_fp32_oracle", g32["worst_px"]), ("linf_px_vs_fp64", g64["worst_px"]),
+                         ("oracle_floor_px", floor["worst_px"])):
+                res[k] = round(max(res[k], v), 6)
+        except AssertionError as e:
+            entry["mismatch"] = str(e)[:300]
+            res["within_1e-3_px"] = False
+        res["per_tracker"][name] = entry
+    res["within_1e-3_px"] = bool(res["within_1e-3_px"] and res["detections"] > 0 and
+                                 max(res["linf_px_vs_fp32_oracle"], res["linf_px_vs_fp64"]) <= 1e-3)
+    return res
 
 
 def spawn_ranks(a) -> int:
@@ -462,6 +524,8 @@ def main():
         for k in ("linf_px_vs_fp32_oracle", "linf_px_vs_fp64", "oracle_floor_px"):
             if par[k] is not None:
                 par[k] = round(par[k], 6)
+        if a.dtype == "f32" and not a.no_fp64 and not a.no_tight:
+            par["low_noise_heads"] = parity_low_noise_heads(eng, names, frames, sample, H, W, ref, parity)
         out["parity"] = par
         out["cpu_baseline"] = {"value": round(ns / tcpu, 3), "unit": "frames/s", "cores": ncores, "kind": "port",
                                "sample": f"{ns} frames of the same workload through the torch-CPU fp32 oracle "
