@@ -628,6 +628,11 @@ static hipError_t launch_t16(const ConvArgs& a_in, hipStream_t s) {
 // tile ids: the fp32 id space (conv_variant_shape) + 30.. for the larger per-wave tiles only the fp16 path has
 hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s) {
     if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 31) || a.cin < 32) return hipErrorNotSupported;
+    if (variant >= 300 && variant < 400) {           // fp16 patch kernel (conv_patch16.hip), or a tap tile where it does not apply
+        const int nf = variant - 300;
+        if (conv_p16_supported(a)) return launch_conv_p16(a, nf, s);
+        variant = nf == 3 ? 20 : nf == 4 ? 9 : 31;
+    }
     switch (variant) {
         case 6: return launch_t16<2, 2, 2, 4>(a, s);    //  64 x 128
         case 7: return launch_t16<2, 2, 2, 3>(a, s);    //  64 x  96
@@ -663,7 +668,8 @@ bool conv_tap16_variant_shape(int variant, int* bm, int* bn) {
 // Tile choice: these kernels are issue- / HBM-bound, not MFMA-bound, so (a) the channel tile should cover all of
 // cout when it can (every extra channel tile re-reads the whole input from L2 / HBM), (b) bigger per-wave tiles
 // amortise the fixed per-k-step instruction cost, (c) the grid still has to fill 256 CUs.
-int choose_conv_tap16_variant(int M, int n16, int ksize, int cin) {
+int choose_conv_tap16_variant(const ConvArgs& a) {
+    const int M = a.M, n16 = a.n16, ksize = a.ksize, cin = a.cin;
     struct V { int id, bm, nf; float speed; bool dbl; };
     // double-step tiles (ids + 40) win where K is a whole number of 64-channel steps and long enough to matter:
     // 3x3 with cin % 64 == 0 (yolov8m 192 -> 192 / 304: 684-696 vs 626 TFLOP/s, profiles/conv_tap16_sweep_r2i.txt);
@@ -685,6 +691,23 @@ int choose_conv_tap16_variant(int M, int n16, int ksize, int cin) {
         const float reread = 1.0f / (1.0f + 0.25f * (float)(ntiles - 1));        // input re-read per extra channel tile
         const float sc = v.speed * fill * occ * (v.dbl ? 1.0f : reread);
         if (sc > best) { best = sc; bv = v.id; }
+    }
+    // stride-1 3x3: the patch kernel (conv_patch16.hip) fetches the input once per chunk instead of once per tap:
+    // 806 vs 662 TFLOP/s on 192 -> 192, 875 vs 674 on the 256-channel heads, 558 vs 461 on 48(64) -> 64, about even on
+    // the short-K 96 -> 96 layers (profiles/conv_tap16_sweep_r2x_patch.txt) — hence the K-length factor
+    if (conv_p16_supported(a)) {
+        struct P { int nf; float sp; };
+        static const P ps[] = {{4, 1.70f}, {3, 1.55f}, {6, 1.45f}};
+        const int nch = cin >> 5;
+        const long long patches = (long long)(M / (a.Ho * a.Wo)) * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+        for (const P& v : ps) {
+            const int ntiles = (n16 + v.nf - 1) / v.nf;
+            const float fill = (float)n16 / (float)(ntiles * v.nf) * (float)M / (float)(patches * 128);
+            const long long blocks = patches * ntiles;
+            const long long per_cu = (blocks + 255) / 256;
+            const float sc = v.sp * (float)nch / (float)(nch + 1) * fill * (float)blocks / (256.f * (float)per_cu);
+            if (sc > best) { best = sc; bv = 300 + v.nf; }
+        }
     }
     return bv;
 }

@@ -641,11 +641,12 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             }
             a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
             const int lv = e->t.variant >= 0 ? e->t.variant
-                           : f16 ? choose_conv_tap16_variant(a.M, a.n16, o.ksize, o.cin)
+                           : f16 ? choose_conv_tap16_variant(a)
                            : use_bx3 ? choose_conv_bx3_variant(a)
                                  : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
             int bm = 0, bn = 0;
-            if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
+            if (f16 && lv >= 300) { bm = 128; bn = (lv - 300) * 16; }
+            else if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
             else if (lv >= 300) { bm = 128; bn = (lv - 300) * 16; }          // patch kernel: 8 x 16 pixels x nf fragments
             else conv_variant_shape(lv >= 200 ? lv - 200 : lv, &bm, &bn);   // profile rows carry BM, BN of the workgroup tile
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);

@@ -74,8 +74,11 @@ hipError_t launch_conv_bx3p(const ConvArgs& a, int nf, hipStream_t s);
 // fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and
 // choff count elements); cin % 32 == 0; weights packed [Npad][Ktot] with K order (64-channel chunk, tap, 32-channel half)
 hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s);
-int choose_conv_tap16_variant(int M, int n16, int ksize, int cin);
+int choose_conv_tap16_variant(const ConvArgs& a);
 bool conv_tap16_variant_shape(int variant, int* bm, int* bn);
+// fp16 stride-1 3x3 patch kernel (conv_patch16.hip), ids 303 / 304 / 306 of launch_conv_tap16
+bool conv_p16_supported(const ConvArgs& a);
+hipError_t launch_conv_p16(const ConvArgs& a, int nf, hipStream_t s);
 
 struct StemArgs {
     const uint8_t* in;    // net input u8 NHWC4 [B][H][W][4]

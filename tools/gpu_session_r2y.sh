@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
+cd $R
+timeout 900 python -m pytest tests/test_gpu_fp16.py -m gpu -q -rf --tb=short -x 2>&1 | tail -8
+timeout 400 python bench.py --dtype f16 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r2y_bench_c3_f16.json 2> gpurun_out/r2y_bench_c3_f16.err; python - <<'PY'
+import json
+j=json.load(open('gpurun_out/r2y_bench_c3_f16.json')); print(j['value'], j['ms_per_step'], j['engine_only']['value']); r=j['roofline']; print({k:r[k] for k in ('achieved','frac','kernel_ms_per_step','conv1x1','all_kernels_ms_per_step','other_ms_per_step')})
+PY
