@@ -16,7 +16,8 @@ inside libpadel_hip.so (pa_engine_bcast_weights) — executed at N=1 too.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4] [--batch 64]
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`, `cpu_baseline` and `parity`.
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline`, `cpu_baseline` and `parity`
+(`parity.low_noise_heads`: the same graphs with well-conditioned heads, where the literal 1e-3 px bar is checked).
 """
 from __future__ import annotations
 

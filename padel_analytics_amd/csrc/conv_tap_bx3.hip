@@ -24,6 +24,13 @@
 // cin % 32 == 16 (yolov8m's 48-channel layers, n-scale's 16): the 3x3 kernel's tail block pairs TAPS instead of channel
 // halves (A0 = the 16 channels at tap 2t, A1 = at tap 2t+1: 5 k-steps instead of 9 half-empty ones); the 1x1 kernel runs
 // its last k-step with A1 switched off (out-of-range lane offsets -> zeros) against zero-padded weights.
+//
+// Since the second half of round 2 this file serves the stride-2 3x3 layers, the 1x1 layers and whatever stride-1 3x3 the
+// patch kernel (conv_patch_bx3.hip: input split once per chunk instead of once per tap) does not take.  Both kernels
+// exist with a 3-stage ring (prefetch distance 2, ids 6..25) and a 2-stage ring (prefetch distance 1, ids + 200: two
+// thirds of the LDS -> 3 workgroups per CU, the default); the 1x1 kernel can absorb a preceding nn.Upsample(2)
+// (template flag UP: the first up_c channels come from the coarse map).  -DPADEL_BX3_PROBES adds instantiations of
+// tile 220 with parts of the k-step removed (wrong results; ceiling measurements, profiles/conv_bx3_probes_r2m.txt).
 #include "bx3_common.h"
 
 namespace padel {

@@ -65,7 +65,7 @@ hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s);      
 constexpr size_t kConvReadSlack = 512;
 int choose_conv_tap_variant(int M, int n16);
 // fp32 convolutions on the bf16 matrix pipe (conv_tap_bx3.hip): exact 3-way bf16 split, 6 products, fp32 accumulate
-hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s);      // ids 6,7,9,11,12,13,14,20
+hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s);      // ids 6,7,9,11,12,13,14,20,25 (3-stage ring), 206..225 (2-stage), 303/304/306 (patch kernel)
 int choose_conv_bx3_variant(const ConvArgs& a);      // per-layer tile heuristic (ids + 200: 2-stage ring, 30x: patch kernel)
 // stride-1 3x3, cin % 32 == 0: 8 x 16-pixel patch kernel (conv_patch_bx3.hip), the input patch is split once per chunk;
 // nf = channel fragments per workgroup (3, 4, 6); reached through launch_conv_bx3 ids 303 / 304 / 306
