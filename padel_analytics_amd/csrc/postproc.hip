@@ -88,9 +88,11 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------------- NMS
 #define NMS_THREADS 1024
 #define NMS_LDS_KEYS 4096
+#define NMS_LDS_SUPP 16384          // suppression flags of up to this many ranked candidates live in LDS
 
 __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
     __shared__ uint64_t skeys[NMS_LDS_KEYS];
+    __shared__ uint8_t ssupp[NMS_LDS_SUPP];
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     int n = a.cand_cnt[b];
@@ -98,7 +100,10 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
     const float* cand = a.cand + (long long)b * a.A * 6;
     const int32_t* cidx = a.cand_idx + (long long)b * a.A;
     int32_t* order = a.order + (long long)b * a.A;
-    uint8_t* supp = a.supp + (long long)b * a.A;
+    // the greedy loop below reads one flag per ranked candidate, serially: from LDS that is ~100 cycles per candidate
+    // instead of an L2 round trip per candidate — the global array only backs very long lists
+    const int ne0 = min(n < a.A ? n : a.A, a.max_nms);
+    uint8_t* supp = ne0 <= NMS_LDS_SUPP ? ssupp : a.supp + (long long)b * a.A;
 
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
