@@ -87,7 +87,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------- NMS
 #define NMS_THREADS 1024
-#define NMS_LDS_KEYS 4096
+#define NMS_LDS_KEYS 8192          // bitonic sort in LDS up to this many candidates per image (64 KB), in HBM beyond
 #define NMS_LDS_SUPP 16384          // suppression flags of up to this many ranked candidates live in LDS
 
 __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
