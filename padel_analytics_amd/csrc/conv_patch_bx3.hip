@@ -64,7 +64,9 @@ __device__ __forceinline__ void lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)
 // TAIL: cin % 32 == 16 — after the full chunks a 16-channel patch (32 bytes per pixel and plane) is walked in 5 k-steps
 // that pair TAPS like the tap kernel's tail block: K slots 0-3 of a lane = its 4 channels at tap 2t, slots 4-7 = at tap
 // 2t + 1 (two ds_read_b64 per operand; 8-byte slot q of pixel p lives at q ^ 2 * ((p >> 3) & 1): conflict-free)
-template <int NF, bool TAIL>
+// UP: the first a.up_c channels (whole chunks) are read from a.in2, a map of half the spatial size, at [y >> 1][x >> 1]:
+// an nn.Upsample(2) + torch.cat in front of this conv (TrackNet's decoder blocks) that is never materialised
+template <int NF, bool TAIL, bool UP>
 __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const ConvArgs a) {
     constexpr int MF = 2;
     constexpr int BN = NF * 16;
@@ -107,6 +109,13 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
     }
     const float* const in0 = a.in + (((long long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.in_cs + a.in_choff;
     const __amdgpu_buffer_rsrc_t rsrcP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(in0), 0, (int)0x80000000u, 0x00020000);
+    // coarse map of an absorbed upsample: descriptor based at the coarse pixel of the patch's top-left halo pixel
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    const int cy0 = (y0 - 1) >> 1, cx0 = (x0 - 1) >> 1;                 // arithmetic shifts: -1 for the halo above / left of the image
+    const float* const inU = UP ? a.in2 + (((long long)n * H2 + cy0) * W2 + cx0) * a.in2_cs + a.in2_choff : in0;
+    const __amdgpu_buffer_rsrc_t rsrcU = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(inU), 0, (int)0x80000000u, 0x00020000);
+    const int nup = UP ? a.up_c >> 5 : 0;
+    (void)H2; (void)W2; (void)cy0; (void)cx0; (void)rsrcU; (void)nup;
 
     // ---- weights: rows of (cin / 32) * 9 k-steps x 192 bytes (hi | mid | lo), k-step = chunk * 9 + tap
     const int nch = a.cin >> 5;
@@ -151,7 +160,19 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
 #define PADEL_P_LOAD(CH_)                                                                                         \
     do {                                                                                                          \
         const unsigned so_ = (unsigned)(CH_) * 128u;                                                              \
-        _Pragma("unroll") for (int i = 0; i < kPasses; ++i) pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, voffP[i], so_, 0); \
+        if (UP && (int)(CH_) < nup) {      /* lane offsets into the coarse map, recomputed (once per chunk) */      \
+            _Pragma("unroll") for (int i = 0; i < kPasses; ++i) {                                                 \
+                const int item = i * 256 + tid;                                                                   \
+                const int pp = item >> 3, c4 = item & 7;                                                          \
+                const int py = pp / kPW, px = pp - py * kPW;                                                      \
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;                                                     \
+                const bool ok = item < kItems && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;   \
+                const unsigned vo_ = ok ? (unsigned)(((((iy >> 1) - cy0) * W2 + ((ix >> 1) - cx0)) * a.in2_cs + c4 * 4) * 4) : kOOR3; \
+                pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcU, vo_, so_, 0);                               \
+            }                                                                                                     \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < kPasses; ++i) pre[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcP, voffP[i], so_, 0); \
+        }                                                                                                         \
     } while (0)
 #define PADEL_P_READA(T_)                                                                                         \
     do {                                                                                                          \
@@ -331,21 +352,25 @@ __global__ void __launch_bounds__(256, NF <= 3 ? 3 : 2) conv_bx3p_kernel(const C
     bx3_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
 }
 
-template <int NF, bool TAIL>
+template <int NF, bool TAIL, bool UP>
 static hipError_t launch_pt(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const int batch = a.M / (a.Ho * a.Wo);
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + NF - 1) / NF;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    hipLaunchKernelGGL((conv_bx3p_kernel<NF, TAIL>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_bx3p_kernel<NF, TAIL, UP>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
 template <int NF>
 static hipError_t launch_p(const ConvArgs& a_in, hipStream_t s) {
-    if (a_in.cin & 16) return launch_pt<NF, true>(a_in, s);
-    return launch_pt<NF, false>(a_in, s);
+    if (a_in.in2) {                    // absorbed upsample: whole 32-channel chunks only, even map size
+        if ((a_in.cin & 31) || (a_in.up_c & 31) || a_in.up_c <= 0 || a_in.up_c > a_in.cin || ((a_in.H | a_in.W) & 1)) return hipErrorNotSupported;
+        return launch_pt<NF, false, true>(a_in, s);
+    }
+    if (a_in.cin & 16) return launch_pt<NF, true, false>(a_in, s);
+    return launch_pt<NF, false, false>(a_in, s);
 }
 
 bool conv_bx3p_supported(const ConvArgs& a) {

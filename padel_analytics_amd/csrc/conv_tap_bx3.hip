@@ -452,7 +452,11 @@ static hipError_t launch_b3u(const ConvArgs& a_in, hipStream_t s) {
 // tile ids of the fp32 id space (conv_variant_shape); the ring holds 2 BM + 3 BN rows per stage
 hipError_t launch_conv_bx3(const ConvArgs& a, int variant, hipStream_t s) {
     if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16 || !a.w3) return hipErrorNotSupported;
-    if (a.in2) {                                                // absorbed upsample: the three tiles instantiated for it
+    if (a.in2 && a.ksize == 3) {                                // absorbed upsample in front of a 3x3: the patch kernel only
+        if (variant < 300 || variant >= 400 || !conv_bx3p_supported(a)) return hipErrorNotSupported;
+        return launch_conv_bx3p(a, variant - 300, s);
+    }
+    if (a.in2) {                                                // absorbed upsample in front of a 1x1: the three tiles instantiated for it
         if (a.ksize != 1) return hipErrorNotSupported;
         if (variant == 209 || variant == 9 || variant == 304) return launch_b3u<4, 1, 2, 4>(a, s);
         if (variant == 213 || variant == 13 || variant == 14 || variant == 306 || variant == 206 || variant == 6) return launch_b3u<4, 1, 2, 6>(a, s);

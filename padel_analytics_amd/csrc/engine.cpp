@@ -406,10 +406,12 @@ static hipError_t upload(pa_engine* e, int32_t** dptr, const std::vector<int32_t
 // live from before op 0, head buffers stay live past the last op (decode / NMS / pa_yolo_read_head read them).
 // Aliased bytes always hold finite fp32 activations, so a zero-weighted pad channel still contributes exactly 0.
 // nn.Upsample(scale_factor=2) + torch.cat is never materialised where the consumer allows it.  Upsample op j
-// (coarse slice S[so, so + c) -> fine slice X[xo, xo + c)) is absorbed by conv i when: i is a 1x1 stride-1 conv with
-// bf16x3 weights whose input slice starts at X[xo] and covers the c channels (c % 32 == 0), nothing else reads those
-// channels of X, and nothing overwrites the source slice between j and i.  Whether the absorption is USED is decided
-// per launch (fp32 model, impl bx3, tuning fold_up); the liveness plan keeps S alive until i either way.
+// (coarse slice S[so, so + c) -> fine slice X[xo, xo + c)) is absorbed by conv i when: i is a stride-1 conv with bf16x3
+// weights — 1x1 (YOLOv8's FPN joins) or 3x3 with cin % 32 == 0 (TrackNet's decoder blocks) — whose input slice starts
+// at X[xo] and covers the c channels (c % 32 == 0), nothing else reads those channels of X, and nothing overwrites the
+// source slice between j and i.  Whether the absorption is USED is decided per launch (fp32 model, impl bx3, tuning
+// fold_up, and for a 3x3 consumer the patch kernel being the tile chosen: conv_launch_args); the liveness plan keeps S
+// alive until i either way.
 static void find_upsample_folds(pa_model* m) {
     const int nops = (int)m->ops.size();
     m->fold_src.assign(nops, -1);
@@ -438,8 +440,9 @@ static void find_upsample_folds(pa_model* m) {
         }
         if (readers != 1 || reader < j) continue;
         const pa_op_desc& c = m->ops[reader];
-        if (c.kind != PA_OP_CONV || c.ksize != 1 || c.stride != 1 || c.reserved <= 0 || c.in_buf != u.out_buf ||
-            c.in_choff != u.out_choff || c.cin < u.cin || m->fold_src[reader] >= 0)
+        const bool shape_ok = c.kind == PA_OP_CONV && c.stride == 1 && (c.ksize == 1 || (c.ksize == 3 && (c.cin & 31) == 0));
+        if (!shape_ok || c.reserved <= 0 || c.in_buf != u.out_buf || c.in_choff != u.out_choff || c.cin < u.cin ||
+            m->fold_src[reader] >= 0)
             continue;
         bool clobbered = false;
         for (int k = j + 1; k < reader && !clobbered; ++k) {
@@ -604,6 +607,44 @@ static ProfRec* prof_begin(pa_model* m, size_t idx, int kind, int ksize, double 
 }
 static void prof_end(pa_model* m, ProfRec* r) { if (r) hipEventRecord(r->e1, m->e->stream); }
 
+// ConvArgs of conv op i for `n` images and the tile id it will be launched with (kernel choice: bf16x3 by default,
+// tap kernels / the LDS cross-check kernel by tuning, conv_tap16 for fp16 models; a forced variant picks the tile of
+// whichever kernel is selected).  An absorbed upsample (find_upsample_folds) is attached here: always for a 1x1
+// consumer, for a 3x3 consumer only when the tile chosen is the patch kernel's.
+static int conv_launch_args(const pa_model* m, size_t i, int n, ConvArgs& a) {
+    const pa_engine* e = m->e;
+    const pa_op_desc& o = m->ops[i];
+    const pa_buf_desc& ob = m->bufs[o.out_buf];
+    const pa_buf_desc& ib = m->bufs[o.in_buf];
+    const int Ho = m->net_h >> ob.level, Wo = m->net_w >> ob.level;
+    a.in = m->bptr[o.in_buf]; a.in_cs = ib.channels; a.in_choff = o.in_choff;
+    a.out = m->bptr[o.out_buf]; a.out_cs = ob.channels; a.out_choff = o.out_choff;
+    a.res = o.res_buf >= 0 ? m->bptr[o.res_buf] : nullptr;
+    a.res_cs = o.res_buf >= 0 ? m->bufs[o.res_buf].channels : 0; a.res_choff = o.res_choff;
+    a.zeros = e->zeros;
+    a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;
+    a.H = m->net_h >> ib.level; a.W = m->net_w >> ib.level; a.Ho = Ho; a.Wo = Wo;
+    a.cin = o.cin; a.cout = o.cout; a.n16 = o.npad / 16; a.ksize = o.ksize; a.stride = o.stride; a.act = o.act;
+    a.M = n * Ho * Wo;
+    fill_fastdiv((unsigned)(Ho * Wo), &a.howo_magic, &a.howo_shift);
+    fill_fastdiv((unsigned)Wo, &a.wo_magic, &a.wo_shift);
+    a.tune = e->t.tune; a.tap_pd = e->t.tap_pd;
+    const bool f16 = m->d.dtype == PA_DTYPE_F16;
+    const bool use_tap = e->t.impl == 0 || f16;
+    const bool use_bx3 = !f16 && e->t.impl == 2 && o.reserved > 0;
+    a.w3 = use_bx3 ? (const void*)(m->d_w + o.reserved) : nullptr;
+    a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
+    const int lv = e->t.variant >= 0 ? e->t.variant
+                   : f16 ? choose_conv_tap16_variant(a)
+                   : use_bx3 ? choose_conv_bx3_variant(a)
+                         : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
+    if (use_bx3 && fold_active(m, (int)i) && (o.ksize == 1 || (lv >= 300 && lv < 400 && conv_bx3p_supported(a)))) {
+        const pa_op_desc& u = m->ops[m->fold_src[i]];       // the first up_c channels come from the coarse map
+        a.in2 = m->bptr[u.in_buf]; a.in2_cs = m->bufs[u.in_buf].channels; a.in2_choff = u.in_choff; a.up_c = u.cin;
+    }
+    return lv;
+}
+
 // replay the op list for `n` images (prof records appended starting at *pi)
 static int run_ops(pa_model* m, int n, size_t* pi) {
     pa_engine* e = m->e;
@@ -615,35 +656,11 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
         hipError_t r = hipSuccess;
         ProfRec* pr = nullptr;
         if (o.kind == PA_OP_CONV) {
-            const pa_buf_desc& ib = m->bufs[o.in_buf];
             ConvArgs a{};
-            a.in = m->bptr[o.in_buf]; a.in_cs = ib.channels; a.in_choff = o.in_choff;
-            a.out = m->bptr[o.out_buf]; a.out_cs = ob.channels; a.out_choff = o.out_choff;
-            a.res = o.res_buf >= 0 ? m->bptr[o.res_buf] : nullptr;
-            a.res_cs = o.res_buf >= 0 ? m->bufs[o.res_buf].channels : 0; a.res_choff = o.res_choff;
-            a.zeros = e->zeros;
-            a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;
-            a.H = m->net_h >> ib.level; a.W = m->net_w >> ib.level; a.Ho = Ho; a.Wo = Wo;
-            a.cin = o.cin; a.cout = o.cout; a.n16 = o.npad / 16; a.ksize = o.ksize; a.stride = o.stride; a.act = o.act;
-            a.M = n * Ho * Wo;
-            fill_fastdiv((unsigned)(Ho * Wo), &a.howo_magic, &a.howo_shift);
-            fill_fastdiv((unsigned)Wo, &a.wo_magic, &a.wo_shift);
-            a.tune = e->t.tune; a.tap_pd = e->t.tap_pd;
-            // kernel choice: tap kernels (conv_tap.hip) unless tuning asks for the LDS cross-check kernel; a forced
-            // variant picks the tile of whichever kernel is selected
+            const int lv = conv_launch_args(m, i, n, a);
             const bool f16 = m->d.dtype == PA_DTYPE_F16;
             const bool use_tap = e->t.impl == 0 || f16;
-            const bool use_bx3 = !f16 && e->t.impl == 2 && o.reserved > 0;
-            a.w3 = use_bx3 ? (const void*)(m->d_w + o.reserved) : nullptr;
-            if (use_bx3 && fold_active(m, (int)i)) {             // the first up_c channels come from the coarse map
-                const pa_op_desc& u = m->ops[m->fold_src[i]];
-                a.in2 = m->bptr[u.in_buf]; a.in2_cs = m->bufs[u.in_buf].channels; a.in2_choff = u.in_choff; a.up_c = u.cin;
-            }
-            a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
-            const int lv = e->t.variant >= 0 ? e->t.variant
-                           : f16 ? choose_conv_tap16_variant(a)
-                           : use_bx3 ? choose_conv_bx3_variant(a)
-                                 : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
+            const bool use_bx3 = a.w3 != nullptr;
             int bm = 0, bn = 0;
             if (f16 && lv >= 300) { bm = 128; bn = (lv - 300) * 16; }
             else if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
@@ -690,7 +707,11 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s,
                                  m->d.dtype == PA_DTYPE_F16);
         } else if (o.kind == PA_OP_UPSAMPLE2X) {
-            if (m->fold_dst[i] >= 0 && fold_active(m, m->fold_dst[i])) continue;      // absorbed by its consumer conv
+            if (m->fold_dst[i] >= 0) {                   // absorbed by its consumer conv?  (same decision as at that conv)
+                ConvArgs ca{};
+                conv_launch_args(m, (size_t)m->fold_dst[i], n, ca);
+                if (ca.in2) continue;
+            }
             pr = prof_begin(m, (*pi)++, o.kind, 0, 0.0);
             r = launch_upsample2x(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
                                   ob.channels, o.out_choff, o.cin, n, Ho / 2, Wo / 2, s, m->d.dtype == PA_DTYPE_F16);

@@ -18,7 +18,7 @@ struct ConvArgs {
     const float* bias;    // [Npad]
     const float* res;     // optional residual buffer base (added AFTER the activation) or nullptr
     const float* zeros;   // >= 64 bytes of zeros in HBM (source of padded taps)
-    const float* in2;     // bf16x3 1x1 kernel only: channels [0, up_c) of the input are read from this buffer of HALF the
+    const float* in2;     // bf16x3 1x1 and patch kernels: channels [0, up_c) of the input are read from this buffer of HALF the
     int in2_cs, in2_choff, up_c;   // spatial size at [y >> 1][x >> 1] (an absorbed nn.Upsample(2)); nullptr: none; up_c % 32 == 0
     float* out;           // output buffer base
     int in_cs, in_choff;  // input pixel stride (channels) and channel offset of the slice read
