@@ -29,7 +29,7 @@ extern "C" {
 typedef struct pa_engine pa_engine;
 typedef struct pa_model pa_model;
 
-#define PA_ABI_VERSION 2
+#define PA_ABI_VERSION 3
 
 /* ---- graph description (built on the host from a state_dict; see padel_analytics_amd/graph.py) ---- */
 
@@ -58,7 +58,8 @@ typedef struct pa_op_desc {
     int32_t npad;                       /* PA_OP_CONV: rows of the packed weight matrix (multiple of 16) */
     int32_t reserved;                   /* PA_OP_CONV, fp32 models: offset (in floats, > 0) of the same weights pre-split
                                            into three bf16 planes for the bf16x3 kernels, [npad][k-step][hi|mid|lo][32];
-                                           0: not provided                                                      */
+                                           0: not provided.  PA_DTYPE_H2 models: offset (> 0) of the conv's npad per-output-
+                                           channel inverse weight-row scales (fp32)                                  */
     int64_t w_off, b_off;               /* offsets (in floats) of packed weights / bias in the blob */
 } pa_op_desc;
 
@@ -68,8 +69,15 @@ enum pa_task { PA_TASK_DETECT = 0, PA_TASK_POSE = 1, PA_TASK_TRACKNET = 2 };
  * PA_DTYPE_F16 (detect / pose only; BASELINE configs[4]): activations and conv weights are fp16, accumulation fp32
  * (v_mfma_f32_16x16x32_f16), biases / stem weights / the Detect-Pose head maps (head_buf) stay fp32; conv weights sit
  * in the blob as fp16 [npad][Ktot] with K order (64-channel chunk, tap, 32-channel half), cin % 32 == 0,
- * w_off still counts 4-byte blob words.                                                                      */
-enum pa_dtype { PA_DTYPE_F32 = 0, PA_DTYPE_F16 = 1 };
+ * w_off still counts 4-byte blob words.
+ * PA_DTYPE_H2 (the fast fp32-equivalent path): every activation is an fp16 PAIR (x ~ h + m / 2048, 22-23 significant
+ * bits) stored in 16-channel groups of 64 bytes [h x 16 | m x 16] — 4 bytes per channel like fp32 — written once by its
+ * producer; conv weights sit at w_off as pre-split planes [npad][k-step][h | m][32 fp16] of the row-scaled weights, the
+ * inverse row scales at `reserved`; a product is three f16 MFMAs instead of the six bf16 ones of the PA_DTYPE_F32 default
+ * (csrc/h2_common.h).  Biases, stem weights, head maps and the TrackNet heat map stay fp32.  Values beyond the fp16
+ * range (|x| > 65504) raise the model's overflow flag (pa_model_take_overflow): the caller repeats the call on a
+ * PA_DTYPE_F32 model.                                                                                         */
+enum pa_dtype { PA_DTYPE_F32 = 0, PA_DTYPE_F16 = 1, PA_DTYPE_H2 = 2 };
 
 typedef struct pa_model_desc {
     int32_t task;
@@ -120,6 +128,9 @@ int pa_engine_set_timeline_path(pa_engine* eng, const char* path);
 int pa_model_create(pa_engine* eng, const pa_model_desc* desc, const float* weights, size_t n_floats,
                     pa_model** out);
 void pa_model_destroy(pa_model* m);
+/* PA_DTYPE_H2 models: *out = 1 if any activation written since the last call did not fit the fp16 range (results of
+ * those inferences are invalid: repeat them on a PA_DTYPE_F32 model), then clears the flag; always 0 for other dtypes */
+int pa_model_take_overflow(pa_model* m, int* out);
 /* frames / windows processed per replay of the graph (activation buffers are sized for it); default 64 */
 int pa_model_set_max_batch(pa_model* m, int max_batch);
 /* activation bytes of the current plan: the liveness-shared arena actually allocated, and the sum of the

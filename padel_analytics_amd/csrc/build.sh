@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value ${PADEL_EXTRA_FLAGS:-}"
 mkdir -p build
 pids=()
-for f in conv_lds.hip conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_patch16.hip kernels_misc.hip postproc.hip tracknet_post.hip; do
+for f in conv_lds.hip conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_tap_h2.hip conv_patch_h2.hip conv_patch16.hip kernels_misc.hip postproc.hip tracknet_post.hip; do
   [ -f "$f" ] || continue
   hipcc $FLAGS -c "$f" -o "build/${f%.hip}.o" &
   pids+=($!)

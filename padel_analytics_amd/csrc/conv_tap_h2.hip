@@ -1,0 +1,378 @@
+// K3/K4 "h2" — the fp32 convolutions on the F16 matrix pipe with THREE products per operand pair (h2_common.h).
+//
+// Activations arrive in HBM as fp16 pairs (x ~ h + m / 2048, 16-channel groups of 64 bytes [h | m]) written by their
+// producer's epilogue, weights as pre-split planes [Npad][k-step][h | m][32].  This file is the implicit-GEMM TAP
+// kernel family for them — stride-2 3x3, 1x1 (optionally absorbing a preceding nn.Upsample(2)) and whatever stride-1
+// 3x3 the patch kernel (conv_patch_h2.hip) does not take.  It is the machine of conv_tap_bx3.hip (buffer-addressed
+// LDS-DMA ring with prefetch distance 1, XOR-swizzled 64-byte rows, one raw barrier per k-step, XCD-aware tile map)
+// with the in-register operand split REMOVED: sub-row A0 of a k-step is the h plane of its 32 channels, A1 the m plane,
+// both fetched with the same lane offsets (the lane that fills 16-byte slot s of a row fetches K slots 8s..8s+7: group
+// s >> 1, half s & 1 of the 128-byte chunk), and a k-step is 3 x MF x NF v_mfma_f32_16x16x32_f16:
+//     cross += wh * am;   cross += wm * ah;   part += wh * ah;          part -> acc once per 9-step block (two-level)
+// cin % 32 == 16: the 3x3 tail block pairs TAPS (K slots 0-15 = the 16 channels at tap 2t, 16-31 = at tap 2t+1: the
+// lanes of slots 2, 3 of a row fetch from the second tap's pixel); the 1x1 runs its last k-step with the lanes of the
+// absent group switched off (out-of-range offsets -> zeros).
+#include "h2_common.h"
+
+namespace padel {
+
+#define PADEL_H2T_AR(ST_) (((ST_) & 1) ? a_rd1 : a_rd0)
+#define PADEL_H2T_BR(ST_) (((ST_) & 1) ? b_rd1 : b_rd0)
+#define PADEL_H2T_LW(SR_) (((SR_) & 1) ? lw1 : lw0)
+#define PADEL_H2T_COMPUTE(ST_)                                                                                    \
+    do {                                                                                                          \
+        h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
+            ah[f] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(PADEL_H2T_AR(ST_) + f * 256));     \
+            am[f] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(PADEL_H2T_AR(ST_) + BM * 16 + f * 256)); \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
+            wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(PADEL_H2T_BR(ST_) + j * 256));     \
+            wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(PADEL_H2T_BR(ST_) + BN * 16 + j * 256)); \
+        }                                                                                                         \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[f], cross[f][j], 0, 0, 0);             \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);             \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], part[f][j], 0, 0, 0);               \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+
+#define PADEL_H2T_FLUSH()                                                                                         \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                            \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
+    } while (0)
+#define PADEL_H2T_SWAP()                                                                                          \
+    do { const float* t_ = a_rd0; a_rd0 = a_rd1; a_rd1 = t_; t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_;                \
+         const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; } while (0)
+
+// requests of one k-step into ring stage SR_: the h / m sub-rows of the activation tile (lane offsets V0_ / V1_ for
+// the 1-2 row passes, SGPR offset SA_ for the h plane, SA_ + 32 for the m plane), the two weight planes (SB_, SB_ + 64)
+#define PADEL_H2T_DMA_R(rsrcA, SR_, SA_, SB_, V0_, V1_)                                                           \
+    do {                                                                                                          \
+        const unsigned sa_ = (SA_), sb_ = (SB_);                                                                  \
+        dma3<0>((V0_), rsrcA, sa_, PADEL_H2T_LW(SR_));                                                            \
+        if constexpr (AP >= 2) dma3<RP * 64>((V1_), rsrcA, sa_, PADEL_H2T_LW(SR_));                               \
+        dma3<BM * 64>((V0_), rsrcA, sa_ + 32u, PADEL_H2T_LW(SR_));                                                \
+        if constexpr (AP >= 2) dma3<BM * 64 + RP * 64>((V1_), rsrcA, sa_ + 32u, PADEL_H2T_LW(SR_));               \
+        PADEL_H2T_DMAB(SR_, 0, sb_);                                                                              \
+        PADEL_H2T_DMAB(SR_, 1, sb_ + 64u);                                                                        \
+    } while (0)
+#define PADEL_H2T_DMAB(SR_, PL_, SB_)                                                                             \
+    do {                                                                                                          \
+        if constexpr (BFULL >= 1) dma3<2 * BM * 64 + (PL_) * BN * 64>(voffB[0], rsrcB, (SB_), PADEL_H2T_LW(SR_)); \
+        if constexpr (BFULL >= 2) dma3<2 * BM * 64 + (PL_) * BN * 64 + RP * 64>(voffB[1], rsrcB, (SB_), PADEL_H2T_LW(SR_)); \
+        if constexpr (BP > BFULL) { if (b_last) dma3<2 * BM * 64 + (PL_) * BN * 64 + BFULL * RP * 64>(voffB[BP - 1], rsrcB, (SB_), PADEL_H2T_LW(SR_)); } \
+    } while (0)
+
+#define PADEL_H2T_GEOMETRY()                                                                                      \
+    constexpr int NW = WM * WN;                                                                                   \
+    constexpr int RP = NW * 16;                                                                                   \
+    constexpr int BM = WM * MF * 16, BN = WN * NF * 16;                                                           \
+    constexpr int AP = BM / RP, BP = (BN + RP - 1) / RP, BFULL = BN / RP;                                         \
+    constexpr int STAGE = (2 * BM + 2 * BN) * 16;      /* 4-byte words per ring stage: Ah | Am | Wh | Wm */        \
+    constexpr int STAGE_B = STAGE * 4;                                                                            \
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");                                              \
+    static_assert(BM % RP == 0 && AP <= 2 && BFULL <= 2, "A in 1-2 full passes, B in at most 2 full + 1 partial"); \
+    static_assert(2 * STAGE_B <= 160 * 1024, "ring must fit the LDS");                                            \
+    __shared__ __attribute__((aligned(16))) float lds[2 * STAGE];                                                 \
+    const int tid = threadIdx.x;                                                                                  \
+    const int lane = tid & 63;                                                                                    \
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                                                    \
+    const int lr = lane & 15, lq = lane >> 4;                                                                     \
+    const int wm_ = wave / WN, wn_ = wave % WN;                                                                   \
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;                                                                 \
+    const int bid = blockIdx.x;                                                                                   \
+    /* XCD-aware 1-D tile map (conv_tap_bx3.hip): the channel tiles of one pixel tile are neighbours on one XCD */ \
+    const int q = nmt >> 3, r = nmt & 7, xcd = bid & 7, idx = bid >> 3;                                           \
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;                                                            \
+    if (mloc >= q + (xcd < r ? 1 : 0)) return;                                                                    \
+    const int mt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + mloc;                                \
+    const int m0 = mt * BM;                                                                                       \
+    const int f0 = nt * (WN * NF);                                                                                \
+    const int HoWo = a.Ho * a.Wo;                                                                                 \
+    const int srow = tid >> 2;                                                                                    \
+    const int sc = (tid & 3) ^ ((4 - ((srow >> 2) & 3)) & 3);      /* logical 16-byte slot this lane fetches */      \
+    const bool sc_hi = (sc >> 1) != 0;                                                                            \
+    const unsigned slot_b = (unsigned)((sc >> 1) * 64 + (sc & 1) * 16);   /* its place in a 128-byte h2 chunk (h plane) */ \
+    const int n0 = fastdiv3(m0, a.howo_magic, a.howo_shift), rem0 = m0 - n0 * HoWo;                               \
+    const int oy0 = fastdiv3(rem0, a.wo_magic, a.wo_shift), ox0 = rem0 - oy0 * a.Wo;                              \
+    const long long lin0 = ((long long)n0 * a.H + oy0 * a.stride) * a.W + ox0 * a.stride;                         \
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + wave * 1024u);            \
+    const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);                                       \
+    const float *a_rd0 = lds + (wm_ * MF * 16) * 16 + ld_off, *a_rd1 = a_rd0 + STAGE;                             \
+    const float *b_rd0 = lds + 2 * BM * 16 + (wn_ * NF * 16) * 16 + ld_off, *b_rd1 = b_rd0 + STAGE;               \
+    unsigned lw0 = lds_wave, lw1 = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)STAGE_B);                  \
+    const bool b_last = BP > BFULL && (BFULL * RP + wave * 16 < BN);                                              \
+    const int nch = (a.cin + 31) >> 5;                 /* 32-channel chunks (the last one half empty if cin & 16) */ \
+    const bool half_tail = (a.cin & 16) != 0;                                                                     \
+    (void)sc_hi; (void)nch;                                                                                       \
+    f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];                                                               \
+    _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                                \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
+
+// weight rows: nsteps * 128 bytes each (per k-step h | m planes of 32 fp16)
+#define PADEL_H2T_WEIGHTS(NSTEPS_)                                                                                \
+    const unsigned rowb = (unsigned)(NSTEPS_) * 128u;                                                             \
+    unsigned voffB[BP];                                                                                           \
+    _Pragma("unroll") for (int p = 0; p < BP; ++p) {                                                              \
+        const int rr = srow + RP * p;                                                                             \
+        const int frag = min(f0 + (rr >> 4), a.n16 - 1);                                                          \
+        voffB[p] = (unsigned)(((frag - f0) * 16 + (rr & 15)) * rowb + sc * 16);                                   \
+    }                                                                                                             \
+    const i32x4 rsrcB = make_rsrc3(reinterpret_cast<const char*>(a.w) + (long long)f0 * 16 * rowb);
+
+#define PADEL_H2T_FINISH()                                                                                        \
+    const bool fast_ = m0 + BM <= a.M && (f0 + WN * NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) && \
+                       (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));                                         \
+    int mpix_[MF];                                                                                                \
+    _Pragma("unroll") for (int f = 0; f < MF; ++f) { const int m_ = m0 + wm_ * MF * 16 + f * 16 + lr; mpix_[f] = m_ < a.M ? m_ : -1; } \
+    h2_epilogue<MF, NF>(a, acc, cross, mpix_, f0 + wn_ * NF, lq, fast_);
+
+// =====================================================================================================  3x3
+template <int WM, int WN, int MF, int NF>
+__global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_kernel(const ConvArgs a) {
+    PADEL_H2T_GEOMETRY()
+    unsigned voffA[AP][9];
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        int m = m0 + srow + RP * p;
+        const bool rv = m < a.M;
+        if (!rv) m = m0;
+        const int n = fastdiv3(m, a.howo_magic, a.howo_shift);
+        const int rem = m - n * HoWo;
+        const int oy = fastdiv3(rem, a.wo_magic, a.wo_shift);
+        const int ox = rem - oy * a.Wo;
+        const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
+        const unsigned off = (unsigned)((lin - lin0) * a.in_cs * 4) + slot_b;
+        bool vy[3], vx[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            vy[d] = rv && (unsigned)(oy * a.stride - 1 + d) < (unsigned)a.H;
+            vx[d] = (unsigned)(ox * a.stride - 1 + d) < (unsigned)a.W;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) voffA[p][t] = (vy[t / 3] && vx[t % 3]) ? off : kOORh;
+    }
+    const i32x4 rsrcA = make_rsrc3(a.in + ((lin0 - (a.W + 1)) * a.in_cs + a.in_choff));
+    unsigned tapoff[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((unsigned)((((t / 3) * a.W + (t % 3)) * a.in_cs) * 4));
+    // K walk: nfull 32-channel chunks x 9 taps, then — for cin % 32 == 16 — a TAIL block of 5 steps that pair taps
+    const int nfull = a.cin >> 5;
+    PADEL_H2T_WEIGHTS(nfull * 9 + (half_tail ? 5 : 0))
+
+    unsigned s_chunk = 0, s_kb = 0;
+#define PADEL_H2T_REQ_FULL(SR_, CH_, KB_, T_)                                                                      \
+    PADEL_H2T_DMA_R(rsrcA, SR_, (CH_) + tapoff[T_], KB_, voffA[0][T_], voffA[AP - 1][T_])
+    // tail step JT_: lanes of slots 0, 1 fetch the group's parts at tap 2 JT_, lanes of slots 2, 3 at tap 2 JT_ + 1 (their
+    // offsets carry + 64 for "second group of a chunk": taken back out; the tap distance goes in instead)
+#define PADEL_H2T_TV(P_, JT_)                                                                                      \
+    (sc_hi ? (2 * (JT_) + 1 < 9 ? voffA[P_][2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] + (tapoff[2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] - tapoff[2 * (JT_)]) - 64u : kOORh) \
+           : voffA[P_][2 * (JT_)])
+#define PADEL_H2T_REQ_TAIL(SR_, CH_, KB_, JT_)                                                                     \
+    do {                                                                                                          \
+        const unsigned v0_ = PADEL_H2T_TV(0, JT_), v1_ = PADEL_H2T_TV(AP - 1, JT_);                                \
+        PADEL_H2T_DMA_R(rsrcA, SR_, (CH_) + tapoff[2 * (JT_)], KB_, v0_, v1_);                                     \
+    } while (0)
+    bool nxt_tail = false;       // the block after the current full chunk is the tail block
+
+    // step J waits for ITS requests (issued one step earlier), passes the barrier, requests step J + 1 into the stage
+    // everybody just finished reading, computes.  Stage = parity of the step inside the block; blocks have odd length
+    // (9 / 5), so the two stages swap roles after every block.
+#define PADEL_H2T_STEP2(J)                                                                                        \
+    do {                                                                                                          \
+        wait_vm3<0>();                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        if constexpr ((J) + 1 < 9) {                                                                              \
+            PADEL_H2T_REQ_FULL((J) + 1, s_chunk, s_kb + ((J) + 1) * 128u, (J) + 1 < 9 ? (J) + 1 : 0);             \
+        } else {                                                                                                  \
+            if (nxt_tail) { PADEL_H2T_REQ_TAIL((J) + 1, s_chunk + 128u, s_kb + ((J) + 1) * 128u, 0); }            \
+            else if (c + 1 < nfull) { PADEL_H2T_REQ_FULL((J) + 1, s_chunk + 128u, s_kb + ((J) + 1) * 128u, 0); }  \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_H2T_COMPUTE(J);                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define PADEL_H2T_TSTEP2(JT)                                                                                      \
+    do {                                                                                                          \
+        wait_vm3<0>();                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        if constexpr ((JT) + 1 < 5) { PADEL_H2T_REQ_TAIL((JT) + 1, s_chunk, s_kb + ((JT) + 1) * 128u, (JT) + 1 < 5 ? (JT) + 1 : 0); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_H2T_COMPUTE(JT);                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    if (nfull > 0) { PADEL_H2T_REQ_FULL(0, 0u, 0u, 0); } else { PADEL_H2T_REQ_TAIL(0, 0u, 0u, 0); }
+    for (int c = 0; c < nfull; ++c) {
+        nxt_tail = half_tail && c == nfull - 1;
+        PADEL_H2T_STEP2(0); PADEL_H2T_STEP2(1); PADEL_H2T_STEP2(2); PADEL_H2T_STEP2(3); PADEL_H2T_STEP2(4);
+        PADEL_H2T_STEP2(5); PADEL_H2T_STEP2(6); PADEL_H2T_STEP2(7); PADEL_H2T_STEP2(8);
+        PADEL_H2T_FLUSH();
+        PADEL_H2T_SWAP();
+        s_chunk += 128u;
+        s_kb += 9u * 128u;
+    }
+    if (half_tail) {
+        PADEL_H2T_TSTEP2(0); PADEL_H2T_TSTEP2(1); PADEL_H2T_TSTEP2(2); PADEL_H2T_TSTEP2(3); PADEL_H2T_TSTEP2(4);
+        PADEL_H2T_FLUSH();
+    }
+    wait_vm3<0>();
+    PADEL_H2T_FINISH()
+#undef PADEL_H2T_STEP2
+#undef PADEL_H2T_TSTEP2
+#undef PADEL_H2T_REQ_FULL
+#undef PADEL_H2T_REQ_TAIL
+#undef PADEL_H2T_TV
+}
+
+// =====================================================================================================  1x1
+// UP: the first a.up_c channels (whole 32-channel chunks) are read from a.in2, a map of half the spatial size, at
+// [y >> 1][x >> 1] — an nn.Upsample(2) + torch.cat in front of this conv that is never materialised
+template <int WM, int WN, int MF, int NF, bool UP>
+__global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_1_kernel(const ConvArgs a) {
+    PADEL_H2T_GEOMETRY()
+    unsigned voffA[AP], voffT[AP], voffU[AP];
+    const int H2 = a.H >> 1, W2 = a.W >> 1;
+    const long long linU0 = ((long long)n0 * H2 + (oy0 >> 1)) * W2;      // first coarse pixel of the coarse row of m0
+#pragma unroll
+    for (int p = 0; p < AP; ++p) {
+        int m = m0 + srow + RP * p;
+        const bool rv = m < a.M;
+        if (!rv) m = m0;
+        const int n = fastdiv3(m, a.howo_magic, a.howo_shift);
+        const int rem = m - n * HoWo;
+        const int oy = fastdiv3(rem, a.wo_magic, a.wo_shift);
+        const int ox = rem - oy * a.Wo;
+        const long long lin = ((long long)n * a.H + oy * a.stride) * a.W + ox * a.stride;
+        voffA[p] = rv ? (unsigned)((lin - lin0) * a.in_cs * 4) + slot_b : kOORh;
+        voffT[p] = sc_hi ? kOORh : voffA[p];               // last chunk of a cin % 32 == 16 layer: its second group does not exist
+        if constexpr (UP) {
+            const long long linU = ((long long)n * H2 + (oy >> 1)) * W2 + (ox >> 1);
+            voffU[p] = rv ? (unsigned)((linU - linU0) * a.in2_cs * 4) + slot_b : kOORh;
+        }
+    }
+    (void)voffU; (void)linU0;
+    const i32x4 rsrcA = make_rsrc3(a.in + (lin0 * a.in_cs + a.in_choff));
+    const i32x4 rsrcU = make_rsrc3(UP ? a.in2 + (linU0 * a.in2_cs + a.in2_choff) : a.in);
+    const unsigned nup = UP ? (unsigned)(a.up_c >> 5) : 0u;
+    (void)rsrcU; (void)nup;
+    PADEL_H2T_WEIGHTS(nch)
+    // requests of chunk K_ into stage SR_: from the coarse map while K_ < nup
+#define PADEL_H2T_1REQ(SR_, K_)                                                                                   \
+    do {                                                                                                          \
+        const unsigned k_ = (K_);                                                                                 \
+        if (UP && k_ < nup) {                                                                                     \
+            PADEL_H2T_DMA_R(rsrcU, SR_, k_ * 128u, k_ * 128u, voffU[0], voffU[AP - 1]);                            \
+        } else if (half_tail && (int)k_ >= nch - 1) {                                                             \
+            PADEL_H2T_DMA_R(rsrcA, SR_, k_ * 128u, k_ * 128u, voffT[0], voffT[AP - 1]);                            \
+        } else {                                                                                                  \
+            PADEL_H2T_DMA_R(rsrcA, SR_, k_ * 128u, k_ * 128u, voffA[0], voffA[AP - 1]);                            \
+        }                                                                                                         \
+    } while (0)
+
+    unsigned s_k = 0;                         // index of the first k-step of the current 9-step accumulation block
+#define PADEL_H2T_1STEP2(J)                                                                                       \
+    if ((J) < nb) {                                                                                               \
+        wait_vm3<0>();                                                                                            \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        if ((int)(s_k + (J) + 1) < nch) PADEL_H2T_1REQ((J) + 1, s_k + (J) + 1);                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_H2T_COMPUTE(J);                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    }
+    PADEL_H2T_1REQ(0, 0u);
+    for (int k = 0; k < nch; k += 9) {
+        const int nb = min(9, nch - k);
+        PADEL_H2T_1STEP2(0) PADEL_H2T_1STEP2(1) PADEL_H2T_1STEP2(2) PADEL_H2T_1STEP2(3) PADEL_H2T_1STEP2(4)
+        PADEL_H2T_1STEP2(5) PADEL_H2T_1STEP2(6) PADEL_H2T_1STEP2(7) PADEL_H2T_1STEP2(8)
+        PADEL_H2T_FLUSH();
+        PADEL_H2T_SWAP();
+        s_k += 9u;
+    }
+    wait_vm3<0>();
+    PADEL_H2T_FINISH()
+#undef PADEL_H2T_1STEP2
+#undef PADEL_H2T_1REQ
+}
+
+template <int WM, int WN, int MF, int NF>
+static hipError_t launch_h2t(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    constexpr int BM = WM * MF * 16;
+    a.n_mtiles = (a.M + BM - 1) / BM;
+    a.n_ntiles = (a.n16 + WN * NF - 1) / (WN * NF);
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    if (a.ksize == 3) {
+        if (a.in2) return hipErrorNotSupported;
+        hipLaunchKernelGGL((conv_h2_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+    } else if (a.in2) {
+        if (a.stride != 1 || (a.up_c & 31) || a.up_c <= 0 || a.up_c > a.cin || ((a.H | a.W) & 1)) return hipErrorNotSupported;
+        hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, true>), grid, dim3(64 * WM * WN), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, false>), grid, dim3(64 * WM * WN), 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+// tile ids follow the bf16x3 ids (conv_variant_shape + 200); 30x = the patch kernel (conv_patch_h2.hip) or, where it does
+// not apply, its tap sibling
+hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
+    if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16 || !a.w || !a.oscale || !a.ovf_flag) return hipErrorNotSupported;
+    if (variant >= 300 && variant < 400) {
+        const int nf = variant - 300;
+        if (conv_h2p_supported(a)) return launch_conv_h2p(a, nf, s);
+        if (a.in2 && a.ksize == 3) return hipErrorNotSupported;      // an absorbed upsample in front of a 3x3: the patch kernel only
+        variant = nf == 3 ? 220 : nf == 4 ? 209 : 213;
+    }
+    if (a.in2 && a.ksize == 3) return hipErrorNotSupported;
+    switch (variant) {
+        case 207: return launch_h2t<2, 2, 2, 3>(a, s);    //  64 x  96
+        case 220: return launch_h2t<4, 1, 2, 3>(a, s);    // 128 x  48
+        case 209: return launch_h2t<4, 1, 2, 4>(a, s);    // 128 x  64
+        case 211: return launch_h2t<4, 1, 2, 2>(a, s);    // 128 x  32
+        case 213: return launch_h2t<4, 1, 2, 6>(a, s);    // 128 x  96, 4 waves of 2 x 6 fragments
+        case 225: return launch_h2t<4, 1, 1, 5>(a, s);    //  64 x  80: the 19-fragment (304-channel) fused pose heads
+    }
+    return hipErrorNotSupported;
+}
+
+// Per-layer tile choice.  Relative speeds start from the bf16x3 measurements (profiles/conv_bx3_sweep_r2*.txt) and are
+// re-measured for h2 in profiles/conv_h2_sweep_r3*.txt; the rest is padding waste and the fill of the last round.
+int choose_conv_h2_variant(const ConvArgs& a) {
+    const int M = a.M, n16 = a.n16, ksize = a.ksize;
+    struct V { int id, bm, nf; float s3, s1; };
+    static const V vs[] = {{213, 128, 6, 1.07f, 1.08f}, {220, 128, 3, 1.00f, 1.00f}, {207, 64, 6, 0.98f, 0.95f}, {209, 128, 4, 1.00f, 1.00f},
+                           {211, 128, 2, 0.85f, 0.87f}, {225, 64, 5, 0.95f, 0.90f}};
+    float best = -1.f;
+    int bv = 220;
+    for (const V& v : vs) {
+        const int ntiles = (n16 + v.nf - 1) / v.nf;
+        const long long mtiles = (M + v.bm - 1) / v.bm;
+        const float fill = (float)n16 / (float)(ntiles * v.nf) * (float)M / (float)(mtiles * v.bm);
+        const long long blocks = mtiles * ntiles;
+        const long long per_cu = (blocks + 255) / 256;
+        const float occ = (float)blocks / (256.f * (float)per_cu);
+        const float sc = (ksize == 3 ? v.s3 : v.s1) * fill * occ;
+        if (sc > best) { best = sc; bv = v.id; }
+    }
+    if (conv_h2p_supported(a)) {
+        struct P { int nf; float sp; };
+        static const P ps[] = {{3, 1.17f}, {4, 1.14f}, {6, 1.16f}};
+        const long long patches = (long long)(M / (a.Ho * a.Wo)) * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+        for (const P& v : ps) {
+            const int ntiles = (n16 + v.nf - 1) / v.nf;
+            const float fill = (float)n16 / (float)(ntiles * v.nf) * (float)M / (float)(patches * 128);
+            const long long blocks = patches * ntiles;
+            const long long per_cu = (blocks + 255) / 256;
+            const float sc = v.sp * fill * (float)blocks / (256.f * (float)per_cu);
+            if (sc > best) { best = sc; bv = 300 + v.nf; }
+        }
+    }
+    return bv;
+}
+
+}  // namespace padel

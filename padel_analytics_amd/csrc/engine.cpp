@@ -78,6 +78,8 @@ struct pa_model {
     std::vector<int> fold_dst;             // upsample op j -> its absorbing conv (-1: none)
     float* d_w = nullptr;
     size_t n_w = 0;
+    unsigned* d_ovf = nullptr;             // h2 models: sticky "a value did not fit fp16" flag (pa_model_take_overflow)
+    float* d_stage = nullptr; size_t stage_cap = 0;   // h2 generic graphs: fp32 input staged here before it is encoded
     int max_batch = 64;
 
     // plan
@@ -220,8 +222,8 @@ int pa_memcpy_d2h(pa_engine* e, void* dst, const void* src, size_t n) {
 // ------------------------------------------------------------------------------- model
 static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) {
     if (d->n_bufs <= 0 || d->n_ops <= 0 || !d->bufs || !d->ops) PA_FAIL(e, "model desc: empty graph");
-    const bool f16 = d->dtype == PA_DTYPE_F16;
-    if (d->dtype != PA_DTYPE_F32 && d->dtype != PA_DTYPE_F16) PA_FAIL(e, "model desc: dtype %d", d->dtype);
+    const bool f16 = d->dtype == PA_DTYPE_F16, h2 = d->dtype == PA_DTYPE_H2;
+    if (d->dtype != PA_DTYPE_F32 && d->dtype != PA_DTYPE_F16 && d->dtype != PA_DTYPE_H2) PA_FAIL(e, "model desc: dtype %d", d->dtype);
     // (a TASK_TRACKNET graph in fp16 is a generic op list run through pa_tracknet_infer — conv unit tests; the ball
     // session itself is fp32 only, see pa_ball_create)
     const int kalign = f16 ? 31 : 15, valign = f16 ? 7 : 3;      // conv K granularity, 16-byte vector granularity (elements)
@@ -231,22 +233,30 @@ static int validate_desc(pa_engine* e, const pa_model_desc* d, size_t n_floats) 
     auto okslice = [&](int b, int off, int c) {
         return b >= 0 && b < d->n_bufs && off >= 0 && c > 0 && off + c <= d->bufs[b].channels;
     };
+    auto is_head_buf = [&](int b) { return b == d->head_buf[0] || b == d->head_buf[1] || b == d->head_buf[2]; };
+    if (h2)          // h2 buffers are made of whole 16-channel groups (the fp32 head maps excepted)
+        for (int i = 0; i < d->n_bufs; ++i)
+            if (!is_head_buf(i) && (d->bufs[i].channels & 15)) PA_FAIL(e, "model desc: h2 buffer %d has %d channels", i, d->bufs[i].channels);
     for (int i = 0; i < d->n_ops; ++i) {
         const pa_op_desc& o = d->ops[i];
         if (!okslice(o.out_buf, o.out_choff, o.cout)) PA_FAIL(e, "op %d: bad output slice", i);
+        if (h2 && o.kind != PA_OP_STEM && (((o.in_choff | o.cin) & 15) || (!is_head_buf(o.out_buf) && (o.out_choff & 3))))
+            PA_FAIL(e, "op %d: h2 slices must start on a 16-channel group", i);
         if (o.kind != PA_OP_STEM && !okslice(o.in_buf, o.in_choff, o.cin)) PA_FAIL(e, "op %d: bad input slice", i);
         if (o.kind == PA_OP_CONV) {
             if ((o.cin & kalign) || (o.in_choff & valign) || (o.ksize != 1 && o.ksize != 3) || (o.stride != 1 && o.stride != 2))
                 PA_FAIL(e, "op %d: unsupported conv (cin %d choff %d k %d s %d)", i, o.cin, o.in_choff, o.ksize, o.stride);
             if (o.npad < o.cout || (o.npad & 15)) PA_FAIL(e, "op %d: npad %d for cout %d", i, o.npad, o.cout);
-            const size_t wn = (size_t)o.npad * o.cin * o.ksize * o.ksize / (f16 ? 2 : 1);
+            const size_t ksteps3 = o.ksize == 3 ? (size_t)(o.cin / 32) * 9 + ((o.cin & 16) ? 5 : 0) : (size_t)(o.cin + 31) / 32;
+            const size_t wn = h2 ? (size_t)o.npad * ksteps3 * 32 : (size_t)o.npad * o.cin * o.ksize * o.ksize / (f16 ? 2 : 1);
             if (o.w_off < 0 || (o.w_off & 3) || (size_t)o.w_off + wn > n_floats || o.b_off < 0 ||
                 (size_t)o.b_off + o.npad > n_floats)
                 PA_FAIL(e, "op %d: weights outside the blob", i);
             if (o.res_buf >= 0 && !okslice(o.res_buf, o.res_choff, o.cout)) PA_FAIL(e, "op %d: bad residual slice", i);
-            if (o.reserved < 0 || (o.reserved & 3) ||
-                (o.reserved > 0 && (size_t)o.reserved + (size_t)o.npad * 48 *
-                     (o.ksize == 3 ? (size_t)(o.cin / 32) * 9 + ((o.cin & 16) ? 5 : 0) : (size_t)(o.cin + 31) / 32) > n_floats))
+            if (h2) {
+                if (o.reserved <= 0 || (o.reserved & 3) || (size_t)o.reserved + o.npad > n_floats) PA_FAIL(e, "op %d: h2 row scales outside the blob", i);
+                if (o.res_buf >= 0 && (o.res_choff & 3)) PA_FAIL(e, "op %d: h2 residual slice alignment", i);
+            } else if (o.reserved < 0 || (o.reserved & 3) || (o.reserved > 0 && (size_t)o.reserved + (size_t)o.npad * 48 * ksteps3 > n_floats))
                 PA_FAIL(e, "op %d: bf16x3 weights outside the blob", i);
             const int lin = d->bufs[o.in_buf].level, lout = d->bufs[o.out_buf].level;
             if (lout != lin + (o.stride == 2 ? 1 : 0)) PA_FAIL(e, "op %d: level mismatch", i);
@@ -298,6 +308,8 @@ int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weight
         r = weights ? hipMemcpyAsync(m->d_w, weights, n_floats * sizeof(float), hipMemcpyHostToDevice, e->stream)
                     : hipMemsetAsync(m->d_w, 0, n_floats * sizeof(float), e->stream);
     if (r == hipSuccess) r = hipMemsetAsync(m->d_w + n_floats, 0, kConvReadSlack, e->stream);
+    if (r == hipSuccess) r = hipMalloc((void**)&m->d_ovf, 256);
+    if (r == hipSuccess) r = hipMemsetAsync(m->d_ovf, 0, 256, e->stream);
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
     if (r != hipSuccess) { delete m; PA_FAIL(e, "weights upload: %s", hipGetErrorString(r)); }
     *out = m;
@@ -329,7 +341,26 @@ void pa_model_destroy(pa_model* m) {
     if (m->d_frames) hipFree(m->d_frames);
     if (m->d_classes) hipFree(m->d_classes);
     if (m->d_w) hipFree(m->d_w);
+    if (m->d_ovf) hipFree(m->d_ovf);
+    if (m->d_stage) hipFree(m->d_stage);
     delete m;
+}
+
+int pa_model_take_overflow(pa_model* m, int* out) {
+    if (!m || !out) return 1;
+    pa_engine* e = m->e;
+    *out = 0;
+    if (m->d.dtype != PA_DTYPE_H2) return 0;
+    PA_HIP(e, hipSetDevice(e->dev));
+    unsigned v = 0;
+    PA_HIP(e, hipMemcpyAsync(&v, m->d_ovf, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    if (v) {
+        PA_HIP(e, hipMemsetAsync(m->d_ovf, 0, sizeof(v), e->stream));
+        PA_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    *out = v ? 1 : 0;
+    return 0;
 }
 
 int pa_model_set_max_batch(pa_model* m, int max_batch) {
@@ -456,6 +487,7 @@ static void find_upsample_folds(pa_model* m) {
     }
 }
 static bool fold_active(const pa_model* m, int conv_op) {
+    if (m->d.dtype == PA_DTYPE_H2) return m->e->t.fold_up && m->fold_src[conv_op] >= 0;
     return m->e->t.fold_up && m->e->t.impl == 2 && m->d.dtype != PA_DTYPE_F16 && m->fold_src[conv_op] >= 0;
 }
 
@@ -629,11 +661,21 @@ static int conv_launch_args(const pa_model* m, size_t i, int n, ConvArgs& a) {
     fill_fastdiv((unsigned)(Ho * Wo), &a.howo_magic, &a.howo_shift);
     fill_fastdiv((unsigned)Wo, &a.wo_magic, &a.wo_shift);
     a.tune = e->t.tune; a.tap_pd = e->t.tap_pd;
-    const bool f16 = m->d.dtype == PA_DTYPE_F16;
+    const bool f16 = m->d.dtype == PA_DTYPE_F16, h2 = m->d.dtype == PA_DTYPE_H2;
     const bool use_tap = e->t.impl == 0 || f16;
-    const bool use_bx3 = !f16 && e->t.impl == 2 && o.reserved > 0;
+    const bool use_bx3 = !f16 && !h2 && e->t.impl == 2 && o.reserved > 0;
     a.w3 = use_bx3 ? (const void*)(m->d_w + o.reserved) : nullptr;
-    a.out_f32 = f16 && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
+    a.out_f32 = (f16 || h2) && (o.out_buf == m->d.head_buf[0] || o.out_buf == m->d.head_buf[1] || o.out_buf == m->d.head_buf[2]);
+    if (h2) {
+        a.oscale = m->d_w + o.reserved;
+        a.ovf_flag = m->d_ovf;
+        const int lv = e->t.variant >= 0 ? e->t.variant : choose_conv_h2_variant(a);
+        if (fold_active(m, (int)i) && (o.ksize == 1 || (lv >= 300 && lv < 400 && conv_h2p_supported(a)))) {
+            const pa_op_desc& u = m->ops[m->fold_src[i]];       // the first up_c channels come from the coarse map
+            a.in2 = m->bptr[u.in_buf]; a.in2_cs = m->bufs[u.in_buf].channels; a.in2_choff = u.in_choff; a.up_c = u.cin;
+        }
+        return lv;
+    }
     const int lv = e->t.variant >= 0 ? e->t.variant
                    : f16 ? choose_conv_tap16_variant(a)
                    : use_bx3 ? choose_conv_bx3_variant(a)
@@ -658,11 +700,11 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
         if (o.kind == PA_OP_CONV) {
             ConvArgs a{};
             const int lv = conv_launch_args(m, i, n, a);
-            const bool f16 = m->d.dtype == PA_DTYPE_F16;
+            const bool f16 = m->d.dtype == PA_DTYPE_F16, h2 = m->d.dtype == PA_DTYPE_H2;
             const bool use_tap = e->t.impl == 0 || f16;
             const bool use_bx3 = a.w3 != nullptr;
             int bm = 0, bn = 0;
-            if (f16 && lv >= 300) { bm = 128; bn = (lv - 300) * 16; }
+            if ((f16 || h2) && lv >= 300) { bm = 128; bn = (lv - 300) * 16; }
             else if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
             else if (lv >= 300) { bm = 128; bn = (lv - 300) * 16; }          // patch kernel: 8 x 16 pixels x nf fragments
             else conv_variant_shape(lv >= 200 ? lv - 200 : lv, &bm, &bn);   // profile rows carry BM, BN of the workgroup tile
@@ -677,7 +719,9 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
                 else dbg_dev = nullptr;
                 a.dbg = dbg_dev;
             }
-            if (f16) {
+            if (h2) {
+                r = launch_conv_h2(a, lv, s);
+            } else if (f16) {
                 r = launch_conv_tap16(a, lv, s);
             } else if (use_bx3) {
                 r = launch_conv_bx3(a, lv, s);
@@ -699,13 +743,13 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.in = m->d_netin; a.w = m->d_w + o.w_off; a.bias = m->d_w + o.b_off;
             a.out = m->bptr[o.out_buf]; a.out_cs = ob.channels; a.out_choff = o.out_choff;
             a.H = m->net_h; a.W = m->net_w; a.Ho = Ho; a.Wo = Wo; a.cout = o.cout; a.B = n;
-            a.out_f16 = m->d.dtype == PA_DTYPE_F16;
+            a.out_f16 = m->d.dtype == PA_DTYPE_F16 ? 1 : m->d.dtype == PA_DTYPE_H2 ? 2 : 0;
+            a.ovf_flag = m->d_ovf;
             pr = prof_begin(m, (*pi)++, o.kind, 3, 2.0 * n * Ho * Wo * (double)o.cout * 27);
             r = launch_stem(a, s);
         } else if (o.kind == PA_OP_SPPF_POOL) {
             pr = prof_begin(m, (*pi)++, o.kind, 5, 0.0);
-            r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s,
-                                 m->d.dtype == PA_DTYPE_F16);
+            r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s, (int)m->d.dtype);
         } else if (o.kind == PA_OP_UPSAMPLE2X) {
             if (m->fold_dst[i] >= 0) {                   // absorbed by its consumer conv?  (same decision as at that conv)
                 ConvArgs ca{};
@@ -714,11 +758,11 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             }
             pr = prof_begin(m, (*pi)++, o.kind, 0, 0.0);
             r = launch_upsample2x(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
-                                  ob.channels, o.out_choff, o.cin, n, Ho / 2, Wo / 2, s, m->d.dtype == PA_DTYPE_F16);
+                                  ob.channels, o.out_choff, o.cin, n, Ho / 2, Wo / 2, s, (int)m->d.dtype);
         } else if (o.kind == PA_OP_MAXPOOL2) {
             pr = prof_begin(m, (*pi)++, o.kind, 2, 0.0);
             r = launch_maxpool2(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, m->bptr[o.out_buf],
-                                ob.channels, o.out_choff, o.cin, n, Ho * 2, Wo * 2, s, m->d.dtype == PA_DTYPE_F16);
+                                ob.channels, o.out_choff, o.cin, n, Ho * 2, Wo * 2, s, (int)m->d.dtype);
         }
         prof_end(m, pr);
         if (r != hipSuccess) PA_FAIL(e, "op %zu (kind %d) launch failed: %s", i, o.kind, hipGetErrorString(r));
@@ -933,11 +977,28 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
     const int ob = m->d.head_buf[0];
     const int cout = m->bufs[ob].channels;
     const size_t es_in = m->d.dtype == PA_DTYPE_F16 ? 2 : 4;     // fp16 graphs take their input as halves
+    const bool h2 = m->d.dtype == PA_DTYPE_H2;                  // h2 graphs take fp32 and encode it on the device
+    if (h2 && (cin & 15)) PA_FAIL(e, "pa_tracknet_infer: h2 input buffer has %d channels", cin);
     size_t pi = 0;
     for (int c0 = 0; c0 < n; c0 += m->max_batch) {
         const int nb = std::min(m->max_batch, n - c0);
         const size_t in_bytes = (size_t)nb * h * w * cin * es_in;
-        PA_HIP(e, hipMemcpyAsync(m->bptr[0], reinterpret_cast<const char*>(x) + (size_t)c0 * h * w * cin * es_in, in_bytes,
+        const char* xs = reinterpret_cast<const char*>(x) + (size_t)c0 * h * w * cin * es_in;
+        if (h2) {
+            const float* src = reinterpret_cast<const float*>(xs);
+            if (!x_on_device) {
+                if (m->stage_cap < in_bytes) {
+                    if (m->d_stage) hipFree(m->d_stage);
+                    m->stage_cap = (size_t)m->max_batch * h * w * cin * 4;
+                    PA_HIP(e, hipMalloc((void**)&m->d_stage, m->stage_cap));
+                }
+                PA_HIP(e, hipMemcpyAsync(m->d_stage, xs, in_bytes, hipMemcpyHostToDevice, s));
+                src = m->d_stage;
+            }
+            const hipError_t er = launch_h2_encode(src, m->bptr[0], (long long)(in_bytes / 4), m->d_ovf, s);
+            if (er != hipSuccess) PA_FAIL(e, "h2 encode launch failed: %s", hipGetErrorString(er));
+        } else
+        PA_HIP(e, hipMemcpyAsync(m->bptr[0], xs, in_bytes,
                                  x_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
         if (run_graph(m, nb, &pi)) return 1;
         const size_t ohw = (size_t)(h >> m->bufs[ob].level) * (w >> m->bufs[ob].level);
@@ -977,7 +1038,8 @@ void pa_ball_destroy(pa_ball* b);
 int pa_ball_create(pa_model* m, int src_h, int src_w, pa_ball** out) {
     if (!m || !out) return 1;
     pa_engine* e = m->e;
-    if (m->d.task != PA_TASK_TRACKNET || m->d.dtype != PA_DTYPE_F32) PA_FAIL(e, "pa_ball_create: not an fp32 TrackNet model");
+    if (m->d.task != PA_TASK_TRACKNET || (m->d.dtype != PA_DTYPE_F32 && m->d.dtype != PA_DTYPE_H2))
+        PA_FAIL(e, "pa_ball_create: not an fp32 / h2 TrackNet model");
     if (m->bufs[0].channels != 32) PA_FAIL(e, "pa_ball_create: TrackNet input buffer must have 32 channels (27 + pad)");
     PA_HIP(e, hipSetDevice(e->dev));
     if (src_h <= 0 || src_w <= 0) PA_FAIL(e, "pa_ball_create: unsupported source size %dx%d", src_w, src_h);
@@ -1156,6 +1218,7 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
             BallAssembleArgs aa{};
             aa.median = b->d_med; aa.frames = b->d_small; aa.lut = b->d_lut; aa.out = m->bptr[0];
             aa.B = nw; aa.H = BALL_H; aa.W = BALL_W; aa.ring = b->ring; aa.first_slot = (int)(g_lo % b->ring);
+            aa.out_h2 = m->d.dtype == PA_DTYPE_H2;
             hipError_t r = launch_ball_assemble(aa, s);
             if (r != hipSuccess) PA_FAIL(e, "ball assemble launch failed: %s", hipGetErrorString(r));
             if (run_graph(m, nw, &prof_n)) return 1;

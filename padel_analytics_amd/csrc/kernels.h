@@ -36,7 +36,9 @@ struct ConvArgs {
     int n_ntiles;         // bx3 / fp16 kernels (1-D grid): channel tiles per pixel tile
     int tune;             // bit 0: s_setprio(1) around MFMA clusters; bit 1: staggered workgroup start
     int tap_pd;           // 1x1 tap kernel: prefetch distance 2 or 3 (pa_engine_set_tuning "tap_pd")
-    int out_f32;          // fp16 kernels only: 1 = `out` is an fp32 buffer (convs that feed the Detect/Pose decode)
+    int out_f32;          // fp16 / h2 kernels only: 1 = `out` is an fp32 buffer (convs that feed the Detect/Pose decode)
+    const float* oscale;  // h2 kernels: [Npad] 1 / (power-of-two scale of the weight row), applied before the bias
+    unsigned* ovf_flag;   // h2 kernels: set to 1 when an output value does not fit the fp16 range (h2_common.h)
     unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_lds.hip DIAG 16
     // m / (Ho*Wo) and rem / Wo without an integer-division sequence (conv_tap.hip prologue): q = (umulhi(n, magic) + n) >> shift,
     // exact for 0 <= n < 2^31 (fill_fastdiv below; the conv kernels' rows satisfy n < 2^31)
@@ -71,6 +73,13 @@ int choose_conv_bx3_variant(const ConvArgs& a);      // per-layer tile heuristic
 // nf = channel fragments per workgroup (3, 4, 6); reached through launch_conv_bx3 ids 303 / 304 / 306
 bool conv_bx3p_supported(const ConvArgs& a);
 hipError_t launch_conv_bx3p(const ConvArgs& a, int nf, hipStream_t s);
+// h2 path (conv_tap_h2.hip, conv_patch_h2.hip; h2_common.h): activations are fp16 PAIRS (x ~ h + m / 2048) in 16-channel
+// groups of 64 bytes [h x 16 | m x 16], 4 bytes per channel like fp32 (cs / choff count channels); weights `w` are the
+// pre-split planes [Npad][k-step][h | m][32 fp16], `oscale` the inverse row scales; three f16 MFMAs per operand pair
+hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s);        // tap tiles 207..225, patch tiles 303 / 304 / 306
+int choose_conv_h2_variant(const ConvArgs& a);
+bool conv_h2p_supported(const ConvArgs& a);
+hipError_t launch_conv_h2p(const ConvArgs& a, int nf, hipStream_t s);
 // fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and
 // choff count elements); cin % 32 == 0; weights packed [Npad][Ktot] with K order (64-channel chunk, tap, 32-channel half)
 hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s);
@@ -87,17 +96,21 @@ struct StemArgs {
     float* out;           // NHWC fp32 (or fp16 with out_f16), pixel stride out_cs
     int out_cs, out_choff;
     int H, W, Ho, Wo, cout, B;
-    int out_f16;          // 1: `out` is a _Float16 buffer (fp16 models; the stem itself computes in fp32)
+    int out_f16;          // 1: `out` is a _Float16 buffer (fp16 models; the stem itself computes in fp32); 2: h2 pairs
+    unsigned* ovf_flag;   // out_f16 == 2: raised when a value does not fit the fp16 range
     unsigned howo_magic, howo_shift, wo_magic, wo_shift;   // filled by launch_stem (fill_fastdiv): pixel index -> (n, oy, ox)
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
 
 // SPPF: three chained MaxPool2d(5,1,2) of slice [choff, choff+c) written to the next three slices
-// (f16 != 0 in these three: the buffers hold _Float16 elements; cs / choff / c count elements, c % 8 == 0)
+// (f16 == 1 in these three: the buffers hold _Float16 elements; cs / choff / c count elements, c % 8 == 0;
+//  f16 == 2: h2 pairs in 16-channel groups, 4 bytes per channel, cs / choff / c count channels)
 hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16 = 0);
 // nearest x2 upsample of a slice into a slice of a buffer with twice the spatial size
 hipError_t launch_upsample2x(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
                              int c, int B, int H, int W, hipStream_t s, int f16 = 0);
+// fp32 NHWC -> h2 pairs (n_floats % 16 == 0: whole 16-channel groups)
+hipError_t launch_h2_encode(const float* in, float* out, long long n_floats, unsigned* ovf_flag, hipStream_t s);
 // MaxPool2d(2,2)
 hipError_t launch_maxpool2(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
                            int c, int B, int H, int W, hipStream_t s, int f16 = 0);
@@ -170,8 +183,9 @@ struct BallAssembleArgs {
     const uint8_t* median;   // [H][W][3] RGB, resized background
     const uint8_t* frames;   // ring [ring][H][W][3] RGB, resized frames
     const float* lut;        // [256] u8 -> float(double(u)/255)
-    float* out;              // [B][H][W][32] fp32
+    float* out;              // [B][H][W][32] fp32 (or h2 pairs: out_h2)
     int B, H, W, ring, first_slot;
+    int out_h2;              // 1: the TrackNet graph is an h2 graph (h2_common.h)
 };
 hipError_t launch_ball_assemble(const BallAssembleArgs& a, hipStream_t s);
 

@@ -7,12 +7,11 @@
 //                           MFMA-unfriendly and <1.5% of the FLOPs: plain VALU FMA)
 //   pool5_kernel          : MaxPool2d(5,1,2) on a channel slice (SPPF, chained 3x like upstream)
 //   upsample2x / maxpool2 : nearest x2 into a concat slice; MaxPool2d(2,2) (TrackNet models.py:60-64)
-#include "kernels.h"
+#include "h2_common.h"
 #include <algorithm>
 
 namespace padel {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // 16-byte vectors of the two activation types: 4 floats or 8 halves (pools / upsample work on whole vectors)
@@ -122,7 +121,8 @@ hipError_t launch_resample_pass(const ResamplePassArgs& a, hipStream_t s) {
 // Input values are u8 -> float(u8)/255 through a 256-entry LDS table (bit-identical to `im.float() /= 255`);
 // out-of-image taps contribute exact zeros.  The layer is HBM-write-bound (48-64 output floats per 4 input bytes):
 // round 1's VALU kernel needed 4.1 ms for the 64 x 1280^2 pose batch, the output alone is 1.0 ms at 5 TB/s.
-template <int NF, bool F16>
+// OM: output storage — 0 fp32, 1 fp16, 2 h2 pairs (h2_common.h)
+template <int NF, int OM>
 __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
     __shared__ float lut[256];
     lut[threadIdx.x] = (float)threadIdx.x / 255.0f;
@@ -151,6 +151,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
     const int ntiles = (P + 15) / 16;
     const int HoWo = a.Ho * a.Wo;
     const uint32_t* const img0 = reinterpret_cast<const uint32_t*>(a.in);
+    bool bad = false;
     for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
         const int p = tile * 16 + lr;
         const bool pv = p < P;
@@ -185,7 +186,13 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
                     v[r] = x / (1.0f + expf(-x));
                 }
                 const long long o = (long long)p * a.out_cs + a.out_choff + j * 16 + lq * 4;
-                if (F16) {
+                if (OM == 2) {
+                    h16x4 hv, mv;
+                    h2_encode4(v, hv, mv, bad);
+                    char* op = reinterpret_cast<char*>(a.out) + (long long)p * a.out_cs * 4 + h2_chan_off(a.out_choff + j * 16 + lq * 4);
+                    *reinterpret_cast<h16x4*>(op) = hv;
+                    *reinterpret_cast<h16x4*>(op + 32) = mv;
+                } else if (OM == 1) {
                     _Float16* oh = reinterpret_cast<_Float16*>(a.out) + o;
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     h4 hv;
@@ -198,12 +205,14 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
             }
         }
     }
+    if (OM == 2) h2_raise(a.ovf_flag, bad);
 }
 
 template <int NF>
 static void launch_stem_nf(const StemArgs& a, unsigned grid, hipStream_t s) {
-    if (a.out_f16) hipLaunchKernelGGL((stem_mfma_kernel<NF, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((stem_mfma_kernel<NF, false>), dim3(grid), dim3(256), 0, s, a);
+    if (a.out_f16 == 2) hipLaunchKernelGGL((stem_mfma_kernel<NF, 2>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.out_f16) hipLaunchKernelGGL((stem_mfma_kernel<NF, 1>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((stem_mfma_kernel<NF, 0>), dim3(grid), dim3(256), 0, s, a);
 }
 
 hipError_t launch_stem(const StemArgs& a_in, hipStream_t s) {
@@ -251,7 +260,104 @@ __global__ void __launch_bounds__(256) pool5_kernel(typename VecT<V>::E* buf, in
     *reinterpret_cast<V*>(buf + (((long long)n * H + y) * W + x) * cs + dst_off + c4 * VN) = m;
 }
 
+// ---- h2 buffers: a "unit" is 8 channels = 16 bytes of h + 16 bytes of m (32 bytes further) inside a 16-channel group.
+// Max-pooling compares the VALUES (h + m / 2048) and copies the winning pair: exact, nothing is re-encoded.
+struct H2Unit { h16x8 h, m; };
+__device__ __forceinline__ const char* h2_unit_ptr(const float* buf, long long pix, int cs, int choff, int u) {
+    const int c = choff + u * 8;
+    return reinterpret_cast<const char*>(buf) + pix * cs * 4 + (long long)(c >> 4) * 64 + (c & 15) * 2;
+}
+__device__ __forceinline__ H2Unit h2_load_unit(const char* p) {
+    return H2Unit{*reinterpret_cast<const h16x8*>(p), *reinterpret_cast<const h16x8*>(p + 32)};
+}
+__device__ __forceinline__ H2Unit h2_max_unit(const H2Unit a, const H2Unit b) {
+    H2Unit r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float va = fmaf((float)a.m[i], kH2InvScale, (float)a.h[i]), vb = fmaf((float)b.m[i], kH2InvScale, (float)b.h[i]);
+        const bool ta = va > vb;
+        r.h[i] = ta ? a.h[i] : b.h[i];
+        r.m[i] = ta ? a.m[i] : b.m[i];
+    }
+    return r;
+}
+__global__ void __launch_bounds__(256) pool5_h2_kernel(float* buf, int cs, int src_off, int dst_off, int un, int B, int H, int W) {
+    const long long total = (long long)B * H * W * un;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= total) return;
+    const int u = (int)(i % un);
+    long long t = i / un;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    H2Unit m = h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + y) * W + x, cs, src_off, u));
+    for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = y + dy;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int dx = -2; dx <= 2; ++dx) {
+            const int xx = x + dx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            m = h2_max_unit(h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + yy) * W + xx, cs, src_off, u)), m);
+        }
+    }
+    char* o = const_cast<char*>(h2_unit_ptr(buf, ((long long)n * H + y) * W + x, cs, dst_off, u));
+    *reinterpret_cast<h16x8*>(o) = m.h;
+    *reinterpret_cast<h16x8*>(o + 32) = m.m;
+}
+__global__ void __launch_bounds__(256) maxpool2_h2_kernel(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
+                                                           int un, int B, int H, int W) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long long total = (long long)B * Ho * Wo * un;
+    const long long i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= total) return;
+    const int u = (int)(i % un);
+    long long t = i / un;
+    const int x = (int)(t % Wo); t /= Wo;
+    const int y = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const long long p00 = ((long long)n * H + 2 * y) * W + 2 * x;
+    // same comparison order as vmax(vmax(a0, a1), vmax(b0, b1)) of the fp32 kernel
+    const H2Unit a0 = h2_load_unit(h2_unit_ptr(in, p00, in_cs, in_choff, u)), a1 = h2_load_unit(h2_unit_ptr(in, p00 + 1, in_cs, in_choff, u));
+    const H2Unit b0 = h2_load_unit(h2_unit_ptr(in, p00 + W, in_cs, in_choff, u)), b1 = h2_load_unit(h2_unit_ptr(in, p00 + W + 1, in_cs, in_choff, u));
+    const H2Unit m = h2_max_unit(h2_max_unit(a0, a1), h2_max_unit(b0, b1));
+    char* o = const_cast<char*>(h2_unit_ptr(out, ((long long)n * Ho + y) * Wo + x, out_cs, out_choff, u));
+    *reinterpret_cast<h16x8*>(o) = m.h;
+    *reinterpret_cast<h16x8*>(o + 32) = m.m;
+}
+// fp32 NHWC -> h2 pairs, whole 16-channel groups (the network input of a generic h2 graph, pa_tracknet_infer)
+__global__ void __launch_bounds__(256) h2_encode_kernel(const float* in, float* out, long long n4, unsigned* ovf) {
+    const long long i = blockIdx.x * 256ll + threadIdx.x;      // 4-channel piece
+    bool bad = false;
+    if (i < n4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(in + i * 4);
+        h16x4 hv, mv;
+        h2_encode4(v, hv, mv, bad);
+        char* op = reinterpret_cast<char*>(out) + (i >> 2) * 64 + (i & 3) * 8;
+        *reinterpret_cast<h16x4*>(op) = hv;
+        *reinterpret_cast<h16x4*>(op + 32) = mv;
+    }
+    h2_raise(ovf, bad);
+}
+hipError_t launch_h2_encode(const float* in, float* out, long long n_floats, unsigned* ovf_flag, hipStream_t s) {
+    if (n_floats & 15) return hipErrorInvalidValue;
+    const long long n4 = n_floats / 4;
+    hipLaunchKernelGGL(h2_encode_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, out, n4, ovf_flag);
+    return hipGetLastError();
+}
+
+// f16: storage type of the buffer — 0 fp32, 1 fp16, 2 h2 pairs
 hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16) {
+    if (f16 == 2) {
+        if ((c | choff) & 7) return hipErrorInvalidValue;
+        const long long total = (long long)B * H * W * (c / 8);
+        for (int k = 0; k < 3; ++k) {
+            hipLaunchKernelGGL(pool5_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf, cs, choff + k * c,
+                               choff + (k + 1) * c, c / 8, B, H, W);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
     const int vn = f16 ? 8 : 4;
     const long long total = (long long)B * H * W * (c / vn);
     const unsigned grid = (unsigned)((total + 255) / 256);
@@ -286,6 +392,10 @@ __global__ void __launch_bounds__(256) upsample2x_kernel(const typename VecT<V>:
 
 hipError_t launch_upsample2x(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
                              int c, int B, int H, int W, hipStream_t s, int f16) {
+    if (f16 == 2) {                    // h2: whole 16-channel groups are moved as bytes, like fp32
+        if ((c | in_choff | out_choff) & 15) return hipErrorInvalidValue;
+        f16 = 0;
+    }
     const int vn = f16 ? 8 : 4;
     const long long total = (long long)B * H * 2 * W * 2 * (c / vn);
     const dim3 grid((unsigned)((total + 255) / 256));
@@ -320,6 +430,13 @@ __global__ void __launch_bounds__(256) maxpool2_kernel(const typename VecT<V>::E
 
 hipError_t launch_maxpool2(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
                            int c, int B, int H, int W, hipStream_t s, int f16) {
+    if (f16 == 2) {
+        if ((c | in_choff | out_choff) & 7) return hipErrorInvalidValue;
+        const long long tot = (long long)B * (H / 2) * (W / 2) * (c / 8);
+        hipLaunchKernelGGL(maxpool2_h2_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, in, in_cs, in_choff, out, out_cs,
+                           out_choff, c / 8, B, H, W);
+        return hipGetLastError();
+    }
     const int vn = f16 ? 8 : 4;
     const long long total = (long long)B * (H / 2) * (W / 2) * (c / vn);
     const dim3 grid((unsigned)((total + 255) / 256));

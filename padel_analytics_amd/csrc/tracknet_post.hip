@@ -8,11 +8,9 @@
 //                          (ball_tracker.py:449-509, predict.py:184-189): out = sum_k c_k * Y[row0+k][slot 7-k]
 //                          (products rounded separately, summed in k order like torch's (rows*w).sum(0)),
 //                          or sum_k Y / div for the head / tail means; mask = out > 0.5.
-#include "kernels.h"
+#include "h2_common.h"
 
 namespace padel {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256) ball_assemble_kernel(const BallAssembleArgs a) {
     __shared__ float lut[256];
@@ -34,6 +32,19 @@ __global__ void __launch_bounds__(256) ball_assemble_kernel(const BallAssembleAr
     }
 #pragma unroll
     for (int c = 27; c < 32; ++c) v[c] = 0.0f;
+    if (a.out_h2) {                      // h2 graph: two 16-channel groups of fp16 pairs (values in [0, 1]: always in range)
+        bool bad = false;
+        char* ob = reinterpret_cast<char*>(a.out + i * 32);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            h16x4 hv, mv;
+            h2_encode4((f32x4){v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]}, hv, mv, bad);
+            char* op = ob + (c >> 2) * 64 + (c & 3) * 8;
+            *reinterpret_cast<h16x4*>(op) = hv;
+            *reinterpret_cast<h16x4*>(op + 32) = mv;
+        }
+        return;
+    }
     f32x4* o = reinterpret_cast<f32x4*>(a.out + i * 32);
 #pragma unroll
     for (int c = 0; c < 8; ++c) o[c] = (f32x4){v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};

@@ -44,6 +44,17 @@ def broadcast_array(arr: Optional[np.ndarray], shape: tuple, dtype, src: int = 0
     return t.cpu().numpy()
 
 
+def broadcast_flag(value: bool, src: int = 0) -> bool:
+    """A decision taken on `src` (e.g. "this tracker's predictions are already cached") that every rank must follow
+    before entering a collective path."""
+    import torch.distributed as dist
+    if world_size() == 1:
+        return bool(value)
+    box = [bool(value) if rank() == src else None]
+    dist.broadcast_object_list(box, src=src)
+    return bool(box[0])
+
+
 def share_unique_id(make_id) -> bytes:
     """RCCL bootstrap for ``Engine.comm_init``: rank 0 calls ``make_id()`` (``engine.comm_unique_id``), the 128
     bytes reach the other ranks through the process group's store (TCP, out of band of the data path)."""

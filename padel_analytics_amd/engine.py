@@ -27,6 +27,20 @@ class EngineError(RuntimeError):
     pass
 
 
+class RangeOverflow(EngineError):
+    """An activation of an h2 model (fp16 pairs, |x| <= 65504) did not fit: the results of that call are invalid and
+    the caller repeats it on the full-range fp32 (bf16x3) model (yolo.py / trackers/ball_tracker.py do)."""
+
+
+def fp32_mode() -> str:
+    """Arithmetic of the fp32-equivalent path: "h2" (default: fp16 pairs, three MFMA products, csrc/h2_common.h) or
+    "bx3" (exact bf16 triples, six products: full fp32 range, the fallback of the former).  PADEL_FP32_MODE overrides."""
+    m = os.environ.get("PADEL_FP32_MODE", "h2").lower()
+    if m not in ("h2", "bx3"):
+        raise ValueError(f"PADEL_FP32_MODE={m!r}: expected 'h2' or 'bx3'")
+    return m
+
+
 class pa_buf_desc(C.Structure):
     _fields_ = [("level", C.c_int32), ("channels", C.c_int32)]
 
@@ -68,6 +82,7 @@ ABI_SYMBOLS = [
     "pa_comm_unique_id", "pa_engine_comm_init", "pa_engine_comm_destroy", "pa_engine_bcast_weights",
     "pa_engine_bcast", "pa_engine_allreduce_max",
     "pa_bytetrack_create", "pa_bytetrack_destroy", "pa_bytetrack_reset", "pa_bytetrack_update_batch",
+    "pa_model_take_overflow",
 ]
 
 
@@ -136,7 +151,8 @@ def load_library():
     lib.pa_bytetrack_reset.argtypes = [vp]
     lib.pa_bytetrack_reset.restype = None
     lib.pa_bytetrack_update_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp]
-    if lib.pa_abi_version() != 2:
+    lib.pa_model_take_overflow.argtypes = [vp, C.POINTER(i32)]
+    if lib.pa_abi_version() != 3:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -316,6 +332,12 @@ class Model:
             self.handle, ptr, n, h, w, C.byref(p), boxes.ctypes.data,
             kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
         return boxes, kpts, counts
+
+    def take_overflow(self) -> bool:
+        """h2 models: True if an activation written since the last call did not fit the fp16 range (clears the flag)."""
+        v = C.c_int(0)
+        self.engine._check(self.engine.lib.pa_model_take_overflow(self.handle, C.byref(v)))
+        return bool(v.value)
 
     def read_head(self, level: int, n: int) -> np.ndarray:
         hh, ww, cc = C.c_int(), C.c_int(), C.c_int()

@@ -26,7 +26,7 @@ from . import yolo_arch
 OP_STEM, OP_CONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_MAXPOOL2 = 1, 2, 3, 4, 5
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
 TASK_DETECT, TASK_POSE, TASK_TRACKNET = 0, 1, 2
-DTYPE_F32, DTYPE_F16 = 0, 1
+DTYPE_F32, DTYPE_F16, DTYPE_H2 = 0, 1, 2
 
 
 def pad16(c: int) -> int:
@@ -115,6 +115,75 @@ def pack_conv_weight_bx3(w: np.ndarray) -> np.ndarray:
     return out
 
 
+# ---- "h2": fp32 values as PAIRS of fp16 numbers, x ~ h + m / 2048 (22-23 significant bits; csrc/h2_common.h) ----------
+# Activations of a DTYPE_H2 graph live in HBM in this form, 4 bytes per channel like fp32: per pixel and 16-channel GROUP
+# 64 bytes = [h of the 16 channels | m of the 16 channels].  The producer's epilogue encodes once; every consumer reads
+# ready-made fp16 MFMA operands and evaluates a * w with THREE products (ah*wh + (ah*wm + am*wh) / 2048) instead of the
+# six of the bf16x3 scheme.
+H2_MAX = 65504.0
+H2_RSCALE = 2048.0
+
+
+def h2_split(x: np.ndarray):
+    """fp32 array -> (h, m) float16 arrays with h = RN16(x), m = RN16((x - h) * 2048); |x| is clamped to the fp16 range
+    (the device encoder raises the model's overflow flag in that case, engine.py re-runs on the bf16x3 path)."""
+    xs = np.clip(np.asarray(x, np.float32), -H2_MAX, H2_MAX)
+    h = xs.astype(np.float16)
+    m = ((xs - h.astype(np.float32)) * np.float32(H2_RSCALE)).astype(np.float16)
+    return h, m
+
+
+def h2_value(h: np.ndarray, m: np.ndarray) -> np.ndarray:
+    """The fp32 value a pair stands for (exact: the two parts do not overlap)."""
+    return h.astype(np.float32) + m.astype(np.float32) * np.float32(1.0 / H2_RSCALE)
+
+
+def h2_encode_nhwc(x: np.ndarray) -> np.ndarray:
+    """(..., C) fp32 with C % 16 == 0 -> (..., C) uint32-sized words holding the group layout, returned as float32 view
+    of shape (..., C): per 16-channel group 16 h halves then 16 m halves."""
+    x = np.asarray(x, np.float32)
+    c = x.shape[-1]
+    assert c % 16 == 0
+    h, m = h2_split(x.reshape(x.shape[:-1] + (c // 16, 16)))
+    return np.ascontiguousarray(np.concatenate([h, m], axis=-1)).view(np.float32).reshape(x.shape)
+
+
+def h2_decode_nhwc(e: np.ndarray) -> np.ndarray:
+    e = np.ascontiguousarray(e, np.float32)
+    c = e.shape[-1]
+    hm = e.view(np.float16).reshape(e.shape[:-1] + (c // 16, 32))
+    return h2_value(hm[..., :16], hm[..., 16:]).reshape(e.shape)
+
+
+def h2_row_scale(w2d: np.ndarray) -> np.ndarray:
+    """Per output channel power of two s with max |w| * s in [2^12, 2^13): keeps both planes of a weight row in the
+    normal fp16 range whatever the magnitude of the folded weights; all-zero (padding) rows get 1."""
+    mx = np.abs(w2d).max(axis=1)
+    s = np.ones_like(mx, dtype=np.float32)
+    nz = mx > 0
+    s[nz] = np.exp2(12.0 - np.floor(np.log2(mx[nz].astype(np.float64)))).astype(np.float32)
+    return s
+
+
+def pack_conv_weight_h2(w: np.ndarray):
+    """(Cout, Cin, k, k) fp32, Cout % 16 == 0, Cin % 16 == 0 -> (uint16 [Cout][k-step][h|m][32], fp32 [Cout] = 1 / row
+    scale).  K-steps are ``bx3_ksteps`` (tap pairing for the 16-channel tail of a 3x3); the 32 slots of a step are in
+    natural order: an MFMA lane group q holds slots 8q..8q+7."""
+    cout, cin, k, _ = w.shape
+    assert cout % 16 == 0 and cin % 16 == 0
+    sc = h2_row_scale(w.reshape(cout, -1))
+    steps = bx3_ksteps(cin, k)
+    out = np.empty((cout, len(steps), 2, 32), np.uint16)
+    for s, slots in enumerate(steps):
+        blk = np.zeros((cout, 32), np.float32)
+        for i, sl in enumerate(slots):
+            if sl is not None:
+                blk[:, i] = w[:, sl[0], sl[1] // k, sl[1] % k]
+        h, m = h2_split(blk * sc[:, None])
+        out[:, s, 0], out[:, s, 1] = h.view(np.uint16), m.view(np.uint16)
+    return out, (1.0 / sc).astype(np.float32)
+
+
 def fold_bn(sd, prefix: str, eps: float):
     """Conv+BN fold in fp32, same operation order as ultralytics' fuse_conv_and_bn."""
     w = np.asarray(sd[f"{prefix}.conv.weight"], np.float32)
@@ -191,6 +260,10 @@ class Graph:
         w3_off = 0
         if self.dtype == DTYPE_F16:
             w_off = self._add(np.ascontiguousarray(pack_conv_weight(wp, 32).astype(np.float16)).view(np.float32))
+        elif self.dtype == DTYPE_H2:
+            planes, inv_scale = pack_conv_weight_h2(wp)
+            w_off = self._add(np.ascontiguousarray(planes).view(np.float32))
+            w3_off = self._add(inv_scale)         # `reserved` of an h2 conv: its per-output-channel 1 / row scale
         else:
             w_off = self._add(pack_conv_weight(wp))
             if self.bx3:            # the same weights pre-split for the bf16x3 kernels (engine tuning impl=2)
@@ -228,7 +301,7 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f
     c2h, c3h, c4h, nk = yolo_arch.head_dims(d, nc, kpt_shape)
     assert nk == info["nk"], (nk, info)
     g = Graph(task=TASK_POSE if kpt_shape else TASK_DETECT, nc=nc, nk=nk, kpt_dim=int(kpt_shape[1]) if kpt_shape else 0,
-              dtype={"f32": DTYPE_F32, "f16": DTYPE_F16}[dtype])
+              dtype={"f32": DTYPE_F32, "f16": DTYPE_F16, "h2": DTYPE_H2}[dtype])
     eps = yolo_arch.BN_EPS
     fuse = lambda p: fold_bn(sd, p, eps)
 
@@ -348,13 +421,13 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f
 TRACKNET_BN_EPS = 1e-5      # nn.BatchNorm2d default (reference models.py:9)
 
 
-def build_tracknet(sd) -> Graph:
+def build_tracknet(sd, dtype: str = "f32") -> Graph:
     """TrackNetV3 U-Net (reference ``trackers/ball_tracker/models.py:45-74``) over the engine's op set.
 
     Buffer 0 is the fp32 NHWC input with the 27 channels (background + 8 frames x RGB) zero-padded to 32.
     ``torch.cat([Upsample(x), skip])`` (:66,:68,:70) is a concat buffer whose first slice is written by the
     upsample op and whose second slice is written directly by the encoder block that produces the skip."""
-    g = Graph(task=TASK_TRACKNET)
+    g = Graph(task=TASK_TRACKNET, dtype={"f32": DTYPE_F32, "h2": DTYPE_H2}[dtype])
     in_dim = int(np.asarray(sd["down_block_1.conv_1.conv.weight"]).shape[1])
     out_dim = int(np.asarray(sd["predictor.weight"]).shape[0])
     cin0 = pad16(in_dim)

@@ -80,7 +80,9 @@ class BallTracker(Tracker):
         assert self.tracknet_seq_len == self.TRAJECTORY_LENGTH
         self.bg_mode = ck.param_dict.get("bg_mode", "concat")
         assert self.bg_mode == "concat", "only bg_mode='concat' (27 input channels) is wired, like the reference (:402,:443)"
-        self.graph = G.build_tracknet(ck.state_dict)
+        self._state_dict = ck.state_dict
+        self.fp32_mode = E.fp32_mode()           # "h2" (fp16 pairs, 3 products) or "bx3"; see yolo.YOLO
+        self.graph = G.build_tracknet(ck.state_dict, dtype="h2" if self.fp32_mode == "h2" else "f32")
         self.inpaintnet = None
         if inpainting_model_path:
             ick = checkpoint.load_checkpoint(inpainting_model_path)
@@ -209,6 +211,14 @@ class BallTracker(Tracker):
                 consume(sess.feed(np.stack(c), want_rects=True))
         consume(sess.feed(None, flush=True, want_rects=True))
         sess.close()
+        if self.graph.dtype == G.DTYPE_H2 and self._model.take_overflow():
+            # activations beyond the fp16 range: the stream has been consumed, so the caller (TrackingRunner) restarts
+            # this tracker; from now on it runs the full-range bf16x3 arithmetic
+            self._model.close()
+            self._model = None
+            self.fp32_mode = "bx3"
+            self.graph = G.build_tracknet(self._state_dict, dtype="f32")
+            raise E.RangeOverflow("TrackNet activations left the fp16 range: tracker switched to the bf16x3 path, run it again")
         if len(out) < n_fed:                       # fewer than 8 frames fed: no window, no detection (reference :688-696)
             out += [None] * (n_fed - len(out))
         return out[head_context:n_fed - tail_context]

@@ -42,6 +42,9 @@ class TrackingRunner:
         self.end = end
         self.video_info = video.VideoInfo.from_video_path(video_path)
         self.total_frames = self.video_info.total_frames if end is None else end - start
+        # frames actually available from `start` on (the reference reports the whole clip's length when end is None,
+        # runner.py:52; the sharded path must split what the generator really yields)
+        self.n_available = max(0, self.video_info.total_frames - start) if end is None else max(0, end - start)
         self.trackers = {}
         for tracker in trackers:
             self.trackers[str(tracker)] = tracker.video_info_post_init(self.video_info)
@@ -70,7 +73,10 @@ class TrackingRunner:
             self._run_fanout()
         else:
             for tracker in self.trackers.values():
-                if len(tracker) != 0:
+                # results (and the prediction caches) live on rank 0 only: its decision to skip a tracker is the one
+                # every rank follows, or the others would wait in the sharded path's collectives for ever
+                stored = D.broadcast_flag(len(tracker) != 0) if self.distributed else len(tracker) != 0
+                if stored:
                     print(f"{tracker.__str__()}: {len(tracker)} predictions stored")
                     continue
                 tracker.to(tracker.DEVICE)
@@ -79,13 +85,26 @@ class TrackingRunner:
                 if self.distributed:
                     self._predict_sharded(tracker)
                 else:
-                    tracker.predict_and_update(self._frames(), total_frames=self.total_frames)
+                    self._predict(tracker)
                 t1 = timeit.default_timer()
                 tracker.to("cpu")
                 self._report(tracker, t0, t1)
                 if not self.distributed or D.rank() == 0:
                     tracker.save_predictions()
         self.draw_and_collect_data()
+
+    def _predict(self, tracker: Tracker) -> None:
+        """One tracker over the whole clip.  A stream tracker on the h2 arithmetic whose activations left the fp16
+        range has switched itself to the full-range path and asks to be run again (engine.RangeOverflow); batch
+        trackers repeat the offending batch themselves (yolo.YOLO.infer_frames)."""
+        from .. import engine as E
+        try:
+            tracker.predict_and_update(self._frames(), total_frames=self.total_frames)
+        except E.RangeOverflow as ex:
+            print(f"{str(tracker)}: {ex}")
+            tracker.restart()
+            tracker.to(tracker.DEVICE)
+            tracker.predict_and_update(self._frames(), total_frames=self.total_frames)
 
     def _report(self, tracker, t0, t1) -> None:
         print(f"{str(tracker)}: {t1 - t0} inference time.")
@@ -97,7 +116,7 @@ class TrackingRunner:
     # ------------------------------------------------------------------ sharded over GPUs
     def _predict_sharded(self, tracker: Tracker) -> None:
         rank, world = D.rank(), D.world_size()
-        n = self.total_frames
+        n = self.n_available
         lo, hi = D.shard_range(n, rank, world)
         ch, ct = tracker.temporal_context
         head, tail = min(ch, lo), min(ct, n - hi)
@@ -118,7 +137,7 @@ class TrackingRunner:
             return
         med = None
         if D.rank() == 0:
-            nmed = min(tracker.median_max_sample_num, self.total_frames)
+            nmed = min(tracker.median_max_sample_num, self.n_available)
             med = tracker.compute_median(list(self._frames(0, nmed)))
         tracker.median = D.broadcast_array(med, (self.video_info.height, self.video_info.width, 3), np.uint8, src=0)
 
@@ -197,13 +216,12 @@ class TrackingRunner:
         # stream trackers (TrackNet needs the clip's background median before its first window): their own pass —
         # over the same HBM-resident handles when the clip lives in HBM, else a second read of the source
         for t in stream:
-            t.predict_and_update(self._frames(), total_frames=self.total_frames)
+            self._predict(t)
         t1 = timeit.default_timer()
         for t in todo:
             t.to("cpu")
             print(f"{t.__str__()}: {len(t.results)} predictions.")
-            self.timings[str(t)] = {"seconds": (t1 - t0) / len(todo), "frames": len(t)}
-            t.save_predictions()
+            t.save_predictions()       # (the trackers share every upload: only the combined time below is meaningful)
         self.timings["__fanout__"] = {"seconds": t1 - t0, "frames": self.total_frames}
         print(f"runner: fan-out pass {t1 - t0} inference time, {self.total_frames / max(t1 - t0, 1e-9):.1f} frames/s (all trackers)")
 

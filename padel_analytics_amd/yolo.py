@@ -65,10 +65,15 @@ class Results:
 
 
 class YOLO:
-    def __init__(self, model_path, engine: Optional[E.Engine] = None, half: bool = False):
+    def __init__(self, model_path, engine: Optional[E.Engine] = None, half: bool = False, fp32_mode: Optional[str] = None):
         """``half=True`` is upstream's ``predict(half=True)`` / ``model.half()``: fp16 activations and weights with
         fp32 accumulation (BASELINE configs[4]).  The reference leaves it False (players_tracker.py:351-359), and
-        only the fp32 path meets the parity bar; the fp16 path reports its own error."""
+        only the fp32 path meets the parity bar; the fp16 path reports its own error.
+
+        ``fp32_mode`` (``half=False`` only): "h2" — activations as fp16 pairs, three MFMA products per operand pair
+        (default, ``engine.fp32_mode()``); "bx3" — exact bf16 triples, six products.  An h2 model whose activations
+        leave the fp16 range (|x| > 65504) raises its overflow flag: the call is repeated on a bx3 model, which this
+        object then keeps using."""
         self.ckpt = checkpoint.load_checkpoint(model_path)
         if self.ckpt.task not in ("detect", "pose"):
             raise ValueError(f"{model_path}: not a YOLOv8 detect/pose checkpoint (task {self.ckpt.task})")
@@ -76,17 +81,32 @@ class YOLO:
         self.names = self.ckpt.names or {i: str(i) for i in range(self.ckpt.nc)}
         self.kpt_shape = self.ckpt.kpt_shape
         self.half = bool(half)
-        self.graph = G.build_yolov8(self.ckpt.state_dict, self.ckpt.nc, self.kpt_shape, dtype="f16" if self.half else "f32")
+        self.fp32_mode = fp32_mode or E.fp32_mode()
+        self.graph = G.build_yolov8(self.ckpt.state_dict, self.ckpt.nc, self.kpt_shape, dtype=self._graph_dtype())
         self._engine = engine
         self._model: Optional[E.Model] = None
         self.max_batch = 64
 
+    def _graph_dtype(self) -> str:
+        return "f16" if self.half else ("h2" if self.fp32_mode == "h2" else "f32")
+
+    def _rebuild(self) -> None:
+        self.close()
+        self.graph = G.build_yolov8(self.ckpt.state_dict, self.ckpt.nc, self.kpt_shape, dtype=self._graph_dtype())
+
     def set_half(self, half: bool) -> None:
         """Switch precision (rebuilds the packed graph; the HBM-resident model is re-created on next use)."""
         if bool(half) != self.half:
-            self.close()
             self.half = bool(half)
-            self.graph = G.build_yolov8(self.ckpt.state_dict, self.ckpt.nc, self.kpt_shape, dtype="f16" if self.half else "f32")
+            self._rebuild()
+
+    def set_fp32_mode(self, mode: str) -> None:
+        if mode not in ("h2", "bx3"):
+            raise ValueError(mode)
+        if mode != self.fp32_mode:
+            self.fp32_mode = mode
+            if not self.half:
+                self._rebuild()
 
     # ---- device placement ("cuda" == the HIP engine; there is no CPU execution path)
     def to(self, device) -> "YOLO":
@@ -165,10 +185,15 @@ class YOLO:
         else:
             src = frames if isinstance(frames, np.ndarray) else np.stack(list(frames))
             n, h, w, _ = src.shape
+        kw = dict(imgsz=int(imgsz), conf=float(conf), iou=float(iou), classes=classes, max_det=int(max_det),
+                  pre_mode=pre_mode, channel_reverse=channel_reverse, letterbox_auto=True)
         m = self._ensure_model()
-        boxes, kpts, counts = m.yolo_infer(src, n, h, w, imgsz=int(imgsz), conf=float(conf), iou=float(iou),
-                                           classes=classes, max_det=int(max_det), pre_mode=pre_mode,
-                                           channel_reverse=channel_reverse, letterbox_auto=True)
+        boxes, kpts, counts = m.yolo_infer(src, n, h, w, **kw)
+        if self.graph.dtype == G.DTYPE_H2 and m.take_overflow():
+            # an activation left the fp16 range: this checkpoint needs the full-range arithmetic from now on
+            print(f"padel_analytics_amd: activations beyond the fp16 range — switching this model to the bf16x3 path")
+            self.set_fp32_mode("bx3")
+            boxes, kpts, counts = self._ensure_model().yolo_infer(src, n, h, w, **kw)
         return boxes, kpts, counts, (h, w), int(imgsz), pre_mode
 
     def _run(self, frames: np.ndarray, conf, iou, imgsz, classes, max_det, pre_mode, reverse) -> list:

@@ -61,6 +61,7 @@ class FakeModel:
     def __init__(self, engine, graph, blob=None, **kw): self.max_batch = 64
     def set_max_batch(self, n): self.max_batch = int(n)
     def close(self): pass
+    def take_overflow(self): return False
 
 
 class FakeBallSession:

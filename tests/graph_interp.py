@@ -30,6 +30,29 @@ def unpack_conv(blob, o, f16: bool = False):
     return w, b
 
 
+def unpack_conv_h2(blob, o):
+    """Weights of a DTYPE_H2 conv back in (npad, cin, k, k) order, as the VALUE its fp16 pairs stand for:
+    (h + m / 2048) / row scale (csrc/h2_common.h); also returns the bias."""
+    k, cin, npad = o["ksize"], o["cin"], o["npad"]
+    steps = G.bx3_ksteps(cin, k)
+    n = npad * len(steps) * 64
+    planes = blob[o["w_off"]:o["w_off"] + n // 2].view(np.float16).reshape(npad, len(steps), 2, 32)
+    inv = blob[o["reserved"]:o["reserved"] + npad]
+    val = G.h2_value(planes[:, :, 0], planes[:, :, 1]) * inv[:, None, None]
+    w = np.zeros((npad, cin, k, k), np.float32)
+    for s, slots in enumerate(steps):
+        for i, sl in enumerate(slots):
+            if sl is not None:
+                w[:, sl[0], sl[1] // k, sl[1] % k] = val[:, s, i]
+    return w, blob[o["b_off"]:o["b_off"] + npad]
+
+
+def h2_round(x: torch.Tensor) -> torch.Tensor:
+    """What an h2 buffer holds after a value was stored in it: h + m / 2048 of the fp16 pair (22-23 bits)."""
+    h, m = G.h2_split(x.numpy())
+    return torch.from_numpy(G.h2_value(h, m))
+
+
 def act(x, a):
     if a == G.ACT_SILU:
         return F.silu(x)
@@ -48,17 +71,20 @@ def run(graph: G.Graph, net_in: torch.Tensor = None, buf0: torch.Tensor = None, 
     ref = net_in if net_in is not None else buf0
     B, _, H, W = ref.shape
     f16 = getattr(graph, "dtype", 0) == G.DTYPE_F16
+    h2 = getattr(graph, "dtype", 0) == G.DTYPE_H2
     heads = set(graph.head_buf)
     # fp16 graphs: what is written to a non-head buffer is rounded to fp16 (storage), arithmetic stays fp32 —
     # the engine's fp16 path up to the order of the fp32 accumulation.  `stale` fills the buffers first, to prove
     # that pad channels read under zero weights / never-written channels cannot leak into results.
     bufs = [torch.full((B, c, H >> l, W >> l), float(stale)) for (l, c) in graph.bufs]
     if buf0 is not None:
-        bufs[0][:] = buf0
+        bufs[0][:] = h2_round(buf0) if h2 else buf0
 
     def store(bi, lo, val):
         if f16 and bi not in heads:
             val = val.half().float()
+        if h2 and bi not in heads:
+            val = h2_round(val)
         bufs[bi][:, lo:lo + val.shape[1]] = val
 
     for o in graph.ops:
@@ -68,7 +94,7 @@ def run(graph: G.Graph, net_in: torch.Tensor = None, buf0: torch.Tensor = None, 
             b = torch.from_numpy(blob[o["b_off"]:o["b_off"] + o["cout"]].copy())
             store(o["out_buf"], o["out_choff"], F.silu(F.conv2d(net_in, w, b, stride=2, padding=1)))
         elif kd == G.OP_CONV:
-            w, b = unpack_conv(blob, o, f16)
+            w, b = unpack_conv_h2(blob, o) if h2 else unpack_conv(blob, o, f16)
             x = bufs[o["in_buf"]][:, o["in_choff"]:o["in_choff"] + o["cin"]]
             y = act(F.conv2d(x, torch.from_numpy(w), torch.from_numpy(b.copy()), stride=o["stride"], padding=o["ksize"] // 2), o["act"])
             y = y[:, :o["cout"]]
