@@ -40,6 +40,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_m
 PEAK_FP16_MFMA_TFLOPS = 2500.0     # same guide: BF16/FP16 MFMA, dense (not the 2:1-sparsity headline)
 # default fp32 path = bf16x3 kernels: every fp32 multiply costs 6 bf16 products on the bf16 pipe
 PEAK_BX3_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 6.0, 1)
+# h2 path (default since round 3): activations as fp16 pairs, every fp32 multiply costs 3 f16 products on the same pipe
+PEAK_H2_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 3.0, 1)
+PEAK_BY_IMPL = {"h2": PEAK_H2_TFLOPS, "bx3": PEAK_BX3_TFLOPS, "tap": PEAK_FP32_MFMA_TFLOPS, "lds": PEAK_FP32_MFMA_TFLOPS}
 
 # tracker table: name -> (scale, nc, kpt_shape, imgsz, conf, classes, pre_mode, channel_reverse)
 TRACKERS = {
@@ -83,9 +86,10 @@ def parse():
                     help="also time the runner with the clip in pageable host memory: sequential (one upload per "
                          "tracker, like the reference) and fan-out (one upload per batch) — PCIe-inclusive rates")
     ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the op lists (tuning; -1 = engine default)")
-    ap.add_argument("--impl", default="bx3", choices=["bx3", "tap", "lds"],
-                    help="fp32 conv kernels: bx3 (default: exact 3-way bf16 split, 6 products on the bf16 matrix pipe, fp32 "
-                         "accumulate), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
+    ap.add_argument("--impl", default="h2", choices=["h2", "bx3", "tap", "lds"],
+                    help="fp32-equivalent conv arithmetic: h2 (default: activations as fp16 pairs, 3 products on the f16 matrix "
+                         "pipe, corrections in their own accumulator), bx3 (exact 3-way bf16 split, 6 products; the full-range "
+                         "fallback of h2), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
     ap.add_argument("--no-tight", action="store_true", help="skip the low-noise-head parity leg of the CPU baseline section")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the parity path (the reference runs half=False) — the headline; f16: fp16 activations / "
@@ -150,7 +154,7 @@ def parity_low_noise_heads(eng, names, frames, sample, H, W, ref, parity):
         r32 = ref.predict(ref.YoloV8Ref(sd, cfg["nc"], cfg["kpt"]), srcs, cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
         r64 = ref.predict(ref.YoloV8Ref(sd, cfg["nc"], cfg["kpt"], dtype=torch.float64), srcs, cfg["conf"], 0.7,
                           cfg["imgsz"], cfg["classes"])
-        m = E.Model(eng, G.build_yolov8(sd, cfg["nc"], cfg["kpt"]))
+        m = E.Model(eng, G.build_yolov8(sd, cfg["nc"], cfg["kpt"], dtype=E.graph_dtype()))
         m.set_max_batch(ns)
         boxes, kpts, counts = m.yolo_infer(np.ascontiguousarray(sample), ns, H, W, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7,
                                            classes=cfg["classes"],
@@ -268,10 +272,11 @@ def main():
         a.height, a.width, a.dtype = 1080, 1920, "f16"
     H, W, B, K, Wm = a.height, a.width, a.batch, a.steps, a.warmup
 
+    os.environ["PADEL_FP32_MODE"] = "h2" if a.impl == "h2" else "bx3"      # what the tracker classes build their graphs for
     eng = E.Engine(local)
     if a.graph >= 0:
         eng.set_tuning(graph=a.graph)
-    IMPL = {"tap": 0, "lds": 1, "bx3": 2}
+    IMPL = {"tap": 0, "lds": 1, "bx3": 2, "h2": 2}
     eng.set_tuning(impl=IMPL[a.impl])
     # RCCL communicator owned by the library (also with one rank: the broadcast path is exercised at N=1)
     eng.comm_init(D.share_unique_id(E.comm_unique_id), world, rank)
@@ -314,7 +319,12 @@ def main():
         "metric": "frames/sec (all trackers) on 1280x720", "value": None, "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": None,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-        "arithmetic": ("fp32 storage; conv products as an EXACT 3-way bf16 split of both operands, 6 of the 9 cross "
+        "arithmetic": ("fp32-equivalent: every activation is an fp16 PAIR x ~ h + m/2048 (22-23 significant bits, 4 bytes per "
+                       "channel) written once by its producer, weights pre-split the same way per scaled row; a product is "
+                       "ah*wh + (ah*wm + am*wh)/2048 = 3 x v_mfma_f32_16x16x32_f16 with the corrections in their own fp32 "
+                       "accumulator — per-conv RMS error vs fp64 <= 1.25 x the fp32-MFMA kernels' (tests/test_gpu_h2.py), same "
+                       "parity criteria; |x| > 65504 raises a flag and the call repeats on the bf16x3 kernels" if a.impl == "h2" else
+                       "fp32 storage; conv products as an EXACT 3-way bf16 split of both operands, 6 of the 9 cross "
                        "products (dropped: < 2^-24 relative) on v_mfma_f32_16x16x32_bf16, fp32 accumulation — per-conv RMS "
                        "error vs fp64 <= the fp32-MFMA kernels' (tests/test_gpu_conv.py), same parity criteria" if a.impl == "bx3"
                        else "fp32 storage, v_mfma_f32_16x16x4_f32 (fp32 in, fp32 accumulate)") if a.dtype == "f32"
@@ -402,7 +412,7 @@ def main():
         ms1, fl1 = sum(r["ms"] for r in c1), sum(r["flops"] for r in c1)
         ms_all = sum(r["ms"] for r in recs)
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
-        PEAK = PEAK_FP16_MFMA_TFLOPS if a.dtype == "f16" else (PEAK_BX3_TFLOPS if a.impl == "bx3" else PEAK_FP32_MFMA_TFLOPS)
+        PEAK = PEAK_FP16_MFMA_TFLOPS if a.dtype == "f16" else PEAK_BY_IMPL[a.impl]
         traffic = None
         tpath = ROOT / "profiles" / "r2_traffic.json"          # PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc_bench_traffic.sh)
         if tpath.exists():
@@ -414,11 +424,17 @@ def main():
         out["roofline"] = {
             "kernel": ("conv_tap16_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x32_f16)"
                        if a.dtype == "f16" else
+                       "conv_h2p_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch of fp16-pair activations staged once per "
+                       "32-channel chunk as h / m planes in LDS, 9 shifted-window taps) + conv_h2_kernel<...> (stride-2 3x3: "
+                       "LDS-DMA ring); 3 x v_mfma_f32_16x16x32_f16 per 16x16x32 block, output encoded to pairs in the epilogue"
+                       if a.impl == "h2" else
                        "conv_bx3p_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch split once per 32-channel chunk into "
                        "bf16 hi/mid/lo planes in LDS, 9 shifted-window taps) + conv_bx3_kernel<...> (stride-2 3x3: LDS-DMA ring, "
                        "split in registers); exact bf16x3, 6 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block" if a.impl == "bx3" else
                        "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)"),
-            "peak_note": ("fp32-equivalent TFLOP/s: bf16 MFMA dense peak 2500 / 6 products per multiply; the fp32-input MFMA "
+            "peak_note": ("fp32-equivalent TFLOP/s: f16 MFMA dense peak 2500 / 3 products per multiply (round 2's bf16x3 kernels: "
+                          "/ 6 = 416.7; fp32-input MFMA: 157.3); matrix-pipe utilisation = frac" if (a.dtype == "f32" and a.impl == "h2") else
+                          "fp32-equivalent TFLOP/s: bf16 MFMA dense peak 2500 / 6 products per multiply; the fp32-input MFMA "
                           "peak this replaces is 157.3" if (a.dtype == "f32" and a.impl == "bx3") else None),
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
             "frac": round(ach / PEAK, 4), "traffic": traffic if a.dtype == "f32" else None,

@@ -158,6 +158,11 @@ def load_library():
     return lib
 
 
+def graph_dtype(mode: Optional[str] = None) -> str:
+    """graph.build_yolov8 / build_tracknet ``dtype`` of the fp32-equivalent path in arithmetic ``mode`` (default: fp32_mode())."""
+    return {"h2": "h2", "bx3": "f32"}[mode or fp32_mode()]
+
+
 class DeviceBuffer:
     """Raw HBM allocation owned by an Engine (bench keeps frame batches resident with it).  ``view(off, n)``
     gives a non-owning window of the same memory (a batch of frames inside a resident clip)."""

@@ -41,7 +41,7 @@ def test_ball_session_matches_oracle(gpu_engine, T, feed):
     sd = _calibrated_tracknet(frames)
     net = tr.TrackNetRef(sd)
     x_ref, y_ref, v_ref, heat_ref = br.track(frames, net.forward, batch=4)
-    m = E.Model(gpu_engine, G.build_tracknet(sd))
+    m = E.Model(gpu_engine, G.build_tracknet(sd, dtype=E.graph_dtype()))
     m.set_max_batch(feed)
     sess = E.BallSession(m, 360, 640)
     sess.set_background(np.median(np.array([f[..., ::-1] for f in frames]), 0).astype("uint8"))
@@ -70,7 +70,7 @@ def test_ball_locate_kernel_synthetic_masks(gpu_engine):
     """Connected-component pick on crafted masks: empty, single blob, diagonal (8-connectivity) links, equal-area
     ties (the component discovered last in raster order wins), a snake, blobs touching the borders, random
     speckle — against the oracle's predict_location."""
-    m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1)))
+    m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1), dtype=E.graph_dtype()))
     m.set_max_batch(8)
     sess = E.BallSession(m, 360, 640)
     rng = np.random.default_rng(0)
@@ -103,7 +103,7 @@ def test_ball_locate_kernel_synthetic_masks(gpu_engine):
 
 @pytest.mark.parametrize("n", [1, 2, 7, 16])
 def test_device_median_matches_numpy(gpu_engine, n):
-    m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1)))
+    m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1), dtype=E.graph_dtype()))
     m.set_max_batch(4)
     sess = E.BallSession(m, 90, 160)
     rng = np.random.default_rng(n)

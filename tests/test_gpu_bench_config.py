@@ -28,10 +28,10 @@ def frames64():
     return synth.synthetic_frames(64, 720, 1280, seed=1000)        # bench.py's rank-0 shard
 
 
-def _model(eng, name, frames, batch):
+def _model(eng, name, frames, batch, mode=None):
     cfg = bench.TRACKERS[name]
     sd = bench.make_state_dict(name, cfg, frames)
-    m = E.Model(eng, G.build_yolov8(sd, cfg["nc"], cfg["kpt"]))
+    m = E.Model(eng, G.build_yolov8(sd, cfg["nc"], cfg["kpt"], dtype=E.graph_dtype(mode)))
     m.set_max_batch(batch)
     return cfg, sd, m
 
@@ -42,12 +42,13 @@ def _infer(m, cfg, frames):
                         pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg["rev"])
 
 
-def test_pose_m_1280_parity(gpu_engine, frames64):
-    cfg, sd, m = _model(gpu_engine, "pose", frames64, 2)
+@pytest.mark.parametrize("mode", ["h2", "bx3"])
+def test_pose_m_1280_parity(gpu_engine, frames64, mode):
+    cfg, sd, m = _model(gpu_engine, "pose", frames64, 2, mode)
     got = _infer(m, cfg, frames64[:2])
     m.close()
     srcs = bench.source_for_oracle(cfg, frames64[:2])
-    _check("pose-m-1280-13x3 (bench graph)", sd, 1, (13, 3), srcs, got, cfg["conf"], 0.7, 1280)
+    _check(f"pose-m-1280-13x3 (bench graph) [{mode}]", sd, 1, (13, 3), srcs, got, cfg["conf"], 0.7, 1280)
 
 
 def test_ball_nc1_detect_parity_and_ball_mapping(gpu_engine, frames64, tmp_path):

@@ -1,0 +1,231 @@
+"""GPU unit tests of the h2 arithmetic (csrc/h2_common.h): activations as fp16 pairs x ~ h + m / 2048 written by the
+producer, three f16 MFMA products per operand pair, correction products in their own accumulator.
+
+* every tile of the tap kernels (conv_tap_h2.hip) and of the patch kernel (conv_patch_h2.hip) on the conv shapes of
+  tests/test_gpu_conv.py against torch conv2d in fp64 ON THE ORIGINAL fp32 OPERANDS — the bound (L-inf 3e-6 relative)
+  and the admission criterion (RMS error <= 1.25 x the fp32-MFMA kernels') are the ones the bf16x3 kernels were
+  admitted under, and they include what the 22-23-bit operand representation costs;
+* bitwise equality among the tiles that share the accumulation scheme;
+* values far below the fp16 normal range (the MFMA must not flush fp16 subnormals), the overflow flag, the absorbed
+  upsample, the helper kernels (SPPF pools, MaxPool2d(2, 2), upsample) — exact on pairs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from padel_analytics_amd import engine as E, graph as G
+from tests.test_gpu_conv import CASES
+
+pytestmark = pytest.mark.gpu
+
+H2_TILES = (207, 209, 211, 213, 220, 225, 303, 304, 306)
+H2_SINGLE_LEVEL = (306,)        # patch tile with 6 fragments: main product accumulated in one level (registers)
+
+
+def _graph(case, w, b, wr, dtype):
+    B, H, W, cin, cout, k, s, act, use_res = case
+    g = G.Graph(task=G.TASK_TRACKNET, dtype=dtype)
+    b0 = g.buf(0, cin)
+    lvl = 1 if s == 2 else 0
+    res = None
+    if use_res:
+        b2 = g.buf(lvl, G.pad16(cout))
+        g.conv((b0, 0, cin), (b2, 0), wr, np.zeros(cout, np.float32), 1, s, G.ACT_NONE)
+        res = (b2, 0)
+    b1 = g.buf(lvl, G.pad16(cout))
+    g.conv((b0, 0, cin), (b1, 0), w, b, k, s, act, res=res)
+    g.head_buf = (b1, -1, -1)          # head buffer: written as plain fp32
+    return g
+
+
+def _run(eng, case, x, w, b, wr, dtype=G.DTYPE_H2, want_flag=False):
+    m = E.Model(eng, _graph(case, w, b, wr, dtype))
+    m.set_max_batch(case[0])
+    y = m.tracknet_infer(x)[..., :case[4]]
+    flag = m.take_overflow()
+    m.close()
+    return (y, flag) if want_flag else y
+
+
+def _data(case, xscale=1.0, wscale=1.0):
+    B, H, W, cin, cout, k, s, act, use_res = case
+    rng = np.random.default_rng(cin * 131 + cout)
+    x = (rng.normal(0, 1, (B, H, W, cin)) * xscale).astype(np.float32)
+    w = (rng.normal(0, (2.0 / (cin * k * k)) ** 0.5, (cout, cin, k, k)) * wscale).astype(np.float32)
+    b = (rng.normal(0, 0.5, cout) * xscale * wscale).astype(np.float32)
+    wr = (rng.normal(0, (1.0 / cin) ** 0.5, (cout, cin, 1, 1)) * wscale).astype(np.float32)
+    return x, w, b, wr
+
+
+def _want(case, x, w, b, wr):
+    B, H, W, cin, cout, k, s, act, use_res = case
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double()
+    want = F.conv2d(xt, torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=s, padding=k // 2)
+    want = {G.ACT_SILU: F.silu, G.ACT_RELU: F.relu, G.ACT_SIGMOID: torch.sigmoid, G.ACT_NONE: lambda t: t}[act](want)
+    if use_res:
+        want = want + F.conv2d(xt, torch.from_numpy(wr).double(), stride=s)
+    return want.permute(0, 2, 3, 1).numpy()
+
+
+@pytest.mark.parametrize("case", CASES, ids=[f"c{i}" for i in range(len(CASES))])
+def test_h2_conv_variants(gpu_engine, case):
+    x, w, b, wr = _data(case)
+    want = _want(case, x, w, b, wr)
+    scale = max(1.0, float(np.abs(want).max()))
+    outs = {}
+    try:
+        for v in H2_TILES:
+            gpu_engine.set_tuning(variant=v)
+            for rep in range(2):                       # LDS-DMA ring: a DMA / barrier race is not deterministic
+                outs[f"H{v}.{rep}"] = _run(gpu_engine, case, x, w, b, wr)
+        gpu_engine.set_tuning(variant=-1)
+        outs["H.auto"] = _run(gpu_engine, case, x, w, b, wr)
+        gpu_engine.set_tuning(alias=0)
+        outs["H.auto.noalias"] = _run(gpu_engine, case, x, w, b, wr)
+        gpu_engine.set_tuning(impl=0, variant=-1, alias=1)
+        y32 = _run(gpu_engine, case, x, w, b, wr, dtype=G.DTYPE_F32)           # fp32-input MFMA kernels
+        gpu_engine.set_tuning(impl=2)
+        y3 = _run(gpu_engine, case, x, w, b, wr, dtype=G.DTYPE_F32)            # bf16x3
+    finally:
+        gpu_engine.set_tuning(impl=2, variant=-1, alias=1)
+    k, cin = case[5], case[3]
+    patch_applies = k == 3 and case[6] == 1
+    ref_name, ref = "H220.0", outs["H220.0"]
+    for name, y in outs.items():
+        assert y.shape == want.shape
+        err = float(np.abs(y - want).max()) / scale
+        assert err < 3e-6, f"{name}: rel err {err:.2e} vs fp64 conv2d"
+        single = patch_applies and any(name.startswith(f"H{v}.") for v in H2_SINGLE_LEVEL)
+        if not single:
+            assert np.array_equal(y, ref), f"{name} differs bitwise from {ref_name} (max {np.abs(y - ref).max():.3e})"
+    rms = lambda y: float(np.sqrt(np.mean((y - want) ** 2)))
+    print(f"case {case}: RMS error vs fp64  fp32-MFMA {rms(y32):.3e}  bf16x3 {rms(y3):.3e}  h2 {rms(ref):.3e}  h2 single-level {rms(outs['H306.0']):.3e}")
+    assert rms(ref) <= 1.25 * rms(y32) + 1e-9, (rms(ref), rms(y32))
+    assert rms(outs["H306.0"]) <= 1.25 * rms(y32) + 1e-9, (rms(outs["H306.0"]), rms(y32))
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-4, 1.0), (3e-6, 1e-3), (200.0, 1e-5), (1.0, 64.0)], ids=["tiny-x", "tiny-x-w", "big-x-tiny-w", "big-w"])
+def test_h2_dynamic_range(gpu_engine, xs, ws):
+    """fp16 subnormal parts (|x| < 6.1e-5: h is subnormal or 0, m carries the value) must survive the MFMA, and the
+    per-row weight scale must keep tiny / large weights exact: same relative error as at unit scale."""
+    case = (2, 24, 40, 32, 64, 3, 1, G.ACT_NONE, False)
+    x, w, b, wr = _data(case, xs, ws)
+    want = _want(case, x, w, b, wr)
+    scale = float(np.abs(want).max())
+    for v in (220, 303):
+        gpu_engine.set_tuning(variant=v)
+        try:
+            y, flag = _run(gpu_engine, case, x, w, b, wr, want_flag=True)
+        finally:
+            gpu_engine.set_tuning(variant=-1)
+        assert not flag
+        err = float(np.abs(y - want).max()) / scale
+        print(f"x scale {xs} w scale {ws} tile {v}: rel err {err:.2e}")
+        assert err < 2e-5 if xs < 1e-5 else err < 3e-6, f"tile {v}: rel err {err:.2e}"
+
+
+def test_h2_overflow_flag(gpu_engine):
+    """|x| > 65504 cannot be an fp16 pair: the encoder clamps, the model's flag goes up once and is cleared by the read."""
+    case = (1, 16, 24, 32, 32, 3, 1, G.ACT_NONE, False)
+    x, w, b, wr = _data(case)
+    g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2)
+    b0 = g.buf(0, 32)
+    mid = g.buf(0, 32)
+    out = g.buf(0, 32)
+    g.conv((b0, 0, 32), (mid, 0), (w * 3e4).astype(np.float32), b, 3, 1, G.ACT_NONE)     # outputs ~ 1e5: do not fit
+    g.conv((mid, 0, 32), (out, 0), w, b, 3, 1, G.ACT_NONE)
+    g.head_buf = (out, -1, -1)
+    m = E.Model(gpu_engine, g)
+    m.set_max_batch(1)
+    y = m.tracknet_infer(x)
+    assert np.isfinite(y).all()
+    assert m.take_overflow() and not m.take_overflow()
+    y2 = m.tracknet_infer((x * 1e-3).astype(np.float32))
+    assert np.isfinite(y2).all() and not m.take_overflow()
+    xin = x.copy()
+    xin[0, 3, 5, 7] = 1e6                                                               # the input encoder raises it too
+    m.tracknet_infer(xin)
+    assert m.take_overflow()
+    m.close()
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 40, 64, 32, 80, 1), (1, 18, 28, 32, 48, 96, 1),
+                                   (2, 24, 48, 64, 32, 80, 3), (1, 16, 32, 32, 96, 48, 3)],
+                         ids=["up64+32", "up32+48", "3x3-up64+32", "3x3-up32+96"])
+def test_h2_upsample_absorbed(gpu_engine, shape):
+    """Upsample(2) + cat in front of a stride-1 conv read from the coarse map (h2 1x1 tap kernel, 3x3 patch kernel):
+    bitwise equal to running the upsample kernel."""
+    B, H, W, c_up, c_skip, cout, k = shape
+    rng = np.random.default_rng(c_up * 7 + c_skip + k)
+    cin0 = 32
+    x = rng.normal(0, 1, (B, H, W, cin0)).astype(np.float32)
+    w_dn = rng.normal(0, (2.0 / (cin0 * 9)) ** 0.5, (c_up, cin0, 3, 3)).astype(np.float32)
+    w_sk = rng.normal(0, (2.0 / cin0) ** 0.5, (c_skip, cin0, 1, 1)).astype(np.float32)
+    w = rng.normal(0, (2.0 / ((c_up + c_skip) * k * k)) ** 0.5, (cout, c_up + c_skip, k, k)).astype(np.float32)
+    b = rng.normal(0, 0.5, cout).astype(np.float32)
+
+    def run(**tuning):
+        g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2)
+        b0 = g.buf(0, cin0)
+        coarse = g.buf(1, c_up)
+        cat = g.buf(0, c_up + c_skip)
+        out = g.buf(0, G.pad16(cout))
+        g.conv((b0, 0, cin0), (coarse, 0), w_dn, np.zeros(c_up, np.float32), 3, 2, G.ACT_SILU)
+        g.ops.append(dict(kind=G.OP_UPSAMPLE2X, in_buf=coarse, in_choff=0, cin=c_up, out_buf=cat, out_choff=0, cout=c_up,
+                          ksize=0, stride=0, act=0, res_buf=-1, res_choff=0, npad=0, w_off=0, b_off=0))
+        g.conv((b0, 0, cin0), (cat, c_up), w_sk, np.zeros(c_skip, np.float32), 1, 1, G.ACT_NONE)
+        g.conv((cat, 0, c_up + c_skip), (out, 0), w, b, k, 1, G.ACT_SILU)
+        g.head_buf = (out, -1, -1)
+        gpu_engine.set_tuning(**tuning)
+        gpu_engine.set_profiling(True)
+        m = E.Model(gpu_engine, g)
+        m.set_max_batch(B)
+        y = m.tracknet_infer(x)[..., :cout]
+        n_up = sum(1 for r in m.profile_rows() if r["kind"] == G.OP_UPSAMPLE2X)
+        m.close()
+        gpu_engine.set_profiling(False)
+        return y, n_up
+
+    absorbing = (220, 209, 213, 207) if k == 1 else (303, 304, 306)
+    keeping = () if k == 1 else (220,)
+    try:
+        ref, n_up = run(variant=220 if k == 1 else 303, fold_up=0)
+        assert n_up == 1
+        for v in absorbing + keeping:
+            y, n_up = run(variant=v, fold_up=1)
+            assert n_up == (0 if v in absorbing else 1), f"variant {v}: {n_up} upsample launches"
+            if v in H2_SINGLE_LEVEL:
+                assert float(np.abs(y - ref).max()) < 2e-6 * max(1.0, float(np.abs(ref).max()))
+            else:
+                assert np.array_equal(y, ref), f"variant {v}: absorbed upsample differs (max {np.abs(y - ref).max():.3e})"
+    finally:
+        gpu_engine.set_tuning(variant=-1, fold_up=1)
+
+
+def test_h2_helper_kernels(gpu_engine):
+    """MaxPool2d(2,2), the (unabsorbed) upsample and the SPPF pools on h2 buffers: the winning PAIR is copied, so the
+    result is exactly the pooling of the values the pairs stand for."""
+    B, H, W, c = 2, 24, 40, 32
+    rng = np.random.default_rng(5)
+    x = rng.normal(0, 3, (B, H, W, c)).astype(np.float32)
+    xr = G.h2_decode_nhwc(G.h2_encode_nhwc(x))                       # what the input buffer holds
+    g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2)
+    b0 = g.buf(0, c)
+    small = g.buf(1, c)
+    cat = g.buf(0, 4 * c)
+    op = lambda kind, src, dst, cin, cout, k, s: dict(kind=kind, in_buf=src[0], in_choff=src[1], cin=cin, out_buf=dst[0], out_choff=dst[1],
+                                                      cout=cout, ksize=k, stride=s, act=0, res_buf=-1, res_choff=0, npad=0, w_off=0, b_off=0)
+    g.ops.append(op(G.OP_MAXPOOL2, (b0, 0), (small, 0), c, c, 2, 2))
+    g.ops.append(op(G.OP_UPSAMPLE2X, (small, 0), (cat, 0), c, c, 0, 0))          # its reader is a pool: never absorbed
+    g.ops.append(op(G.OP_SPPF_POOL, (cat, 0), (cat, c), c, 3 * c, 5, 1))
+    g.head_buf = (cat, -1, -1)                                        # read back raw: the pools wrote PAIRS into it
+    m = E.Model(gpu_engine, g)
+    m.set_max_batch(B)
+    got = G.h2_decode_nhwc(m.tracknet_infer(x))
+    m.close()
+    t = torch.from_numpy(xr).permute(0, 3, 1, 2)
+    ys = [F.interpolate(F.max_pool2d(t, 2, 2), scale_factor=2.0, mode="nearest")]
+    for _ in range(3):
+        ys.append(F.max_pool2d(ys[-1], 5, 1, 2))
+    want = torch.cat(ys, 1).permute(0, 2, 3, 1).numpy()
+    assert np.array_equal(got, want), float(np.abs(got - want).max())

@@ -44,8 +44,11 @@ def _calib(scale, nc, kpt, srcs, imgsz, conf, seed, dfl_scale=1.0, kpt_scale=1.0
     return sd
 
 
-def _engine_predict(eng, sd, nc, kpt, frames, **kw):
-    m = E.Model(eng, G.build_yolov8(sd, nc, kpt))
+MODES = ("h2", "bx3")      # arithmetic of the fp32-equivalent path (engine.fp32_mode): fp16 pairs / exact bf16 triples
+
+
+def _engine_predict(eng, sd, nc, kpt, frames, mode=None, **kw):
+    m = E.Model(eng, G.build_yolov8(sd, nc, kpt, dtype=E.graph_dtype(mode)))
     m.set_max_batch(max(1, min(8, len(frames))))
     n, h, w, _ = frames.shape
     return m, m.yolo_infer(frames, n, h, w, **kw)
@@ -117,16 +120,17 @@ def test_detect_parity(gpu_engine, scale, hw, nf):
     m.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("scale", ["n", "m"])
-def test_detect_parity_tight(gpu_engine, scale):
+def test_detect_parity_tight(gpu_engine, scale, mode):
     """The literal north_star bar (<= 1e-3 px vs the fp32 CPU oracle AND vs fp64) on a head whose own
     fp32 noise floor is below it: DFL logits scaled by 0.02 -> near-uniform bin distributions.  scale m at 720p is
     the bench's players graph."""
     frames = synth.synthetic_frames(3, 720, 1280, seed=13)
     srcs = [f[..., ::-1] for f in frames]
     sd = _calib(scale, 80, None, srcs, 640, 0.5, seed=17, dfl_scale=0.02)
-    m, got = _engine_predict(gpu_engine, sd, 80, None, frames, imgsz=640, conf=0.5, iou=0.7, classes=[0])
-    _check("detect-n-tight" if scale == "n" else f"detect-{scale}-tight", sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
+    m, got = _engine_predict(gpu_engine, sd, 80, None, frames, mode=mode, imgsz=640, conf=0.5, iou=0.7, classes=[0])
+    _check(f"detect-{scale}-tight [{mode}]", sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
     m.close()
 
 
@@ -145,8 +149,9 @@ def test_pose_parity(gpu_engine, scale, S, kpt):
     m.close()
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("scale,S,f", [("n", 640, 0.02), ("m", 1280, 0.004)], ids=["n-640", "m-1280-bench-graph"])
-def test_pose_parity_tight(gpu_engine, scale, S, f):
+def test_pose_parity_tight(gpu_engine, scale, S, f, mode):
     """The literal <= 1e-3 px bar for boxes AND the 13 keypoints, vs the fp32 CPU oracle and vs fp64, on pose heads
     whose own fp32 noise floor is at the ulp of the coordinates (2.4e-4 px, measured on CPU): last conv of the DFL and
     of the keypoint branch scaled by f.  m @ 1280 is the graph the bench times (85 % of its step)."""
@@ -156,7 +161,7 @@ def test_pose_parity_tight(gpu_engine, scale, S, f):
     srcs = [p[..., ::-1] for p in pil]
     kpt = (13, 3)
     sd = _calib(scale, 1, kpt, srcs, S, 0.25, seed=11, dfl_scale=f, kpt_scale=f)
-    m, got = _engine_predict(gpu_engine, sd, 1, kpt, frames, imgsz=S, conf=0.25, iou=0.7, classes=[0],
+    m, got = _engine_predict(gpu_engine, sd, 1, kpt, frames, mode=mode, imgsz=S, conf=0.25, iou=0.7, classes=[0],
                              pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
-    _check(f"pose-{scale}-{S}-tight", sd, 1, kpt, srcs, got, 0.25, 0.7, S, tight=True)
+    _check(f"pose-{scale}-{S}-tight [{mode}]", sd, 1, kpt, srcs, got, 0.25, 0.7, S, tight=True)
     m.close()

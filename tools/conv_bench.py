@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--shapes", default="")
     ap.add_argument("--act", type=int, default=1, help="0 none, 1 SiLU, 2 ReLU (epilogue cost probe)")
     ap.add_argument("--tiles", default="auto,T6,T7,T9,T10,T11,T13,T14,T15,T20")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16"], help="f16: conv_tap16 kernels (tiles Tn = fp16 tile ids 6,7,9,11,12,20,30,31,32)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "h2"], help="f16: conv_tap16 kernels (tiles Tn = fp16 tile ids 6,7,9,11,12,20,30,31,32); h2: fp16-pair kernels (tiles Tn = 207,209,211,213,220,225,303,304,306)")
     a = ap.parse_args()
     from padel_analytics_amd import engine as E, graph as G
     eng = E.default_engine(0)
@@ -59,13 +59,14 @@ def main():
     rng = np.random.default_rng(0)
     for (name, B, H, W, cin, cout, k, s) in shapes:
         f16 = a.dtype == "f16"
-        g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_F16 if f16 else G.DTYPE_F32)
+        h2 = a.dtype == "h2"
+        g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_F16 if f16 else G.DTYPE_H2 if h2 else G.DTYPE_F32)
         cin_p = g.padk(cin)
         b0 = g.buf(0, cin_p)
         b1 = g.buf(1 if s == 2 else 0, g.padk(cout))
         w = rng.normal(0, (2.0 / (cin * k * k)) ** 0.5, (cout, cin, k, k)).astype(np.float32)
-        g.conv((b0, 0, cin_p), (b1, 0), w, np.zeros(cout, np.float32), k, s, a.act, out_width=g.padk(cout) if f16 else None)
-        if f16:                     # the measured conv writes fp16; a tiny fp32 head keeps pa_tracknet_infer's contract
+        g.conv((b0, 0, cin_p), (b1, 0), w, np.zeros(cout, np.float32), k, s, a.act, out_width=g.padk(cout) if (f16 or h2) else None)
+        if f16 or h2:                     # the measured conv writes fp16; a tiny fp32 head keeps pa_tracknet_infer's contract
             hd = g.buf(1 if s == 2 else 0, 16)
             g.conv((b1, 0, g.padk(cout)), (hd, 0), np.zeros((1, g.padk(cout), 1, 1), np.float32), np.zeros(1, np.float32), 1, 1, 0)
             g.head_buf = (hd, -1, -1)
