@@ -225,9 +225,9 @@ int pa_engine_allreduce_max(pa_engine* eng, double* value);
  * boxes n_frames x stride x 6 {x1,y1,x2,y2,conf,cls} (pa_yolo_infer layout, stride = max_det), counts n_frames,
  * keep (optional) n_frames x stride bytes — 0 drops the box before tracking (polygon-zone filter,
  * players_tracker.py:364-365); out_ids n_frames x stride: public track id of each box, -1 = dropped
- * (unmatched / unconfirmed / filtered).                                                                  */
+ * (unmatched / unconfirmed / filtered).  Thresholds are doubles: the same values the Python twin compares with.     */
 typedef struct pa_bytetrack pa_bytetrack;
-int pa_bytetrack_create(float track_activation_threshold, int lost_track_buffer, float minimum_matching_threshold,
+int pa_bytetrack_create(double track_activation_threshold, int lost_track_buffer, double minimum_matching_threshold,
                         int frame_rate, pa_bytetrack** out);
 void pa_bytetrack_destroy(pa_bytetrack* b);
 void pa_bytetrack_reset(pa_bytetrack* b);

@@ -59,18 +59,34 @@ def _make_stub(module, name):
     return type(name, (_Bag,), {"__module__": module})
 
 
-# Globals the stub unpickler resolves for real: tensor / container plumbing only.  Everything else a pickle names
-# (ultralytics.*, but also os.system, builtins.eval, ...) becomes an inert attribute bag, so a crafted .pt cannot
-# execute code through this loader (upstream's plain torch.load(weights_only=False) would).
-_SAFE_MODULE_PREFIXES = ("torch", "collections", "numpy", "_codecs")
+# Globals the stub unpickler resolves for real: an EXACT (module, name) allowlist of tensor / container plumbing.
+# Everything else a pickle names — ultralytics.* and torch.nn.* classes, but also os.system, builtins.eval or any
+# callable that merely lives under torch / numpy (torch.hub.load, torch.utils.collect_env.run,
+# numpy.testing._private.utils.runstring ...) — becomes an inert attribute bag, so a crafted .pt cannot execute code
+# through this loader (upstream's plain torch.load(weights_only=False) would).  nn.Module instances come back as bags
+# whose __dict__ still holds _parameters / _buffers / _modules: all _walk_module needs.
+_TORCH_STORAGES = {"FloatStorage", "HalfStorage", "DoubleStorage", "BFloat16Storage", "LongStorage", "IntStorage",
+                   "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage"}
+_TORCH_DTYPES = {"float16", "float32", "float64", "bfloat16", "int8", "int16", "int32", "int64", "uint8", "bool",
+                 "half", "float", "double", "long", "int", "short"}
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+    ("torch._utils", "_rebuild_parameter"), ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("numpy", "ndarray"), ("numpy", "dtype"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("_codecs", "encode"),
+} | {("torch", n) for n in _TORCH_STORAGES | _TORCH_DTYPES}
 _SAFE_BUILTINS = {"set", "frozenset", "list", "dict", "tuple", "slice", "complex", "bytearray", "range", "object",
                   "int", "float", "bool", "str", "bytes"}
 
 
 class _StubUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        root = module.split(".", 1)[0]
-        if root in _SAFE_MODULE_PREFIXES or (module == "builtins" and name in _SAFE_BUILTINS):
+        if (module, name) in _SAFE_GLOBALS or (module == "builtins" and name in _SAFE_BUILTINS):
             try:
                 return super().find_class(module, name)
             except Exception:

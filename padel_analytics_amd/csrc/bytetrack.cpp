@@ -401,13 +401,13 @@ struct pa_bytetrack {
 
 extern "C" {
 
-int pa_bytetrack_create(float track_activation_threshold, int lost_track_buffer, float minimum_matching_threshold,
+int pa_bytetrack_create(double track_activation_threshold, int lost_track_buffer, double minimum_matching_threshold,
                         int frame_rate, pa_bytetrack** out) {
     if (!out) return 1;
     pa_bytetrack* b = new pa_bytetrack();
-    b->track_thresh = (double)track_activation_threshold;
-    b->match_thresh = (double)minimum_matching_threshold;
-    b->det_thresh = (double)track_activation_threshold + 0.1;
+    b->track_thresh = track_activation_threshold;
+    b->match_thresh = minimum_matching_threshold;
+    b->det_thresh = track_activation_threshold + 0.1;
     b->max_time_lost = (int)((double)frame_rate / 30.0 * lost_track_buffer);
     *out = b;
     return 0;

@@ -361,7 +361,9 @@ int choose_conv_h2_variant(const ConvArgs& a) {
     }
     if (conv_h2p_supported(a)) {
         struct P { int nf; float sp; };
-        static const P ps[] = {{3, 1.17f}, {4, 1.14f}, {6, 1.16f}};
+        // (the 6-fragment patch tile accumulates its main product in ONE level — registers — and measured no faster than the
+        //  3-fragment one, profiles/conv_h2_sweep_r3a.txt: never chosen automatically, so results do not depend on the tile)
+        static const P ps[] = {{3, 1.17f}, {4, 1.10f}};
         const long long patches = (long long)(M / (a.Ho * a.Wo)) * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
         for (const P& v : ps) {
             const int ntiles = (n16 + v.nf - 1) / v.nf;

@@ -145,7 +145,7 @@ def load_library():
     lib.pa_engine_bcast_weights.argtypes = [vp, vp, i32]
     lib.pa_engine_bcast.argtypes = [vp, vp, sz, i32]
     lib.pa_engine_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
-    lib.pa_bytetrack_create.argtypes = [C.c_float, i32, C.c_float, i32, C.POINTER(vp)]
+    lib.pa_bytetrack_create.argtypes = [C.c_double, i32, C.c_double, i32, C.POINTER(vp)]
     lib.pa_bytetrack_destroy.argtypes = [vp]
     lib.pa_bytetrack_destroy.restype = None
     lib.pa_bytetrack_reset.argtypes = [vp]
