@@ -20,7 +20,7 @@ if __name__ == "__main__":
     from padel_analytics_amd import engine as E, graph as G, synth
     eng = E.default_engine(0)
     frames = synth.synthetic_frames(a.frames, 720, 1280, seed=77)
-    g = G.build_tracknet(tr.synth_tracknet_state_dict(3))
+    g = G.build_tracknet(tr.synth_tracknet_state_dict(3), dtype=E.graph_dtype())
     m = E.Model(eng, g)
     m.set_max_batch(a.feed)
     sess = E.BallSession(m, 720, 1280)
@@ -48,4 +48,4 @@ if __name__ == "__main__":
     print(json.dumps({"tracker": "ball_tracker (TrackNetV3 27->8 @288x512, one window per frame)", "frames": n,
                       "frames_per_s": round(n / dt, 1), "ms_per_frame": round(1e3 * dt / n, 3),
                       "conv_tflops": round(fl / ms / 1e9, 1), "conv_ms_per_frame": round(ms / (a.frames - 7), 3),
-                      "input": "host frames (H2D inside the timed region), masks D2H"}))
+                      "input": "host frames (H2D inside the timed region), masks D2H", "arithmetic": E.fp32_mode()}))
