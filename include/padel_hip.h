@@ -159,6 +159,13 @@ typedef struct pa_yolo_params {
 int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
                   float* out_boxes, float* out_kpts, int32_t* out_counts);
 
+/* decode + NMS + rescale alone, on CALLER-SUPPLIED head maps (tests: hand-derived known answers for the Detect / Pose
+ * inference branch, ops.non_max_suppression, scale_boxes — players_tracker.py:351-359 [upstream]): heads[l] =
+ * n x H_l x W_l x c fp32 in the pa_yolo_head_shape layout of the plan for source size h x w (n <= max_batch); outputs as
+ * pa_yolo_infer                                                                                               */
+int pa_yolo_postprocess(pa_model* m, const float* const* heads, int n, int h, int w, const pa_yolo_params* p,
+                        float* out_boxes, float* out_kpts, int32_t* out_counts);
+
 /* raw head maps of the last pa_yolo_infer call (level 0..2): n x H_l x W_l x c fp32 (c from
  * pa_yolo_head_shape; channels [0,64) box DFL logits, [64,64+nc) class logits, then nk keypoint values) */
 int pa_yolo_head_shape(pa_model* m, int level, int* h, int* w, int* c);

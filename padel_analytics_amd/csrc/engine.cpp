@@ -810,6 +810,53 @@ static int finish_profile(pa_model* m, size_t n_rec) {
 
 enum { PROF_PRE = 100, PROF_DECODE = 101, PROF_NMS = 102 };
 
+// decode + NMS + scale_boxes / scale_coords of the head maps in m->lv[] for nb images of a planned model, results copied to
+// the caller's arrays (rows beyond max_det are never written on device).  oh x ow: the size upstream treats as the source
+// (the PIL-resized image on the stretch path).
+static int run_post(pa_model* m, const pa_yolo_params* p, int nb, int oh, int ow, size_t* ppi, float* out_boxes, float* out_kpts,
+                int32_t* out_counts) {
+    pa_engine* e = m->e;
+    hipStream_t s = e->stream;
+    size_t& pi = *ppi;
+    ProfRec* pr = nullptr;
+    hipError_t r = hipSuccess;
+    const double gain = std::min((double)m->net_h / oh, (double)m->net_w / ow);
+    const double kpx = (m->net_w - ow * gain) / 2, kpy = (m->net_h - oh * gain) / 2;
+    // ---- decode + NMS
+    DecodeArgs da{};
+    for (int l = 0; l < 3; ++l) da.lv[l] = m->lv[l];
+    da.cs = m->bufs[m->d.head_buf[0]].channels; da.nc = m->d.nc; da.nk = m->d.nk; da.kdim = m->d.kpt_dim;
+    da.A = m->A; da.B = nb; da.conf = p->conf; da.classes = m->d_classes; da.n_classes = p->n_classes;
+    da.cand = m->d_cand; da.cand_idx = m->d_cidx; da.cand_cnt = m->d_ccnt;
+    pr = prof_begin(m, pi++, PROF_DECODE, 0, 0.0);
+    r = launch_decode(da, s);
+    prof_end(m, pr);
+    if (r != hipSuccess) PA_FAIL(e, "decode launch failed: %s", hipGetErrorString(r));
+    NmsArgs na{};
+    na.cand = m->d_cand; na.cand_idx = m->d_cidx; na.cand_cnt = m->d_ccnt; na.keys = m->d_keys;
+    na.order = m->d_order; na.supp = m->d_supp;
+    for (int l = 0; l < 3; ++l) na.lv[l] = m->lv[l];
+    na.cs = da.cs; na.nc = m->d.nc; na.nk = m->d.nk; na.kdim = m->d.kpt_dim; na.A = m->A; na.B = nb; na.P2 = m->P2;
+    na.iou = p->iou; na.max_det = p->max_det; na.max_nms = 30000;
+    na.gain = (float)gain;
+    na.pad_x = (float)std::nearbyint(kpx - 0.1); na.pad_y = (float)std::nearbyint(kpy - 0.1);
+    na.kpad_x = (float)kpx; na.kpad_y = (float)kpy;
+    na.w0 = (float)ow; na.h0 = (float)oh;
+    na.out_boxes = m->d_oboxes; na.out_kpts = m->d_okpts; na.out_cnt = m->d_ocnt;
+    pr = prof_begin(m, pi++, PROF_NMS, 0, 0.0);
+    r = launch_nms(na, s);
+    prof_end(m, pr);
+    if (r != hipSuccess) PA_FAIL(e, "nms launch failed: %s", hipGetErrorString(r));
+    // ---- results back to the caller's arrays (rows beyond max_det are never written on device)
+    PA_HIP(e, hipMemcpyAsync(out_counts, m->d_ocnt, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PA_HIP(e, hipMemcpyAsync(out_boxes, m->d_oboxes,
+                             (size_t)nb * p->max_det * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (m->d.nk)
+        PA_HIP(e, hipMemcpyAsync(out_kpts, m->d_okpts,
+                                 (size_t)nb * p->max_det * m->d.nk * sizeof(float), hipMemcpyDeviceToHost, s));
+    return 0;
+}
+
 int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
                   float* out_boxes, float* out_kpts, int32_t* out_counts) {
     if (!m || !p) return 1;
@@ -835,8 +882,6 @@ int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const
     const int S = p->imgsz;
     // scale_boxes / scale_coords parameters (upstream treats the PIL-resized image as the source)
     const int oh = p->pre_mode == PA_PRE_PIL_STRETCH ? S : h, ow = p->pre_mode == PA_PRE_PIL_STRETCH ? S : w;
-    const double gain = std::min((double)m->net_h / oh, (double)m->net_w / ow);
-    const double kpx = (m->net_w - ow * gain) / 2, kpy = (m->net_h - oh * gain) / 2;
     size_t pi = 0;
     for (int c0 = 0; c0 < n; c0 += m->max_batch) {
         const int nb = std::min(m->max_batch, n - c0);
@@ -882,41 +927,48 @@ int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const
         if (r != hipSuccess) PA_FAIL(e, "preprocess launch failed: %s", hipGetErrorString(r));
         // ---- network
         if (run_graph(m, nb, &pi)) return 1;
-        // ---- decode + NMS
-        DecodeArgs da{};
-        for (int l = 0; l < 3; ++l) da.lv[l] = m->lv[l];
-        da.cs = m->bufs[m->d.head_buf[0]].channels; da.nc = m->d.nc; da.nk = m->d.nk; da.kdim = m->d.kpt_dim;
-        da.A = m->A; da.B = nb; da.conf = p->conf; da.classes = m->d_classes; da.n_classes = p->n_classes;
-        da.cand = m->d_cand; da.cand_idx = m->d_cidx; da.cand_cnt = m->d_ccnt;
-        pr = prof_begin(m, pi++, PROF_DECODE, 0, 0.0);
-        r = launch_decode(da, s);
-        prof_end(m, pr);
-        if (r != hipSuccess) PA_FAIL(e, "decode launch failed: %s", hipGetErrorString(r));
-        NmsArgs na{};
-        na.cand = m->d_cand; na.cand_idx = m->d_cidx; na.cand_cnt = m->d_ccnt; na.keys = m->d_keys;
-        na.order = m->d_order; na.supp = m->d_supp;
-        for (int l = 0; l < 3; ++l) na.lv[l] = m->lv[l];
-        na.cs = da.cs; na.nc = m->d.nc; na.nk = m->d.nk; na.kdim = m->d.kpt_dim; na.A = m->A; na.B = nb; na.P2 = m->P2;
-        na.iou = p->iou; na.max_det = p->max_det; na.max_nms = 30000;
-        na.gain = (float)gain;
-        na.pad_x = (float)std::nearbyint(kpx - 0.1); na.pad_y = (float)std::nearbyint(kpy - 0.1);
-        na.kpad_x = (float)kpx; na.kpad_y = (float)kpy;
-        na.w0 = (float)ow; na.h0 = (float)oh;
-        na.out_boxes = m->d_oboxes; na.out_kpts = m->d_okpts; na.out_cnt = m->d_ocnt;
-        pr = prof_begin(m, pi++, PROF_NMS, 0, 0.0);
-        r = launch_nms(na, s);
-        prof_end(m, pr);
-        if (r != hipSuccess) PA_FAIL(e, "nms launch failed: %s", hipGetErrorString(r));
-        // ---- results back to the caller's arrays (rows beyond max_det are never written on device)
-        PA_HIP(e, hipMemcpyAsync(out_counts + c0, m->d_ocnt, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        PA_HIP(e, hipMemcpyAsync(out_boxes + (size_t)c0 * p->max_det * 6, m->d_oboxes,
-                                 (size_t)nb * p->max_det * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
-        if (m->d.nk)
-            PA_HIP(e, hipMemcpyAsync(out_kpts + (size_t)c0 * p->max_det * m->d.nk, m->d_okpts,
-                                     (size_t)nb * p->max_det * m->d.nk * sizeof(float), hipMemcpyDeviceToHost, s));
+        // ---- decode + NMS + results back to the caller's arrays
+        if (run_post(m, p, nb, oh, ow, &pi, out_boxes + (size_t)c0 * p->max_det * 6,
+                     m->d.nk ? out_kpts + (size_t)c0 * p->max_det * m->d.nk : nullptr, out_counts + c0)) return 1;
         PA_HIP(e, hipStreamSynchronize(s));
         m->last_n = nb;
     }
+    finish_profile(m, pi);
+    return 0;
+}
+
+int pa_yolo_postprocess(pa_model* m, const float* const* heads, int n, int h, int w, const pa_yolo_params* p,
+                        float* out_boxes, float* out_kpts, int32_t* out_counts) {
+    if (!m || !p || !heads) return 1;
+    pa_engine* e = m->e;
+    if (m->d.task != PA_TASK_DETECT && m->d.task != PA_TASK_POSE) PA_FAIL(e, "pa_yolo_postprocess on a non-YOLO model");
+    if (n <= 0 || n > m->max_batch || !out_boxes || !out_counts || (m->d.nk && !out_kpts)) PA_FAIL(e, "pa_yolo_postprocess: bad arguments");
+    if (p->max_det < 1 || p->max_det > 300) PA_FAIL(e, "max_det %d outside [1,300]", p->max_det);
+    PA_HIP(e, hipSetDevice(e->dev));
+    if (!m->planned || m->p_h0 != h || m->p_w0 != w || m->p_imgsz != p->imgsz || m->p_pre != p->pre_mode ||
+        m->p_auto != p->letterbox_auto || m->p_batch != m->max_batch)
+        if (plan_yolo(m, h, w, p)) return 1;
+    hipStream_t s = e->stream;
+    if (p->n_classes > 0) {
+        if (p->n_classes > m->classes_cap) {
+            if (m->d_classes) hipFree(m->d_classes);
+            PA_HIP(e, hipMalloc((void**)&m->d_classes, p->n_classes * sizeof(int32_t)));
+            m->classes_cap = p->n_classes;
+        }
+        PA_HIP(e, hipMemcpyAsync(m->d_classes, p->classes, p->n_classes * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    const int cs = m->bufs[m->d.head_buf[0]].channels;
+    for (int l = 0; l < 3; ++l) {
+        if (!heads[l]) PA_FAIL(e, "pa_yolo_postprocess: heads[%d] is NULL", l);
+        PA_HIP(e, hipMemcpyAsync(const_cast<float*>(m->lv[l].buf), heads[l], (size_t)n * m->lv[l].H * m->lv[l].W * cs * sizeof(float),
+                                 hipMemcpyHostToDevice, s));
+    }
+    const int S = p->imgsz;
+    const int oh = p->pre_mode == PA_PRE_PIL_STRETCH ? S : h, ow = p->pre_mode == PA_PRE_PIL_STRETCH ? S : w;
+    size_t pi = 0;
+    if (run_post(m, p, n, oh, ow, &pi, out_boxes, out_kpts, out_counts)) return 1;
+    PA_HIP(e, hipStreamSynchronize(s));
+    m->last_n = n;
     finish_profile(m, pi);
     return 0;
 }

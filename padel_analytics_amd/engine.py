@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "pa_comm_unique_id", "pa_engine_comm_init", "pa_engine_comm_destroy", "pa_engine_bcast_weights",
     "pa_engine_bcast", "pa_engine_allreduce_max",
     "pa_bytetrack_create", "pa_bytetrack_destroy", "pa_bytetrack_reset", "pa_bytetrack_update_batch",
-    "pa_model_take_overflow",
+    "pa_model_take_overflow", "pa_yolo_postprocess",
 ]
 
 
@@ -152,6 +152,7 @@ def load_library():
     lib.pa_bytetrack_reset.restype = None
     lib.pa_bytetrack_update_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp]
     lib.pa_model_take_overflow.argtypes = [vp, C.POINTER(i32)]
+    lib.pa_yolo_postprocess.argtypes = [vp, C.POINTER(vp), i32, i32, i32, C.POINTER(pa_yolo_params), vp, vp, vp]
     if lib.pa_abi_version() != 3:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
@@ -336,6 +337,40 @@ class Model:
         self.engine._check(self.engine.lib.pa_yolo_infer(
             self.handle, ptr, n, h, w, C.byref(p), boxes.ctypes.data,
             kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
+        return boxes, kpts, counts
+
+    def head_shapes(self, h: int, w: int, imgsz: int, pre_mode: int = PRE_LETTERBOX) -> list:
+        """[(H_l, W_l, c)] of the three head maps for source size h x w (host arithmetic of the planner)."""
+        if pre_mode == PRE_PIL_STRETCH:
+            nh = nw = imgsz
+        else:
+            r = min(imgsz / h, imgsz / w)
+            rw, rh = int(round(w * r)), int(round(h * r))
+            nw, nh = rw + (imgsz - rw) % 32, rh + (imgsz - rh) % 32
+        c = self.graph.bufs[self.graph.head_buf[0]][1]
+        return [(nh >> (3 + l), nw >> (3 + l), c) for l in range(3)]
+
+    def yolo_postprocess(self, heads, h: int, w: int, *, imgsz: int, conf: float, iou: float,
+                         classes: Optional[Sequence[int]] = None, max_det: int = 300, pre_mode: int = PRE_LETTERBOX):
+        """Decode + NMS + rescale of caller-supplied head maps (``heads[l]``: (n, H_l, W_l, c) fp32, ``head_shapes``):
+        the Detect / Pose inference branch alone — tests feed hand-derived cases through it."""
+        heads = [np.ascontiguousarray(x, np.float32) for x in heads]
+        n = heads[0].shape[0]
+        assert [x.shape[1:] for x in heads] == [tuple(s) for s in self.head_shapes(h, w, imgsz, pre_mode)], [x.shape for x in heads]
+        p = pa_yolo_params(imgsz=imgsz, pre_mode=pre_mode, channel_reverse=0, letterbox_auto=1, conf=conf, iou=iou,
+                           max_det=max_det, n_classes=0, classes=None, frames_on_device=0)
+        cls_arr = None
+        if classes is not None and len(classes):
+            cls_arr = (C.c_int32 * len(classes))(*[int(c) for c in classes])
+            p.n_classes = len(classes)
+            p.classes = cls_arr
+        ptrs = (C.c_void_p * 3)(*[x.ctypes.data for x in heads])
+        boxes = np.zeros((n, max_det, 6), np.float32)
+        counts = np.zeros((n,), np.int32)
+        nk = self.graph.nk
+        kpts = np.zeros((n, max_det, nk), np.float32) if nk else None
+        self.engine._check(self.engine.lib.pa_yolo_postprocess(self.handle, ptrs, n, h, w, C.byref(p), boxes.ctypes.data,
+                                                               kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
         return boxes, kpts, counts
 
     def take_overflow(self) -> bool:
