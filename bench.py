@@ -414,13 +414,17 @@ def main():
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         PEAK = PEAK_FP16_MFMA_TFLOPS if a.dtype == "f16" else PEAK_BY_IMPL[a.impl]
         traffic = None
-        tpath = ROOT / "profiles" / "r2_traffic.json"          # PMC FETCH_SIZE / WRITE_SIZE passes (tools/pmc_bench_traffic.sh)
+        # PMC FETCH_SIZE / WRITE_SIZE passes of this command line (tools/pmc_bench_traffic.sh): counters cannot be read from
+        # inside an un-profiled run, so the figure is the committed measurement, marked "static"
+        tpath = ROOT / "profiles" / "r3_traffic.json"
         if tpath.exists():
             tj = json.loads(tpath.read_text()).get(f"{a.workload}-{a.impl}" if a.dtype == "f32" else "none")
             if tj:
                 traffic = {"bytes_per_launch": tj["bytes_per_launch"], "fetch_bytes_per_launch": tj["fetch_bytes_per_launch"],
                            "write_bytes_per_launch": tj["write_bytes_per_launch"],
-                           "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"], "source": tj["source"]}
+                           "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
+                           "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"), "static": True,
+                           "source": "profiles/r3_traffic.json: " + tj["source"]}
         out["roofline"] = {
             "kernel": ("conv_tap16_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x32_f16)"
                        if a.dtype == "f16" else

@@ -1,10 +1,10 @@
 #!/bin/bash
 # HBM traffic of the bench's dominant kernel, per launch: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc
 # passes (kernel-trace only — MI355X_MICROARCH.md "rocprofv3 PMC slots": both do not fit one pass), over the bench's
-# own command line in engine-only mode, then summarised into profiles/r2_traffic.json (read by bench.py for
+# own command line in engine-only mode, then summarised into profiles/r3_traffic.json (read by bench.py for
 # roofline.traffic).  Usage (on the GPU box, from the repo root):  bash tools/pmc_bench_traffic.sh [c3|c2]
 WL=${1:-c3}
-IMPL=${2:-bx3}
+IMPL=${2:-h2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 export TMPDIR=/tmp

@@ -1,4 +1,4 @@
-"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench_traffic.sh into profiles/r2_traffic.json.
+"""Summarise the FETCH_SIZE / WRITE_SIZE passes of tools/pmc_bench_traffic.sh into profiles/r3_traffic.json.
 
 Per launch of the dominant kernels (every 3x3 conv: conv_bx3p_kernel + conv_bx3_kernel, or conv_tap_kernel for --impl tap): HBM bytes read = FETCH_SIZE (KiB) x 1024 x 2
 — MI355X_MICROARCH.md §HBM: on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B / lane) coalesced
@@ -31,19 +31,19 @@ def main():
     wl, ops_csv, d_fetch, d_write = sys.argv[1:5]
     impl = sys.argv[5] if len(sys.argv) > 5 else "tap"
     # bx3: stride-1 layers run the patch kernel (conv_patch_bx3.hip), stride-2 layers the tap kernel
-    KERNEL = {"tap": ("conv_tap_kernel",), "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel")}[impl]
+    KERNEL = {"tap": ("conv_tap_kernel",), "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel"), "h2": ("conv_h2p_kernel", "conv_h2_kernel")}[impl]
     fetch_kib, n_f = per_kernel(d_fetch, "FETCH_SIZE")
     write_kib, n_w = per_kernel(d_write, "WRITE_SIZE")
     alg, n_ops = 0.0, 0
     for r in csv.DictReader(open(ops_csv)):
         if r["kind"] == "2" and r["ksize"] == "3":
             M, cout, cin, s = int(r["M"]), int(r["cout"]), int(r["cin"]), int(r["stride"])
-            alg += M * s * s * cin * 4 + M * cout * 4 + 9 * cin * cout * (6 if impl == "bx3" else 4)
+            alg += M * s * s * cin * 4 + M * cout * 4 + 9 * cin * cout * (6 if impl == "bx3" else 4)      # weights: 3 x bf16 (bx3), 2 x fp16 (h2) or fp32
             n_ops += 1
     assert n_f and n_w and n_ops, (n_f, n_w, n_ops)
     fetch = fetch_kib * 1024 * 2 / n_f
     write = write_kib * 1024 / n_w
-    out_path = Path("profiles/r2_traffic.json")
+    out_path = Path("profiles/r3_traffic.json")
     doc = json.loads(out_path.read_text()) if out_path.exists() else {}
     doc[f"{wl}-{impl}"] = {
         "kernel": f"{' + '.join(KERNEL)} (all 3x3 convs of the workload)",
