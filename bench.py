@@ -82,9 +82,12 @@ def parse():
     ap.add_argument("--no-compare", action="store_true", help="skip the fp32-MFMA comparison leg of engine_only (profiling runs)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="frames of the CPU baseline sample (0 = auto)")
     ap.add_argument("--dump-ops", default="", help="write the per-op profile (CSV) of the roofline pass here")
-    ap.add_argument("--host-frames", action="store_true",
-                    help="also time the runner with the clip in pageable host memory: sequential (one upload per "
-                         "tracker, like the reference) and fan-out (one upload per batch) — PCIe-inclusive rates")
+    ap.add_argument("--no-host-frames", action="store_true",
+                    help="skip the end-to-end-from-host leg (clip in page-locked host memory: sequential = one upload per "
+                         "tracker like the reference, fan-out = one upload per batch — PCIe-inclusive rates)")
+    ap.add_argument("--no-reference-default", action="store_true",
+                    help="skip the leg with the reference's own default configuration (players yolov8m + pose + the "
+                         "TrackNetV3 BallTracker, config.py:22,29-30,36-39)")
     ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the op lists (tuning; -1 = engine default)")
     ap.add_argument("--impl", default="h2", choices=["h2", "bx3", "tap", "lds"],
                     help="fp32-equivalent conv arithmetic: h2 (default: activations as fp16 pairs, 3 products on the f16 matrix "
@@ -379,16 +382,68 @@ def main():
             out["config"]["tracked_players_rank0"] = kept
         else:
             out["value"], out["ms_per_step"] = out["engine_only"]["value"], out["engine_only"]["ms_per_step"]
-        if a.host_frames and not a.engine_only:
-            hclip = video.ArrayClip(frames, repeat=max(K, 1))
+        # how many result OBJECTS the timed run created: `Players` / `PlayersKeypoints` keep the detector's arrays and build
+        # their `Player` / `PlayerKeypoints` objects on first access (the reference builds them eagerly,
+        # players_tracker.py:371-378) — count what the timed region materialised, then what doing it all costs
+        if not a.engine_only:
+            om = {}
+            for nm_, t_ in trackers.items():
+                preds = t_.results.predictions
+                cached = lambda p_: getattr(p_, "_players", None) if hasattr(p_, "_players") else getattr(p_, "_items", None)
+                lazy = [p_ for p_ in preds if hasattr(p_, "_players") or hasattr(p_, "_items")]
+                if not lazy:
+                    om[nm_] = {"containers": len(preds), "lazy": False}
+                    continue
+                inside = sum(len(cached(p_)) for p_ in lazy if cached(p_) is not None)
+                t1_ = time.perf_counter()
+                total = sum(len(p_.players) if hasattr(p_, "_players") else len(p_.players_keypoints) for p_ in lazy)
+                om[nm_] = {"containers": len(preds), "lazy": True, "objects_built_inside_timed_region": inside,
+                           "objects_total": total, "build_all_ms": round(1e3 * (time.perf_counter() - t1_), 2)}
+            out["objects_materialised"] = om
+        if not a.no_host_frames and not a.engine_only:
+            hclip = video.ArrayClip(frames, repeat=max(K, 1)).pin(eng)        # a decoder writing into page-locked memory
             run_runner(hclip, 1)
             dt_s, _ = run_runner(hclip, K)
             run_runner(hclip, 1, fanout=True, engine=eng)
             dt_f, _ = run_runner(hclip, K, fanout=True, engine=eng)
+            hclip.unpin()
             out["host_frames"] = {"sequential_frames_per_s": round(world * B * K / dt_s, 2),
-                                  "fanout_frames_per_s": round(world * B * K / dt_f, 2),
-                                  "what": "clip in pageable host memory (PCIe-inclusive): one upload per tracker (reference "
-                                          "order) vs one upload per batch feeding all trackers (TrackingRunner(fanout=True))"}
+                                  "fanout_frames_per_s": round(world * B * K / dt_f, 2), "pinned": True,
+                                  "what": "clip in page-locked host memory (hipHostRegister), PCIe-inclusive: one upload per "
+                                          "tracker (reference order, runner.py:215-228) vs one upload per batch feeding all "
+                                          "trackers (TrackingRunner(fanout=True)); never `value`"}
+        if not a.no_reference_default and not a.engine_only and a.workload == "c3" and a.dtype == "f32":
+            # the reference's ACTUAL default configuration: players yolov8m, pose @1280, and the TrackNetV3 ball tracker
+            # (config.py:22,29-30,36-39; ball_tracker.py:373-523) instead of BASELINE's "ball YOLOv8 detect"
+            from oracle import tracknet_ref as tr          # seeded synthetic TrackNet weights (setup only)
+            from padel_analytics_amd import checkpoint
+            from padel_analytics_amd.trackers import BallTracker
+            tpath = Path(tmp) / f"tracknet_r{rank}.pt"
+            checkpoint.save_checkpoint(tpath, tr.synth_tracknet_state_dict(3), "tracknet", param_dict={"seq_len": 8, "bg_mode": "concat"})
+            bt = BallTracker(str(tpath), None, batch_size=B)
+            bt._engine = eng
+            ref_trackers = [trackers["players"], trackers["pose"], bt]
+
+            def run_ref(n_batches):
+                runner = TrackingRunner(ref_trackers, clip, Path(tmp) / "out_ref.mp4", start=0, end=n_batches * B)
+                runner.restart()
+                fence()
+                t0_ = time.perf_counter()
+                runner.run()
+                fence()
+                return eng.allreduce_max(time.perf_counter() - t0_), runner
+
+            run_ref(1)
+            dt_r, rr = run_ref(K)
+            out["reference_default"] = {
+                "value": round(world * B * K / dt_r, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_r / K, 3),
+                "trackers": {"players": "yolov8m-detect-nc80 @640 + PolygonZone + ByteTrack", "pose": "yolov8m-pose13x3 @1280",
+                             "ball": "TrackNetV3 27->8 @288x512, one window per frame, median background over the clip, "
+                                     "temporal ensemble, threshold, connected components on the device (BallTracker)"},
+                "conv_gflop_per_frame": round((flops_per_frame["players"] + flops_per_frame["pose"]) / 1e9 + 227.61, 1),
+                "seconds_per_tracker_rank0": {k_: round(v_["seconds"], 4) for k_, v_ in rr.timings.items()},
+                "what": "TrackingRunner.run() over the same HBM-resident clip with the reference's default trackers"}
+            bt.to("cpu")
 
     if rank == 0 and not a.no_roofline:
         # ---- roofline of the dominant kernel (conv3x3 implicit GEMM, fp32 MFMA): HIP events recorded on

@@ -112,6 +112,12 @@ int pa_memcpy_d2h(pa_engine* eng, void* dst_host, const void* src_dev, size_t nb
  * uploads per tracker, trackers/runner.py:215-220; the runner's fan-out mode uploads once per batch)   */
 int pa_upload(pa_engine* eng, void* dst_dev, const void* src_host, size_t nbytes);
 
+/* page-lock a caller-owned host range (hipHostRegister) so that uploads from it run at PCIe speed and overlap compute:
+ * the frame source of the end-to-end-from-host path (the reference decodes into host memory, trackers/runner.py:215-220).
+ * The caller keeps ownership and unregisters before freeing.                                                  */
+int pa_host_register(pa_engine* eng, void* ptr, size_t nbytes);
+int pa_host_unregister(pa_engine* eng, void* ptr);
+
 /* tuning knobs (tests / tools only).  Defaults come from the environment ONCE at pa_engine_create
  * (PADEL_CONV_IMPL=tap|lds, PADEL_CONV_VARIANT, PADEL_CONV_TUNE, PADEL_CONV_TAP_PD, PADEL_GRAPH, PADEL_ALIAS).
  * keys: "impl" (2 bf16x3 kernels = default, 0 fp32-MFMA tap kernels, 1 fp32-MFMA LDS cross-check kernel),
@@ -220,6 +226,9 @@ int pa_comm_unique_id(void* out, size_t cap);
 int pa_engine_comm_init(pa_engine* eng, const void* unique_id, size_t id_bytes, int nranks, int rank);
 void pa_engine_comm_destroy(pa_engine* eng);
 int pa_engine_bcast_weights(pa_engine* eng, pa_model* m, int root);
+/* same, with a separate source on the root: the root sends src's blob, EVERY rank (the root too) receives into dst, a
+ * model created from a NULL blob; other ranks pass src = NULL                                               */
+int pa_engine_bcast_weights_from(pa_engine* eng, pa_model* src, pa_model* dst, int root);
 /* in-place broadcast of nbytes of device memory (e.g. the ball tracker's background median) */
 int pa_engine_bcast(pa_engine* eng, void* dev_ptr, size_t nbytes, int root);
 /* max over ranks of one double (bench: step time of the slowest rank) */

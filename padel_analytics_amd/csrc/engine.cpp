@@ -212,6 +212,16 @@ int pa_upload(pa_engine* e, void* dst, const void* src, size_t n) {
     PA_HIP(e, hipStreamSynchronize(e->copy_stream));
     return 0;
 }
+int pa_host_register(pa_engine* e, void* ptr, size_t nbytes) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipHostRegister(ptr, nbytes, hipHostRegisterDefault));
+    return 0;
+}
+int pa_host_unregister(pa_engine* e, void* ptr) {
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipHostUnregister(ptr));
+    return 0;
+}
 int pa_memcpy_d2h(pa_engine* e, void* dst, const void* src, size_t n) {
     PA_HIP(e, hipSetDevice(e->dev));
     PA_HIP(e, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, e->stream));
@@ -1457,6 +1467,21 @@ int pa_engine_bcast(pa_engine* e, void* dev_ptr, size_t nbytes, int root) {
 int pa_engine_bcast_weights(pa_engine* e, pa_model* m, int root) {
     if (!e || !m || m->e != e) return 1;
     return pa_engine_bcast(e, m->d_w, m->n_w * sizeof(float), root);
+}
+
+// The same broadcast with a separate SOURCE on the root: the root rank sends `src`'s blob (the model it loaded), every rank —
+// the root included — receives into `dst` (a model created from a NULL blob).  Ranks other than the root pass src = NULL.
+// On one GPU (nranks == 1) this is how a test proves that a blob that only ever travelled through RCCL gives bitwise the
+// detections of the loaded one (BASELINE configs[3]: weights reach 7 of the 8 shards this way).
+int pa_engine_bcast_weights_from(pa_engine* e, pa_model* src, pa_model* dst, int root) {
+    if (!e || !dst || dst->e != e || (src && (src->e != e || src->n_w != dst->n_w))) return 1;
+    if (!e->comm) PA_FAIL(e, "pa_engine_bcast_weights_from: call pa_engine_comm_init first");
+    PA_HIP(e, hipSetDevice(e->dev));
+    const void* send = src ? src->d_w : dst->d_w;
+    const ncclResult_t r = e->comm->Broadcast(send, dst->d_w, dst->n_w * sizeof(float), ncclUint8, root, e->comm->comm, e->stream);
+    if (r != ncclSuccess) PA_FAIL(e, "ncclBroadcast: %s", e->comm->GetErrorString(r));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
 }
 
 // max over ranks of one double (bench: step time) — keeps the measurement inside the same communicator

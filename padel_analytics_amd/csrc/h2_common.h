@@ -33,16 +33,46 @@ constexpr unsigned kOORh = 0x80000000u;      // out-of-range lane offset that st
 // byte offset, inside a pixel, of the h part of channels [c, c + 4) (c % 4 == 0); the m part sits 32 bytes further
 __device__ __forceinline__ long long h2_chan_off(int c) { return (long long)(c >> 4) * 64 + (c & 15) * 2; }
 
-// 4 fp32 -> their h and m parts; `bad` collects "does not fit fp16" (|v| > 65504 or NaN)
+typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h2_h16x2 __attribute__((ext_vector_type(2)));
+
+// 4 fp32 -> their h and m parts; `bad` collects "does not fit fp16" (|v| > 65504 or NaN).  Pairs go through the packed
+// round-to-nearest conversion (v_cvt_pk_f16_f32): 6 VALU per value
 __device__ __forceinline__ void h2_encode4(const f32x4 v, h16x4& h, h16x4& m, bool& bad) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        bad |= !(fabsf(v[r]) <= kH2Max);
-        const float x = __builtin_amdgcn_fmed3f(v[r], -kH2Max, kH2Max);
-        const _Float16 hh = (_Float16)x;
-        h[r] = hh;
-        m[r] = (_Float16)((x - (float)hh) * kH2Scale);
+    for (int p = 0; p < 2; ++p) {
+        bad |= !(fabsf(v[2 * p]) <= kH2Max) | !(fabsf(v[2 * p + 1]) <= kH2Max);
+        const h2_f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * p], -kH2Max, kH2Max), __builtin_amdgcn_fmed3f(v[2 * p + 1], -kH2Max, kH2Max)};
+        const h2_h16x2 hh = __builtin_convertvector(x, h2_h16x2);
+        const h2_f32x2 rr = {(x[0] - (float)hh[0]) * kH2Scale, (x[1] - (float)hh[1]) * kH2Scale};
+        const h2_h16x2 mm = __builtin_convertvector(rr, h2_h16x2);
+        h[2 * p] = hh[0]; h[2 * p + 1] = hh[1];
+        m[2 * p] = mm[0]; m[2 * p + 1] = mm[1];
     }
+}
+
+// SiLU / sigmoid for the epilogues: e^-x through v_exp_f32 on a compensated argument (the product x * log2(e) carried as
+// hi + lo), the quotient through v_rcp_f32 + one Newton step on the remainder.  11 VALU instead of the 28 of
+// expf() + IEEE division, at the accuracy of the fp32 formula itself (max 2.7 ulp / mean 0.37 ulp against 2.4 / 0.35 for
+// correctly rounded exp + division, measured over 2.5 M arguments in [-90, 90]; profiles/h2_silu_accuracy_r3.txt).
+__device__ __forceinline__ float h2_exp_neg(float x) {           // e^-x, finite for every finite x (clamped at 2^126)
+    const float t = -x * 1.4426950216293335f;
+    float tl = fmaf(-x, 1.4426950216293335f, -t);
+    tl = fmaf(-x, 1.9259629911783190e-8f, tl);
+    const float e0 = __builtin_amdgcn_exp2f(fminf(t, 126.0f));
+    return fmaf(e0, tl * 0.6931471805599453f, e0);
+}
+__device__ __forceinline__ float h2_div(float num, float d) {     // num / d for d in [1, 2^127)
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float y = num * r;
+    return fmaf(fmaf(-y, d, num), r, y);
+}
+template <int ACT>
+__device__ __forceinline__ float h2_act(float x) {
+    if (ACT == ACT_SILU) return h2_div(x, 1.0f + h2_exp_neg(x));
+    if (ACT == ACT_RELU) return x > 0.0f ? x : 0.0f;
+    if (ACT == ACT_SIGMOID) return h2_div(1.0f, 1.0f + h2_exp_neg(x));
+    return x;
 }
 __device__ __forceinline__ f32x4 h2_decode4(const h16x4 h, const h16x4 m) {
     f32x4 v;
@@ -81,11 +111,7 @@ __device__ __forceinline__ void h2_epilogue_case(const ConvArgs& a, const f32x4 
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float x = fmaf(fmaf(cross[f][j][r], kH2InvScale, mainacc[f][j][r]), sc[r], b[r]);
-                if (ACT == ACT_SILU) x = x / (1.0f + expf(-x));
-                else if (ACT == ACT_RELU) x = x > 0.0f ? x : 0.0f;
-                else if (ACT == ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
-                v[r] = x;
+                v[r] = h2_act<ACT>(fmaf(fmaf(cross[f][j][r], kH2InvScale, mainacc[f][j][r]), sc[r], b[r]));
             }
             if (FAST) {
                 if (RES) {

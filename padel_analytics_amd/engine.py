@@ -82,7 +82,8 @@ ABI_SYMBOLS = [
     "pa_comm_unique_id", "pa_engine_comm_init", "pa_engine_comm_destroy", "pa_engine_bcast_weights",
     "pa_engine_bcast", "pa_engine_allreduce_max",
     "pa_bytetrack_create", "pa_bytetrack_destroy", "pa_bytetrack_reset", "pa_bytetrack_update_batch",
-    "pa_model_take_overflow", "pa_yolo_postprocess",
+    "pa_model_take_overflow", "pa_yolo_postprocess", "pa_host_register", "pa_host_unregister",
+    "pa_engine_bcast_weights_from",
 ]
 
 
@@ -144,6 +145,7 @@ def load_library():
     lib.pa_engine_comm_destroy.restype = None
     lib.pa_engine_bcast_weights.argtypes = [vp, vp, i32]
     lib.pa_engine_bcast.argtypes = [vp, vp, sz, i32]
+    lib.pa_engine_bcast_weights_from.argtypes = [vp, vp, vp, i32]
     lib.pa_engine_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
     lib.pa_bytetrack_create.argtypes = [C.c_double, i32, C.c_double, i32, C.POINTER(vp)]
     lib.pa_bytetrack_destroy.argtypes = [vp]
@@ -151,6 +153,8 @@ def load_library():
     lib.pa_bytetrack_reset.argtypes = [vp]
     lib.pa_bytetrack_reset.restype = None
     lib.pa_bytetrack_update_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    lib.pa_host_register.argtypes = [vp, vp, sz]
+    lib.pa_host_unregister.argtypes = [vp, vp]
     lib.pa_model_take_overflow.argtypes = [vp, C.POINTER(i32)]
     lib.pa_yolo_postprocess.argtypes = [vp, C.POINTER(vp), i32, i32, i32, C.POINTER(pa_yolo_params), vp, vp, vp]
     if lib.pa_abi_version() != 3:
@@ -227,6 +231,14 @@ class Engine:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
+    def pin(self, arr: np.ndarray) -> None:
+        """Page-lock a host array in place (hipHostRegister): uploads from it run at PCIe speed.  unpin() before freeing."""
+        assert arr.flags.c_contiguous
+        self._check(self.lib.pa_host_register(self.handle, arr.ctypes.data, arr.nbytes))
+
+    def unpin(self, arr: np.ndarray) -> None:
+        self._check(self.lib.pa_host_unregister(self.handle, arr.ctypes.data))
+
     def set_tuning(self, **kv):
         """Tests / tools only: impl (2 bx3, 0 tap, 1 lds), variant (tile id, -1 auto), tune, tap_pd, graph, alias, fold_up, timeline."""
         for k, v in kv.items():
@@ -240,6 +252,10 @@ class Engine:
 
     def bcast_weights(self, model: "Model", root: int = 0):
         self._check(self.lib.pa_engine_bcast_weights(self.handle, model.handle, root))
+
+    def bcast_weights_from(self, src: Optional["Model"], dst: "Model", root: int = 0):
+        """Root sends ``src``'s blob, every rank (root included) receives into ``dst`` (created with empty=True)."""
+        self._check(self.lib.pa_engine_bcast_weights_from(self.handle, src.handle if src is not None else None, dst.handle, root))
 
     def bcast(self, buf: DeviceBuffer, nbytes: int, root: int = 0):
         self._check(self.lib.pa_engine_bcast(self.handle, buf.ptr, nbytes, root))

@@ -135,7 +135,7 @@ class BallTracker(Tracker):
             dev = video.device_batch(frames)
             if dev is not None:
                 return sess.background_from_frames(dev[0], want_median=True, n=dev[1])
-            return sess.background_from_frames(np.stack(frames), want_median=True)
+            return sess.background_from_frames(video.host_batch(frames), want_median=True)
         finally:
             sess.close()
 
@@ -176,7 +176,7 @@ class BallTracker(Tracker):
             if dev is not None:
                 sess.background_from_frames(dev[0], n=dev[1])
             else:
-                sess.background_from_frames(np.stack(head))
+                sess.background_from_frames(video.host_batch(head))
         else:
             sess.set_background(median)
         out = []
@@ -208,7 +208,7 @@ class BallTracker(Tracker):
             if dev is not None:
                 consume(sess.feed(dev[0], want_rects=True, n=dev[1]))
             else:
-                consume(sess.feed(np.stack(c), want_rects=True))
+                consume(sess.feed(video.host_batch(c), want_rects=True))
         consume(sess.feed(None, flush=True, want_rects=True))
         sess.close()
         if self.graph.dtype == G.DTYPE_H2 and self._model.take_overflow():

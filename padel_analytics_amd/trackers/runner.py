@@ -182,7 +182,7 @@ class TrackingRunner:
 
             def stage(k, frames):
                 c = clips[k % len(clips)]
-                c.upload(np.stack(frames), copy_stream=True)
+                c.upload(video.host_batch(frames), copy_stream=True)
                 return [video.DeviceFrame(c, i) for i in range(len(frames))]
 
             with ThreadPoolExecutor(max_workers=1) as up:

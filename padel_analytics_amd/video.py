@@ -117,6 +117,20 @@ class ArrayClip:
         self.array = np.ascontiguousarray(frames, np.uint8)
         self.n, self.h, self.w = self.array.shape[:3]
         self.repeat, self.fps = int(repeat), int(fps)
+        self._pinned_by = None
+
+    def pin(self, engine) -> "ArrayClip":
+        """Page-lock the clip (a decoder writing into pinned memory): batches of consecutive frames then go up without a
+        staging copy (``host_batch``) and at PCIe speed."""
+        if self._pinned_by is None:
+            engine.pin(self.array)
+            self._pinned_by = engine
+        return self
+
+    def unpin(self) -> None:
+        if self._pinned_by is not None:
+            self._pinned_by.unpin(self.array)
+            self._pinned_by = None
 
     @property
     def total_frames(self) -> int:
@@ -140,6 +154,23 @@ def device_batch(sample):
             raise ValueError("a batch of device-resident frames must be a contiguous range of one DeviceClip")
     n = len(sample)
     return clip.buffer.view(i0 * clip.frame_bytes, n * clip.frame_bytes), n, clip.h, clip.w
+
+
+def host_batch(sample) -> np.ndarray:
+    """(n, h, w, 3) uint8 array of a batch of host frames.  Frames that are consecutive in memory — views of ONE
+    contiguous array: an ``ArrayClip``, a memory-mapped .npy stack, a decoder's ring — come back as a view over them: no
+    staging copy, and if that memory is page-locked the upload runs straight from it; anything else is stacked."""
+    if isinstance(sample, np.ndarray):
+        return sample
+    sample = list(sample)
+    f0 = sample[0]
+    if isinstance(f0, np.ndarray) and f0.flags.c_contiguous and f0.dtype == np.uint8 and f0.base is not None:
+        fb, p0 = f0.nbytes, f0.ctypes.data
+        root = f0.base
+        if fb and all(isinstance(f, np.ndarray) and f.base is root and f.shape == f0.shape and f.flags.c_contiguous and
+                      f.ctypes.data == p0 + k * fb for k, f in enumerate(sample)):
+            return np.lib.stride_tricks.as_strided(f0, shape=(len(sample),) + f0.shape, strides=(fb,) + f0.strides, writeable=False)
+    return np.stack(sample)
 
 
 def get_video_frames_generator(source_path, stride: int = 1, start: int = 0, end: Optional[int] = None) -> Iterator[np.ndarray]:

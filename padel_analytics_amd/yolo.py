@@ -183,7 +183,7 @@ class YOLO:
         if dev is not None:
             src, n, h, w = dev
         else:
-            src = frames if isinstance(frames, np.ndarray) else np.stack(list(frames))
+            src = video.host_batch(frames)
             n, h, w, _ = src.shape
         kw = dict(imgsz=int(imgsz), conf=float(conf), iou=float(iou), classes=classes, max_det=int(max_det),
                   pre_mode=pre_mode, channel_reverse=channel_reverse, letterbox_auto=True)
