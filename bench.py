@@ -420,7 +420,9 @@ def main():
             from padel_analytics_amd.trackers import BallTracker
             tpath = Path(tmp) / f"tracknet_r{rank}.pt"
             checkpoint.save_checkpoint(tpath, tr.synth_tracknet_state_dict(3), "tracknet", param_dict={"seq_len": 8, "bg_mode": "concat"})
-            bt = BallTracker(str(tpath), None, batch_size=B)
+            # (background median over the first B frames: the HBM-resident clip is B distinct frames repeated K times, so
+            #  the reference's 1800-frame window would see the same B frames over and over)
+            bt = BallTracker(str(tpath), None, batch_size=B, median_max_sample_num=B)
             bt._engine = eng
             ref_trackers = [trackers["players"], trackers["pose"], bt]
 

@@ -42,7 +42,11 @@ __device__ __forceinline__ void hp_lds_fence() { asm volatile("s_waitcnt lgkmcnt
 
 }  // namespace
 
-template <int NF, bool TAIL, bool UP>
+// NSTG: stages of the weight ring.  2: a tap's weights are requested one step ahead and every step waits for ALL of its
+// wave's requests — the patch prefetch of the next chunk included, which therefore gets one step (~300 matrix-pipe
+// cycles) of latency cover.  3: weights two steps ahead, counted waits (vmcnt(n) with n = what was requested after the
+// data needed now): weights get two steps, the patch loads three.
+template <int NF, bool TAIL, bool UP, int NSTG>
 __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel(const ConvArgs a) {
     constexpr int MF = 2;
     constexpr bool TWOL = NF <= 4;               // two-level main accumulation (part -> acc once per chunk) where registers allow
@@ -50,8 +54,9 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     constexpr int BSTAGE_B = 2 * BN * 64;
     constexpr int BP = (BN + 63) / 64, BFULL = BN / 64;
     static_assert(BP <= 2, "weights in at most 2 passes of 64 rows");
-    static_assert(kHPatchB + 2 * BSTAGE_B <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) float lds[(kHPatchB + 2 * BSTAGE_B) / 4];
+    static_assert(NSTG == 2 || NSTG == 3, "2- or 3-stage weight ring");
+    static_assert(kHPatchB + NSTG * BSTAGE_B <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) float lds[(kHPatchB + NSTG * BSTAGE_B) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -113,9 +118,16 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     const bool b_last = BP > BFULL && (BFULL * 64 + wave * 16 < BN);
     unsigned lw0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)kHPatchB + wave * 1024u);
     unsigned lw1 = __builtin_amdgcn_readfirstlane(lw0 + (unsigned)BSTAGE_B);
+    const unsigned lw2 = __builtin_amdgcn_readfirstlane(lw0 + 2u * (unsigned)BSTAGE_B);          // NSTG == 3
     const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);
     const float* b_rd0 = lds + kHPatchB / 4 + ld_off;
     const float* b_rd1 = b_rd0 + BSTAGE_B / 4;
+    const float* const b_rd2 = b_rd0 + 2 * (BSTAGE_B / 4);
+    (void)lw2; (void)b_rd2;
+    // NSTG == 3: weight requests THIS wave issues per step (a counted wait lets exactly the younger requests stay in flight)
+    const int nw = __builtin_amdgcn_readfirstlane(2 * (BFULL + ((BP > BFULL && b_last) ? 1 : 0)));
+    int pcnt = 0;                              // patch loads of the next chunk issued at step 0 of this one
+    (void)nw; (void)pcnt;
     const int rd_pix = 2 * wave * kHPW + lr;                // patch pixel of fragment 0, tap (0, 0)
 
     f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
@@ -125,9 +137,18 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
         for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
     f32x4 (&pmain)[MF][NF] = TWOL ? part : acc;
 
+#define PADEL_HP_WAITN(N_)                                                                                        \
+    do {                                                                                                          \
+        switch (N_) {                                                                                             \
+            case 0: wait_vm3<0>(); break;   case 2: wait_vm3<2>(); break;   case 3: wait_vm3<3>(); break;        \
+            case 4: wait_vm3<4>(); break;   case 5: wait_vm3<5>(); break;   case 6: wait_vm3<6>(); break;        \
+            case 7: wait_vm3<7>(); break;   case 8: wait_vm3<8>(); break;   case 10: wait_vm3<10>(); break;      \
+            default: wait_vm3<0>(); break;                                                                        \
+        }                                                                                                         \
+    } while (0)
 #define PADEL_HP_DMAB(SR_, SB_)                                                                                   \
     do {                                                                                                          \
-        const unsigned lw_ = ((SR_) & 1) ? lw1 : lw0;                                                             \
+        const unsigned lw_ = NSTG == 3 ? ((SR_) % 3 == 0 ? lw0 : (SR_) % 3 == 1 ? lw1 : lw2) : (((SR_) & 1) ? lw1 : lw0); \
         const unsigned sb_ = (SB_);                                                                               \
         PADEL_HP_DMAB1(0, sb_);                                                                                   \
         PADEL_HP_DMAB1(1, sb_ + 64u);                                                                             \
@@ -176,7 +197,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     } while (0)
 #define PADEL_HP_READB(T_)                                                                                        \
     do {                                                                                                          \
-        const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
+        const float* const br_ = NSTG == 3 ? ((T_) % 3 == 0 ? b_rd0 : (T_) % 3 == 1 ? b_rd1 : b_rd2) : (((T_) & 1) ? b_rd1 : b_rd0); \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
             wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256));          \
@@ -200,16 +221,18 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     do {                                                                                                          \
         h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
         if constexpr ((T_) > 0) PADEL_HP_READA(T_);     /* the planes are static inside a chunk: read under the wait */ \
-        wait_vm3<0>();                                                                                            \
+        if constexpr (NSTG == 3) { PADEL_HP_WAITN(nw + (((T_) == 1 || (T_) == 2) ? pcnt : 0)); } else wait_vm3<0>(); \
         if constexpr ((T_) == 0) hp_lds_fence();        /* this wave's plane writes have reached the LDS */         \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
         PADEL_HP_READB(T_);                                                                                       \
         if constexpr ((T_) == 0) PADEL_HP_READA(T_);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_HP_DMAB((T_) + 1, s_kb + ((T_) + 1) * 128u);                   \
-        if ((T_) == 0 && c + 1 < nch) PADEL_HP_LOAD(c + 1);                                                       \
-        if constexpr (TAIL) { if ((T_) == 0 && c + 1 == nch) PADEL_HP_TLOAD(); }                                  \
+        if constexpr (NSTG == 3) { PADEL_HP_DMAB((T_) + 2, s_kb + ((T_) + 2) * 128u); }   /* past the last step: slack bytes */ \
+        else { if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_HP_DMAB((T_) + 1, s_kb + ((T_) + 1) * 128u); }          \
+        if ((T_) == 0) pcnt = 0;                                                                                  \
+        if ((T_) == 0 && c + 1 < nch) { PADEL_HP_LOAD(c + 1); pcnt = kHPasses; }                                  \
+        if constexpr (TAIL) { if ((T_) == 0 && c + 1 == nch) { PADEL_HP_TLOAD(); pcnt = kHTailPasses; } }         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_HP_MFMA();                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -230,11 +253,12 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
 #define PADEL_HP_TSTEP(JT_)                                                                                       \
     do {                                                                                                          \
         h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
-        wait_vm3<0>();                                                                                            \
+        if constexpr (NSTG == 3) { PADEL_HP_WAITN(nw); } else wait_vm3<0>();                                      \
         hp_lds_fence();                                                                                           \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
-        if constexpr ((JT_) < 4) PADEL_HP_DMAB((JT_) + 1, s_kb + ((JT_) + 1) * 128u);                             \
+        if constexpr (NSTG == 3) { PADEL_HP_DMAB((JT_) + 2, s_kb + ((JT_) + 2) * 128u); }                         \
+        else { if constexpr ((JT_) < 4) PADEL_HP_DMAB((JT_) + 1, s_kb + ((JT_) + 1) * 128u); }                    \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_HP_TREADA(JT_);                                                                                     \
         PADEL_HP_READB(JT_);                                                                                      \
@@ -246,6 +270,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     unsigned s_kb = 0;
     if (!TAIL || nch > 0) PADEL_HP_LOAD(0); else PADEL_HP_TLOAD();
     PADEL_HP_DMAB(0, 0u);
+    if constexpr (NSTG == 3) PADEL_HP_DMAB(1, 128u);
     for (int c = 0; c < nch; ++c) {
         if (c > 0) {                          // every wave is done with the taps of chunk c - 1: the planes may be overwritten
             __builtin_amdgcn_s_barrier();
@@ -263,7 +288,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
 #pragma unroll
                 for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         }
-        { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; }
+        if constexpr (NSTG == 2) { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; }
         s_kb += 9u * 128u;
     }
     if constexpr (TAIL) {
@@ -296,6 +321,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
 #undef PADEL_HP_LOAD
 #undef PADEL_HP_DMAB
 #undef PADEL_HP_DMAB1
+#undef PADEL_HP_WAITN
 
     int mpix[MF];
 #pragma unroll
@@ -308,38 +334,40 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     h2_epilogue<MF, NF>(a, acc, cross, mpix, f0, lq, fast);
 }
 
-template <int NF, bool TAIL, bool UP>
+template <int NF, bool TAIL, bool UP, int NSTG>
 static hipError_t launch_hpt(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const int batch = a.M / (a.Ho * a.Wo);
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + NF - 1) / NF;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP, NSTG>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-template <int NF>
+template <int NF, int NSTG>
 static hipError_t launch_hp(const ConvArgs& a_in, hipStream_t s) {
     if (a_in.in2) {                    // absorbed upsample: whole 32-channel chunks only, even map size
         if ((a_in.cin & 31) || (a_in.up_c & 31) || a_in.up_c <= 0 || a_in.up_c > a_in.cin || ((a_in.H | a_in.W) & 1)) return hipErrorNotSupported;
-        return launch_hpt<NF, false, true>(a_in, s);
+        return launch_hpt<NF, false, true, NSTG>(a_in, s);
     }
-    if (a_in.cin & 16) return launch_hpt<NF, true, false>(a_in, s);
-    return launch_hpt<NF, false, false>(a_in, s);
+    if (a_in.cin & 16) return launch_hpt<NF, true, false, NSTG>(a_in, s);
+    return launch_hpt<NF, false, false, NSTG>(a_in, s);
 }
 
 bool conv_h2p_supported(const ConvArgs& a) {
     return a.ksize == 3 && a.stride == 1 && (a.cin & 15) == 0 && a.cin >= 16 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr;
 }
 
-// nf = channel fragments (of 16) per workgroup: 3 (8x16 pixels x 48 channels), 4, 6
+// nf = channel fragments (of 16) per workgroup: 3 (8x16 pixels x 48 channels), 4, 6; + 10: the 3-stage weight ring
 hipError_t launch_conv_h2p(const ConvArgs& a, int nf, hipStream_t s) {
     if (!conv_h2p_supported(a)) return hipErrorNotSupported;
     switch (nf) {
-        case 3: return launch_hp<3>(a, s);
-        case 4: return launch_hp<4>(a, s);
-        case 6: return launch_hp<6>(a, s);
+        case 3: return launch_hp<3, 2>(a, s);
+        case 4: return launch_hp<4, 2>(a, s);
+        case 6: return launch_hp<6, 2>(a, s);
+        case 13: return launch_hp<3, 3>(a, s);
+        case 14: return launch_hp<4, 3>(a, s);
     }
     return hipErrorNotSupported;
 }

@@ -714,7 +714,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             const bool use_tap = e->t.impl == 0 || f16;
             const bool use_bx3 = a.w3 != nullptr;
             int bm = 0, bn = 0;
-            if ((f16 || h2) && lv >= 300) { bm = 128; bn = (lv - 300) * 16; }
+            if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
             else if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
             else if (lv >= 300) { bm = 128; bn = (lv - 300) * 16; }          // patch kernel: 8 x 16 pixels x nf fragments
             else conv_variant_shape(lv >= 200 ? lv - 200 : lv, &bm, &bn);   // profile rows carry BM, BN of the workgroup tile

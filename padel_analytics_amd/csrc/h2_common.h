@@ -41,7 +41,7 @@ typedef _Float16 h2_h16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void h2_encode4(const f32x4 v, h16x4& h, h16x4& m, bool& bad) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        bad |= !(fabsf(v[2 * p]) <= kH2Max) | !(fabsf(v[2 * p + 1]) <= kH2Max);
+        bad = bad || !(fabsf(v[2 * p]) <= kH2Max) || !(fabsf(v[2 * p + 1]) <= kH2Max);
         const h2_f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * p], -kH2Max, kH2Max), __builtin_amdgcn_fmed3f(v[2 * p + 1], -kH2Max, kH2Max)};
         const h2_h16x2 hh = __builtin_convertvector(x, h2_h16x2);
         const h2_f32x2 rr = {(x[0] - (float)hh[0]) * kH2Scale, (x[1] - (float)hh[1]) * kH2Scale};

@@ -9,11 +9,14 @@
 //
 // decode_kernel : one thread per (image, anchor).  Reads the nc class logits (contiguous), keeps the
 //                 anchor iff max sigmoid > conf and its arg-max class is allowed, only then runs the
-//                 DFL softmax-expectation and dist2bbox, and appends to the image's candidate list
-//                 (one atomic per survivor; order is restored by the sort in nms_kernel).
+//                 DFL softmax-expectation and dist2bbox, and appends to the image's candidate list:
+//                 wave ballot + prefix popcount behind ONE atomic per wave (order is restored by the sort
+//                 in nms_kernel).
 // nms_kernel    : one workgroup per image: bitonic sort of 64-bit keys (~score | anchor | slot) ==
-//                 torchvision's stable descending sort, greedy IoU suppression, then the kept boxes /
-//                 keypoints are rescaled to source-frame pixels and written in rank order.
+//                 torchvision's stable descending sort; greedy IoU suppression as a bit matrix computed in
+//                 parallel (<= 4096 ranked candidates; row blocks in LDS) consumed by a one-wave scan — the
+//                 same decisions as the sequential loop, which stays as the path for longer lists; then
+//                 the kept boxes / keypoints are rescaled to source-frame pixels and written in rank order.
 #include "kernels.h"
 
 namespace padel {
@@ -23,57 +26,74 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __global__ void __launch_bounds__(256) decode_kernel(const DecodeArgs a) {
     const int b = blockIdx.y;
     const int ai = blockIdx.x * 256 + threadIdx.x;
-    if (ai >= a.A) return;
+    // no early exits: the compaction below is a wave-wide ballot (one atomic per WAVE, not per survivor)
+    bool pass = ai < a.A;
     int l = 0;
-    if (ai >= a.lv[2].anchor0) l = 2; else if (ai >= a.lv[1].anchor0) l = 1;
+    if (pass) { if (ai >= a.lv[2].anchor0) l = 2; else if (ai >= a.lv[1].anchor0) l = 1; }
     const HeadLevel lv = a.lv[l];
-    const int pix = ai - lv.anchor0;
+    const int pix = pass ? ai - lv.anchor0 : 0;
     const float* h = lv.buf + ((long long)b * lv.H * lv.W + pix) * a.cs;
 
     // class scores: max over sigmoid == sigmoid of max logit (monotone); arg-max in sigmoid space,
     // first index wins, like torch.max
     const float* cl = h + 64;
-    float mx = cl[0];
-    for (int c = 1; c < a.nc; ++c) mx = fmaxf(mx, cl[c]);
-    const float score = sigmoidf_(mx);
-    if (!(score > a.conf)) return;
+    float score = 0.0f;
     int cls = 0;
-    for (int c = 0; c < a.nc; ++c) {
-        if (sigmoidf_(cl[c]) == score) { cls = c; break; }
+    if (pass) {
+        float mx = cl[0];
+        for (int c = 1; c < a.nc; ++c) mx = fmaxf(mx, cl[c]);
+        score = sigmoidf_(mx);
+        pass = score > a.conf;
     }
-    if (a.n_classes > 0) {
-        bool ok = false;
-        for (int k = 0; k < a.n_classes; ++k) ok |= (a.classes[k] == cls);
-        if (!ok) return;
+    if (pass) {
+        for (int c = 0; c < a.nc; ++c) {
+            if (sigmoidf_(cl[c]) == score) { cls = c; break; }
+        }
+        if (a.n_classes > 0) {
+            bool ok = false;
+            for (int k = 0; k < a.n_classes; ++k) ok |= (a.classes[k] == cls);
+            pass = ok;
+        }
     }
-
-    // DFL: softmax over 16 bins, expectation with arange(16)
-    float d[4];
+    float bx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pass) {
+        // DFL: softmax over 16 bins, expectation with arange(16)
+        float d[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        float v[16];
-        float m = h[s * 16];
+        for (int s = 0; s < 4; ++s) {
+            float v[16];
+            float m = h[s * 16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { v[i] = h[s * 16 + i]; m = fmaxf(m, v[i]); }
-        float sum = 0.0f;
+            for (int i = 0; i < 16; ++i) { v[i] = h[s * 16 + i]; m = fmaxf(m, v[i]); }
+            float sum = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - m); sum += v[i]; }
-        float e = 0.0f;
+            for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - m); sum += v[i]; }
+            float e = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) e += (v[i] / sum) * (float)i;
-        d[s] = e;
+            for (int i = 0; i < 16; ++i) e += (v[i] / sum) * (float)i;
+            d[s] = e;
+        }
+        const float ax = (float)(pix % lv.W) + 0.5f, ay = (float)(pix / lv.W) + 0.5f;
+        const float st = (float)lv.stride;
+        // dist2bbox(xywh=True) * stride, then xywh2xyxy (same op order as upstream)
+        const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
+        const float cx = ((x1 + x2) / 2.0f) * st, cy = ((y1 + y2) / 2.0f) * st;
+        const float w = (x2 - x1) * st, hh = (y2 - y1) * st;
+        const float hw = w / 2.0f, hhh = hh / 2.0f;
+        bx[0] = cx - hw; bx[1] = cy - hhh; bx[2] = cx + hw; bx[3] = cy + hhh;
     }
-    const float ax = (float)(pix % lv.W) + 0.5f, ay = (float)(pix / lv.W) + 0.5f;
-    const float st = (float)lv.stride;
-    // dist2bbox(xywh=True) * stride, then xywh2xyxy (same op order as upstream)
-    const float x1 = ax - d[0], y1 = ay - d[1], x2 = ax + d[2], y2 = ay + d[3];
-    const float cx = ((x1 + x2) / 2.0f) * st, cy = ((y1 + y2) / 2.0f) * st;
-    const float w = (x2 - x1) * st, hh = (y2 - y1) * st;
-    const float hw = w / 2.0f, hhh = hh / 2.0f;
-
-    const int slot = atomicAdd(&a.cand_cnt[b], 1);
+    // stream compaction: survivors of a wave take consecutive slots behind ONE atomic (their order inside the list does
+    // not matter: nms_kernel's sort key carries the anchor index)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(pass);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&a.cand_cnt[b], __builtin_popcountll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (!pass) return;
+    const int slot = base + __builtin_popcountll(m & ((1ull << lane) - 1ull));
     float* o = a.cand + ((long long)b * a.A + slot) * 6;
-    o[0] = cx - hw; o[1] = cy - hhh; o[2] = cx + hw; o[3] = cy + hhh; o[4] = score; o[5] = (float)cls;
+    o[0] = bx[0]; o[1] = bx[1]; o[2] = bx[2]; o[3] = bx[3]; o[4] = score; o[5] = (float)cls;
     a.cand_idx[(long long)b * a.A + slot] = ai;
 }
 
@@ -89,10 +109,13 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
 #define NMS_THREADS 1024
 #define NMS_LDS_KEYS 8192          // bitonic sort in LDS up to this many candidates per image (64 KB), in HBM beyond
 #define NMS_LDS_SUPP 16384          // suppression flags of up to this many ranked candidates live in LDS
+#define NMS_MASK_MAX 4096           // ranked candidates the bit-mask NMS handles (one u64 word of flags per lane of a wave)
 
 __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
     __shared__ uint64_t skeys[NMS_LDS_KEYS];
     __shared__ uint8_t ssupp[NMS_LDS_SUPP];
+    __shared__ float4 sbox[NMS_MASK_MAX];      // bit-mask NMS: ranked boxes, class offset applied
+    __shared__ int s_kept, s_done;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
     int n = a.cand_cnt[b];
@@ -137,6 +160,65 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
 
     // greedy suppression in rank order; boxes are offset by cls * 7680 like upstream (agnostic=False)
     int kept = 0;
+    if (ne <= NMS_MASK_MAX) {
+        // SURVEY K9 — the IoU decisions are computed IN PARALLEL as a bit matrix, only the scan that consumes them is
+        // serial (what torchvision's device NMS does).  Rows are produced in blocks that fit the 64 KB the sort keys no
+        // longer need: mask[(i - r0) * words + w] bit jj = IoU(rank i, rank w * 64 + jj) > iou, for j > i.  One wave then
+        // walks the block: lane l keeps word l of the "removed" set; a kept candidate ORs its row into it.
+        const int words = (ne + 63) >> 6;                       // <= 64
+        for (int i = tid; i < ne; i += NMS_THREADS) {
+            const float* bi = cand + order[i] * 6;
+            const float off = bi[5] * 7680.0f;
+            sbox[i] = make_float4(bi[0] + off, bi[1] + off, bi[2] + off, bi[3] + off);
+        }
+        if (tid == 0) { s_kept = 0; s_done = 0; }
+        __syncthreads();
+        uint64_t* mask = skeys;
+        const int rows_per_block = words > 0 ? NMS_LDS_KEYS / words : 1;
+        unsigned long long removed = 0ull;                       // wave 0, lane l: flags of ranks 64 l .. 64 l + 63
+        for (int r0 = 0; r0 < ne; r0 += rows_per_block) {
+            const int r1 = min(ne, r0 + rows_per_block);
+            for (int idx = tid; idx < (r1 - r0) * words; idx += NMS_THREADS) {
+                const int i = r0 + idx / words, w = idx - (idx / words) * words;
+                unsigned long long bits = 0ull;
+                if (w * 64 + 63 > i) {
+                    const float4 bi = sbox[i];
+                    const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
+                    const int j0 = max(w * 64, i + 1), j1 = min(ne, w * 64 + 64);
+                    for (int j = j0; j < j1; ++j) {
+                        const float4 bj = sbox[j];
+                        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+                        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+                        const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+                        const float inter = ww * hh;
+                        const float ovr = inter / (iarea + (bj.z - bj.x) * (bj.w - bj.y) - inter);
+                        if (ovr > a.iou) bits |= 1ull << (j & 63);
+                    }
+                }
+                mask[idx] = bits;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                int k = s_kept;
+                bool done = false;
+                for (int i = r0; i < r1; ++i) {
+                    const int w = i >> 6;
+                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, w);
+                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), w);
+                    const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
+                    if ((rw >> (i & 63)) & 1ull) continue;
+                    if (tid == 0) order[k] = order[i];              // compacted list of kept slots (k <= i: consumed already)
+                    ++k;
+                    if (k >= a.max_det) { done = true; break; }
+                    if (tid < words) removed |= mask[(i - r0) * words + tid];
+                }
+                if (tid == 0) { s_kept = k; s_done = done ? 1 : 0; }
+            }
+            __syncthreads();
+            if (s_done) break;
+        }
+        kept = s_kept;
+    } else {
     for (int i = 0; i < ne; ++i) {
         if (supp[i]) continue;                       // uniform: every thread reads the same byte
         const int slot_i = order[i];
@@ -160,6 +242,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
             if (ovr > a.iou) supp[j] = 1;
         }
         __syncthreads();
+    }
     }
     __syncthreads();
     if (tid == 0) a.out_cnt[b] = kept;
