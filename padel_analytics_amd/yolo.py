@@ -115,9 +115,12 @@ class YOLO:
             self._ensure_model()
         elif dev == "cpu":
             # runner.py:230 parks each tracker's model on the host after it ran (the reference targets 8 GB cards,
-            # README.md:38-39).  With 288 GB of HBM the weights and the activation plan simply stay resident:
-            # re-planning per run would cost more than the parking saves.  close() releases them.
-            pass
+            # README.md:38-39).  With 288 GB of HBM the weights and the activation plan stay resident by default:
+            # re-planning per run would cost more than the parking saves.  PADEL_RELEASE_ON_CPU=1 makes .to("cpu") give
+            # the HBM back (weights + arena: close()), like the reference; the next .to("cuda") re-uploads.
+            import os
+            if os.environ.get("PADEL_RELEASE_ON_CPU") == "1":
+                self.close()
         else:
             raise ValueError(f"unknown device {device!r}")
         return self

@@ -1,10 +1,10 @@
-"""GPU unit test of the conv kernels through the C-ABI: every tile variant of the two kernel generations that ship —
-the default tap-unrolled LDS-DMA kernels (conv_tap.hip) and the register-staged LDS kernel kept as their cross-check
-(conv_lds.hip) — against torch.nn.functional.conv2d (fp64 CPU), on shapes that exercise stride 2, 1x1, the
-16-channel K tail (cin % 32 == 16) including the full-chunk -> tail wrap of the tap kernel's request ring
-(conv_tap.hip "wrap_off1"), partial channel tiles (cout = 80 -> 5 fragments), the M tail, the fused residual and
-every activation; and against each other BITWISE (same K order + same accumulation blocks => identical results).
-The three retired generations live in tools/legacy_conv/ and are no longer built."""
+"""GPU unit test of the fp32-storage conv kernels through the C-ABI (the h2 kernels — the default arithmetic since round 3
+— have their own file, tests/test_gpu_h2.py): every tile variant of the fp32-input MFMA generations (tap-unrolled LDS-DMA
+kernels conv_tap.hip, and the register-staged LDS kernel conv_lds.hip kept as their cross-check) and of the bf16x3 kernels
+(conv_tap_bx3.hip / conv_patch_bx3.hip: the full-range fallback of h2) against torch.nn.functional.conv2d (fp64 CPU), on
+shapes that exercise stride 2, 1x1, the 16-channel K tail (cin % 32 == 16) including the full-chunk -> tail wrap of the tap
+kernel's request ring, partial channel tiles (cout = 80 -> 5 fragments), the M tail, the fused residual and every
+activation; each family BITWISE equal across its own tiles (same K order + same accumulation blocks)."""
 import numpy as np
 import pytest
 import torch
