@@ -42,21 +42,23 @@ __device__ __forceinline__ void hp_lds_fence() { asm volatile("s_waitcnt lgkmcnt
 
 }  // namespace
 
-// NSTG: stages of the weight ring.  2: a tap's weights are requested one step ahead and every step waits for ALL of its
-// wave's requests — the patch prefetch of the next chunk included, which therefore gets one step (~300 matrix-pipe
-// cycles) of latency cover.  3: weights two steps ahead, counted waits (vmcnt(n) with n = what was requested after the
-// data needed now): weights get two steps, the patch loads three.
-template <int NF, bool TAIL, bool UP, int NSTG>
-__global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel(const ConvArgs a) {
+// PIPE: software-pipelined tap walk.  The plain schedule serialises, per tap step and wave, [wait, barrier, operand
+// reads (LDS latency), weight requests] in front of a burst of 3 MF NF MFMAs: ~220 cycles that only OTHER waves can
+// cover (measured: matrix pipe busy 0.56 where the six-product bf16x3 kernel, same structure and twice the burst, had
+// 0.72).  PIPE splits the burst: after the correction products of step T the wave passes the barrier of step T + 1 and
+// issues the operand reads of T + 1 into a SECOND register set, then runs the main products of step T under their
+// latency.  Costs 40 more VGPRs (2 waves per SIMD instead of 3).  Same products in the same order per accumulator:
+// bitwise equal to the plain schedule.
+template <int NF, bool TAIL, bool UP, bool PIPE>
+__global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h2p_kernel(const ConvArgs a) {
     constexpr int MF = 2;
     constexpr bool TWOL = NF <= 4;               // two-level main accumulation (part -> acc once per chunk) where registers allow
     constexpr int BN = NF * 16;
     constexpr int BSTAGE_B = 2 * BN * 64;
     constexpr int BP = (BN + 63) / 64, BFULL = BN / 64;
     static_assert(BP <= 2, "weights in at most 2 passes of 64 rows");
-    static_assert(NSTG == 2 || NSTG == 3, "2- or 3-stage weight ring");
-    static_assert(kHPatchB + NSTG * BSTAGE_B <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) float lds[(kHPatchB + NSTG * BSTAGE_B) / 4];
+    static_assert(kHPatchB + 2 * BSTAGE_B <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) float lds[(kHPatchB + 2 * BSTAGE_B) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -118,16 +120,9 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     const bool b_last = BP > BFULL && (BFULL * 64 + wave * 16 < BN);
     unsigned lw0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds + (unsigned)kHPatchB + wave * 1024u);
     unsigned lw1 = __builtin_amdgcn_readfirstlane(lw0 + (unsigned)BSTAGE_B);
-    const unsigned lw2 = __builtin_amdgcn_readfirstlane(lw0 + 2u * (unsigned)BSTAGE_B);          // NSTG == 3
     const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);
     const float* b_rd0 = lds + kHPatchB / 4 + ld_off;
     const float* b_rd1 = b_rd0 + BSTAGE_B / 4;
-    const float* const b_rd2 = b_rd0 + 2 * (BSTAGE_B / 4);
-    (void)lw2; (void)b_rd2;
-    // NSTG == 3: weight requests THIS wave issues per step (a counted wait lets exactly the younger requests stay in flight)
-    const int nw = __builtin_amdgcn_readfirstlane(2 * (BFULL + ((BP > BFULL && b_last) ? 1 : 0)));
-    int pcnt = 0;                              // patch loads of the next chunk issued at step 0 of this one
-    (void)nw; (void)pcnt;
     const int rd_pix = 2 * wave * kHPW + lr;                // patch pixel of fragment 0, tap (0, 0)
 
     f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
@@ -137,18 +132,9 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
         for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
     f32x4 (&pmain)[MF][NF] = TWOL ? part : acc;
 
-#define PADEL_HP_WAITN(N_)                                                                                        \
-    do {                                                                                                          \
-        switch (N_) {                                                                                             \
-            case 0: wait_vm3<0>(); break;   case 2: wait_vm3<2>(); break;   case 3: wait_vm3<3>(); break;        \
-            case 4: wait_vm3<4>(); break;   case 5: wait_vm3<5>(); break;   case 6: wait_vm3<6>(); break;        \
-            case 7: wait_vm3<7>(); break;   case 8: wait_vm3<8>(); break;   case 10: wait_vm3<10>(); break;      \
-            default: wait_vm3<0>(); break;                                                                        \
-        }                                                                                                         \
-    } while (0)
 #define PADEL_HP_DMAB(SR_, SB_)                                                                                   \
     do {                                                                                                          \
-        const unsigned lw_ = NSTG == 3 ? ((SR_) % 3 == 0 ? lw0 : (SR_) % 3 == 1 ? lw1 : lw2) : (((SR_) & 1) ? lw1 : lw0); \
+        const unsigned lw_ = ((SR_) & 1) ? lw1 : lw0;                                                             \
         const unsigned sb_ = (SB_);                                                                               \
         PADEL_HP_DMAB1(0, sb_);                                                                                   \
         PADEL_HP_DMAB1(1, sb_ + 64u);                                                                             \
@@ -197,7 +183,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     } while (0)
 #define PADEL_HP_READB(T_)                                                                                        \
     do {                                                                                                          \
-        const float* const br_ = NSTG == 3 ? ((T_) % 3 == 0 ? b_rd0 : (T_) % 3 == 1 ? b_rd1 : b_rd2) : (((T_) & 1) ? b_rd1 : b_rd0); \
+        const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
             wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256));          \
@@ -214,6 +200,87 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
             pmain[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], pmain[f][j], 0, 0, 0);             \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
+    // ---- PIPE: operand sets indexed by step parity
+#define PADEL_HP_READA2(T_, S_)                                                                                   \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
+            const char* p_ = ldsb + hp_off(rd_pix + (f + (T_) / 3) * kHPW + (T_) % 3, lq);                        \
+            ah2[S_][f] = *reinterpret_cast<const h16x8*>(p_);                                                     \
+            am2[S_][f] = *reinterpret_cast<const h16x8*>(p_ + kHPlaneB);                                          \
+        }                                                                                                         \
+    } while (0)
+#define PADEL_HP_TREADA2(JT_, S_)                                                                                 \
+    do {                                                                                                          \
+        constexpr int ta_ = 2 * (JT_), tb_ = 2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8;                               \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
+            const int pa_ = rd_pix + (f + ta_ / 3) * kHPW + ta_ % 3, pb_ = rd_pix + (f + tb_ / 3) * kHPW + tb_ % 3; \
+            const char* p_ = ldsb + hp_tail_off((lq >> 1) ? pb_ : pa_, lq & 1);                                   \
+            ah2[S_][f] = *reinterpret_cast<const h16x8*>(p_);                                                     \
+            am2[S_][f] = *reinterpret_cast<const h16x8*>(p_ + kHPlaneB);                                          \
+        }                                                                                                         \
+    } while (0)
+#define PADEL_HP_READB2(T_, S_)                                                                                   \
+    do {                                                                                                          \
+        const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
+            wh2[S_][j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));               \
+            wm2[S_][j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256));     \
+        }                                                                                                         \
+    } while (0)
+#define PADEL_HP_MFMA_CROSS(S_)                                                                                   \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh2[S_][j], am2[S_][f], cross[f][j], 0, 0, 0);   \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm2[S_][j], ah2[S_][f], cross[f][j], 0, 0, 0);   \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+#define PADEL_HP_MFMA_MAIN(S_)                                                                                    \
+    do {                                                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            pmain[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh2[S_][j], ah2[S_][f], pmain[f][j], 0, 0, 0);   \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+    } while (0)
+    // entry of a block of steps (a chunk's 9 taps or the tail's 5 pairs): this wave's plane writes are fenced and the weights
+    // of step 0 — requested during the previous block / the prologue — have landed: barrier, operands of step 0 into set 0,
+    // request the weights of step 1 (the stage they go to was last read before the correction products of the previous
+    // block's last step, i.e. before every wave reached this barrier)
+#define PADEL_HP_PENTRY(READA0_)                                                                                  \
+    do {                                                                                                          \
+        wait_vm3<0>();                                                                                            \
+        hp_lds_fence();                                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        asm volatile("" ::: "memory");                                                                            \
+        PADEL_HP_READB2(0, 0);                                                                                    \
+        READA0_;                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_HP_DMAB(1, s_kb + 128u);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    // step T_ of a block of NT_ steps (its operands sit in set T_ & 1): correction products; then — for step T_ + 1 — wait
+    // for its weights, barrier, operand reads into the other set, request of the weights two steps ahead (the first ones of
+    // the next block when MORE_) and, at T_ == 0, whatever EXTRA0_ prefetches; then the main products, under the latency
+    // of those reads
+#define PADEL_HP_PSTEP(T_, NT_, READNEXT_, MORE_, EXTRA0_)                                                        \
+    do {                                                                                                          \
+        PADEL_HP_MFMA_CROSS((T_) & 1);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if constexpr ((T_) + 1 < (NT_)) {                                                                         \
+            wait_vm3<0>();                                                                                        \
+            __builtin_amdgcn_s_barrier();                                                                         \
+            asm volatile("" ::: "memory");                                                                        \
+            PADEL_HP_READB2((T_) + 1, ((T_) + 1) & 1);                                                            \
+            READNEXT_;                                                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            if ((T_) + 2 < (NT_) || (MORE_)) PADEL_HP_DMAB((T_) + 2, s_kb + ((T_) + 2) * 128u);                   \
+            if constexpr ((T_) == 0) { EXTRA0_; }                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+        PADEL_HP_MFMA_MAIN((T_) & 1);                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
     // tap step T of the current chunk: its weights (requested one step earlier) have landed for every wave after the
     // barrier, which also releases the other weight stage (read in step T - 1) for the request of step T + 1; step 0
     // additionally publishes the freshly written planes and requests the next chunk's patch
@@ -221,18 +288,16 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     do {                                                                                                          \
         h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
         if constexpr ((T_) > 0) PADEL_HP_READA(T_);     /* the planes are static inside a chunk: read under the wait */ \
-        if constexpr (NSTG == 3) { PADEL_HP_WAITN(nw + (((T_) == 1 || (T_) == 2) ? pcnt : 0)); } else wait_vm3<0>(); \
+        wait_vm3<0>();                                                                                            \
         if constexpr ((T_) == 0) hp_lds_fence();        /* this wave's plane writes have reached the LDS */         \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
         PADEL_HP_READB(T_);                                                                                       \
         if constexpr ((T_) == 0) PADEL_HP_READA(T_);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if constexpr (NSTG == 3) { PADEL_HP_DMAB((T_) + 2, s_kb + ((T_) + 2) * 128u); }   /* past the last step: slack bytes */ \
-        else { if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_HP_DMAB((T_) + 1, s_kb + ((T_) + 1) * 128u); }          \
-        if ((T_) == 0) pcnt = 0;                                                                                  \
-        if ((T_) == 0 && c + 1 < nch) { PADEL_HP_LOAD(c + 1); pcnt = kHPasses; }                                  \
-        if constexpr (TAIL) { if ((T_) == 0 && c + 1 == nch) { PADEL_HP_TLOAD(); pcnt = kHTailPasses; } }         \
+        if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_HP_DMAB((T_) + 1, s_kb + ((T_) + 1) * 128u);                   \
+        if ((T_) == 0 && c + 1 < nch) PADEL_HP_LOAD(c + 1);                                                       \
+        if constexpr (TAIL) { if ((T_) == 0 && c + 1 == nch) PADEL_HP_TLOAD(); }                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_HP_MFMA();                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -253,12 +318,11 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
 #define PADEL_HP_TSTEP(JT_)                                                                                       \
     do {                                                                                                          \
         h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
-        if constexpr (NSTG == 3) { PADEL_HP_WAITN(nw); } else wait_vm3<0>();                                      \
+        wait_vm3<0>();                                                                                            \
         hp_lds_fence();                                                                                           \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
-        if constexpr (NSTG == 3) { PADEL_HP_DMAB((JT_) + 2, s_kb + ((JT_) + 2) * 128u); }                         \
-        else { if constexpr ((JT_) < 4) PADEL_HP_DMAB((JT_) + 1, s_kb + ((JT_) + 1) * 128u); }                    \
+        if constexpr ((JT_) < 4) PADEL_HP_DMAB((JT_) + 1, s_kb + ((JT_) + 1) * 128u);                             \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_HP_TREADA(JT_);                                                                                     \
         PADEL_HP_READB(JT_);                                                                                      \
@@ -270,7 +334,64 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     unsigned s_kb = 0;
     if (!TAIL || nch > 0) PADEL_HP_LOAD(0); else PADEL_HP_TLOAD();
     PADEL_HP_DMAB(0, 0u);
-    if constexpr (NSTG == 3) PADEL_HP_DMAB(1, 128u);
+    if constexpr (PIPE) {
+        h16x8 ah2[2][MF], am2[2][MF], wh2[2][NF], wm2[2][NF];
+        for (int c = 0; c < nch; ++c) {
+            if (c > 0) {                          // every wave is done with the taps of chunk c - 1: the planes may be overwritten
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < kHPasses; ++i)
+                if (i * 256 + 255 < kHItems || i * 256 + tid < kHItems)
+                    *reinterpret_cast<hp_u32x4*>(ldsb + wr0 + hp_off(i * 32 + (tid >> 3), wr_q)) = pre[i];
+            const bool more = c + 1 < nch || TAIL;
+            PADEL_HP_PENTRY(PADEL_HP_READA2(0, 0));
+#define PADEL_HP_PREFETCH() do { if (c + 1 < nch) PADEL_HP_LOAD(c + 1); if constexpr (TAIL) { if (c + 1 == nch) PADEL_HP_TLOAD(); } } while (0)
+            PADEL_HP_PSTEP(0, 9, PADEL_HP_READA2(1, 1), more, PADEL_HP_PREFETCH());
+            PADEL_HP_PSTEP(1, 9, PADEL_HP_READA2(2, 0), more, (void)0);
+            PADEL_HP_PSTEP(2, 9, PADEL_HP_READA2(3, 1), more, (void)0);
+            PADEL_HP_PSTEP(3, 9, PADEL_HP_READA2(4, 0), more, (void)0);
+            PADEL_HP_PSTEP(4, 9, PADEL_HP_READA2(5, 1), more, (void)0);
+            PADEL_HP_PSTEP(5, 9, PADEL_HP_READA2(6, 0), more, (void)0);
+            PADEL_HP_PSTEP(6, 9, PADEL_HP_READA2(7, 1), more, (void)0);
+            PADEL_HP_PSTEP(7, 9, PADEL_HP_READA2(8, 0), more, (void)0);
+            PADEL_HP_PSTEP(8, 9, (void)0, more, (void)0);
+#undef PADEL_HP_PREFETCH
+            if constexpr (TWOL) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+            }
+            { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; }
+            s_kb += 9u * 128u;
+        }
+        if constexpr (TAIL) {
+            if (nch > 0) {
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+#pragma unroll
+            for (int i = 0; i < kHTailPasses; ++i) {
+                const int item = i * 256 + tid;
+                const int pp = item >> 2, pc = item & 3;
+                if (item < kHNPix * 4) *reinterpret_cast<hp_u32x4*>(ldsb + (pc >> 1) * kHPlaneB + hp_tail_off(pp, pc & 1)) = pre[i];
+            }
+            PADEL_HP_PENTRY(PADEL_HP_TREADA2(0, 0));
+            PADEL_HP_PSTEP(0, 5, PADEL_HP_TREADA2(1, 1), false, (void)0);
+            PADEL_HP_PSTEP(1, 5, PADEL_HP_TREADA2(2, 0), false, (void)0);
+            PADEL_HP_PSTEP(2, 5, PADEL_HP_TREADA2(3, 1), false, (void)0);
+            PADEL_HP_PSTEP(3, 5, PADEL_HP_TREADA2(4, 0), false, (void)0);
+            PADEL_HP_PSTEP(4, 5, (void)0, false, (void)0);
+            if constexpr (TWOL) {
+#pragma unroll
+                for (int f = 0; f < MF; ++f)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];
+            }
+        }
+    } else {
     for (int c = 0; c < nch; ++c) {
         if (c > 0) {                          // every wave is done with the taps of chunk c - 1: the planes may be overwritten
             __builtin_amdgcn_s_barrier();
@@ -288,7 +409,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
 #pragma unroll
                 for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         }
-        if constexpr (NSTG == 2) { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; }
+        { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; }
         s_kb += 9u * 128u;
     }
     if constexpr (TAIL) {
@@ -310,8 +431,16 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
                 for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];
         }
     }
+    }
     wait_vm3<0>();
 #undef PADEL_HP_TSTEP
+#undef PADEL_HP_PSTEP
+#undef PADEL_HP_PENTRY
+#undef PADEL_HP_MFMA_MAIN
+#undef PADEL_HP_MFMA_CROSS
+#undef PADEL_HP_READB2
+#undef PADEL_HP_TREADA2
+#undef PADEL_HP_READA2
 #undef PADEL_HP_TLOAD
 #undef PADEL_HP_TREADA
 #undef PADEL_HP_READA
@@ -321,7 +450,6 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
 #undef PADEL_HP_LOAD
 #undef PADEL_HP_DMAB
 #undef PADEL_HP_DMAB1
-#undef PADEL_HP_WAITN
 
     int mpix[MF];
 #pragma unroll
@@ -334,40 +462,40 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP) ? 3 : 2) conv_h2p_kernel
     h2_epilogue<MF, NF>(a, acc, cross, mpix, f0, lq, fast);
 }
 
-template <int NF, bool TAIL, bool UP, int NSTG>
+template <int NF, bool TAIL, bool UP, bool PIPE>
 static hipError_t launch_hpt(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const int batch = a.M / (a.Ho * a.Wo);
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + NF - 1) / NF;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP, NSTG>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP, PIPE>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
-template <int NF, int NSTG>
+template <int NF, bool PIPE>
 static hipError_t launch_hp(const ConvArgs& a_in, hipStream_t s) {
     if (a_in.in2) {                    // absorbed upsample: whole 32-channel chunks only, even map size
         if ((a_in.cin & 31) || (a_in.up_c & 31) || a_in.up_c <= 0 || a_in.up_c > a_in.cin || ((a_in.H | a_in.W) & 1)) return hipErrorNotSupported;
-        return launch_hpt<NF, false, true, NSTG>(a_in, s);
+        return launch_hpt<NF, false, true, PIPE>(a_in, s);
     }
-    if (a_in.cin & 16) return launch_hpt<NF, true, false, NSTG>(a_in, s);
-    return launch_hpt<NF, false, false, NSTG>(a_in, s);
+    if (a_in.cin & 16) return launch_hpt<NF, true, false, PIPE>(a_in, s);
+    return launch_hpt<NF, false, false, PIPE>(a_in, s);
 }
 
 bool conv_h2p_supported(const ConvArgs& a) {
     return a.ksize == 3 && a.stride == 1 && (a.cin & 15) == 0 && a.cin >= 16 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr;
 }
 
-// nf = channel fragments (of 16) per workgroup: 3 (8x16 pixels x 48 channels), 4, 6; + 10: the 3-stage weight ring
+// nf = channel fragments (of 16) per workgroup: 3 (8x16 pixels x 48 channels), 4, 6; + 10: the software-pipelined schedule
 hipError_t launch_conv_h2p(const ConvArgs& a, int nf, hipStream_t s) {
     if (!conv_h2p_supported(a)) return hipErrorNotSupported;
     switch (nf) {
-        case 3: return launch_hp<3, 2>(a, s);
-        case 4: return launch_hp<4, 2>(a, s);
-        case 6: return launch_hp<6, 2>(a, s);
-        case 13: return launch_hp<3, 3>(a, s);
-        case 14: return launch_hp<4, 3>(a, s);
+        case 3: return launch_hp<3, false>(a, s);
+        case 4: return launch_hp<4, false>(a, s);
+        case 6: return launch_hp<6, false>(a, s);
+        case 13: return launch_hp<3, true>(a, s);
+        case 14: return launch_hp<4, true>(a, s);
     }
     return hipErrorNotSupported;
 }
