@@ -117,7 +117,9 @@ def make_state_dict(name, cfg, frames):
     """Setup (untimed): seeded synthetic checkpoint with data-calibrated BatchNorm statistics
     (oracle/synth_weights.py — weight synthesis, not part of the measured path).  1280-input models
     are calibrated on a 640x640 centre crop of the network input (same statistics, 4x cheaper)."""
-    key = (name, cfg["scale"])
+    import zlib
+    # (the fingerprint of the calibration frames is part of the key: tests build the same tracker for different clips)
+    key = (name, cfg["scale"], cfg["nc"], cfg["kpt"], cfg["imgsz"], zlib.crc32(np.ascontiguousarray(frames[:2]).tobytes()))
     if key in _SD_CACHE:
         return _SD_CACHE[key]
     from oracle import synth_weights, yolov8_ref as ref

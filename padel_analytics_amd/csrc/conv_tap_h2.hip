@@ -373,6 +373,11 @@ int choose_conv_h2_variant(const ConvArgs& a) {
             const float sc = v.sp * fill * (float)blocks / (256.f * (float)per_cu);
             if (sc > best) { best = sc; bv = 300 + v.nf; }
         }
+        // cin % 32 == 16 (yolov8m's 48-channel P2 layers): 14 short steps per tile — there the software-pipelined schedule
+        // (313: operand reads of the next step under this step's main products) measured +6..9 % although it runs 2 waves
+        // per SIMD instead of 3; on whole-chunk layers it loses 10-15 % (profiles/conv_h2_sweep_r3f_pipe.txt).  Same
+        // products in the same order: results do not depend on the choice.
+        if (bv == 303 && (a.cin & 16)) bv = 313;
     }
     return bv;
 }

@@ -85,7 +85,7 @@ def _check(tag, sd, nc, kpt, srcs, got, conf, iou, imgsz, tight=False):
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "parity_report.json"), "w") as f:
-            json.dump(REPORT, f, indent=1)
+            json.dump(REPORT, f, indent=1, default=str)
     bound = TOL_PX if tight else max(TOL_PX, 4 * floor["worst_px"])
     assert g64["worst_px"] <= bound, f"{tag}: engine vs exact {g64['worst_px']:.3e} px > {bound:.3e} (floor {floor['worst_px']:.3e})"
     bound32 = TOL_PX if tight else max(TOL_PX, 5 * floor["worst_px"])
@@ -132,6 +132,36 @@ def test_detect_parity_tight(gpu_engine, scale, mode):
     m, got = _engine_predict(gpu_engine, sd, 80, None, frames, mode=mode, imgsz=640, conf=0.5, iou=0.7, classes=[0])
     _check(f"detect-{scale}-tight [{mode}]", sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
     m.close()
+
+
+def test_detect_m_tight_ratio_over_seeds(gpu_engine):
+    """Is the engine noisier than the reference's own fp32 arithmetic?  One clip gives one draw of a heavy-tailed ratio
+    (L-inf over ~60 detections: 0.6 .. 3 on the same kernels, profiles/parity_report_r2.json / _r3.json), so the
+    statement is made over several independently seeded clips and checkpoints of the bench's players graph (yolov8m,
+    low-noise heads): the GEOMETRIC MEAN of engine-vs-fp64 / fp32-oracle-vs-fp64 must not exceed 1 (RMS) / 1.15 (L-inf)."""
+    ratios_rms, ratios_linf = [], []
+    for fseed, wseed in ((13, 17), (3, 5), (21, 23), (31, 37), (41, 43)):
+        frames = synth.synthetic_frames(3, 720, 1280, seed=fseed)
+        srcs = [f[..., ::-1] for f in frames]
+        sd = _calib("m", 80, None, srcs, 640, 0.5, seed=wseed, dfl_scale=0.02)
+        m, got = _engine_predict(gpu_engine, sd, 80, None, frames, imgsz=640, conf=0.5, iou=0.7, classes=[0])
+        m.close()
+        tag = f"detect-m-tight seeds {fseed}/{wseed} [{E.fp32_mode()}]"
+        _check(tag, sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
+        r = REPORT[tag]
+        ratios_rms.append(r["rms_engine_vs_fp64_px"] / r["rms_fp32_oracle_vs_fp64_px"])
+        ratios_linf.append(r["engine_vs_fp64_px"] / r["fp32_oracle_vs_fp64_px"])
+    gm = lambda v: float(np.exp(np.mean(np.log(v))))
+    REPORT[f"detect-m-tight over 5 seeds [{E.fp32_mode()}]"] = {
+        "rms_ratio_engine_over_oracle": [round(x, 3) for x in ratios_rms], "linf_ratio_engine_over_oracle": [round(x, 3) for x in ratios_linf],
+        "geomean_rms_ratio": round(gm(ratios_rms), 3), "geomean_linf_ratio": round(gm(ratios_linf), 3)}
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, default=str)
+    print("detect-m-tight over seeds: RMS ratios", ratios_rms, "L-inf ratios", ratios_linf)
+    assert gm(ratios_rms) <= 1.0, ratios_rms
+    assert gm(ratios_linf) <= 1.15, ratios_linf
 
 
 @pytest.mark.parametrize("scale,S,kpt", [("n", 640, (13, 3)), ("n", 1280, (13, 3)), ("n", 640, (13, 2)), ("m", 640, (13, 3))])
