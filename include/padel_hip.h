@@ -143,6 +143,11 @@ int pa_model_set_max_batch(pa_model* m, int max_batch);
  * logical buffers it replaces */
 int pa_model_plan_bytes(pa_model* m, size_t* arena_bytes, size_t* logical_bytes);
 
+/* tests: overwrite every byte of the planned activation arena (0xFF = NaN patterns in fp32 and fp16).  A following
+ * inference must be unaffected: no kernel may read a byte nobody wrote since (h2 / fp32 graphs; fp16 graphs rely on
+ * zero-initialised pad channels and are excluded)                                                            */
+int pa_model_fill_arena(pa_model* m, int byte_value);
+
 enum pa_pre_mode {
     PA_PRE_LETTERBOX = 0,   /* ultralytics LetterBox(auto, stride 32), cv2 INTER_LINEAR, pad 114    */
     PA_PRE_PIL_STRETCH = 1  /* PIL Image.resize((imgsz, imgsz)) bicubic, then LetterBox == identity */

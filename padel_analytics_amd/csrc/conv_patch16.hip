@@ -87,7 +87,7 @@ __device__ __forceinline__ void p16_epilogue_case(const ConvArgs& a, const p16_f
                 } else {
                     p16_h4 o;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)v[r];
+                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);     // saturate: no infinities in HBM
                     *reinterpret_cast<p16_h4*>(reinterpret_cast<_Float16*>(a.out) + (long long)m * a.out_cs + a.out_choff + co0) = o;
                 }
             } else {
@@ -98,7 +98,7 @@ __device__ __forceinline__ void p16_epilogue_case(const ConvArgs& a, const p16_f
                     float x = v[r];
                     if (RES) x += (float)res[(long long)m * a.res_cs + a.res_choff + co];
                     if (a.out_f32) a.out[(long long)m * a.out_cs + a.out_choff + co] = x;
-                    else reinterpret_cast<_Float16*>(a.out)[(long long)m * a.out_cs + a.out_choff + co] = (_Float16)x;
+                    else reinterpret_cast<_Float16*>(a.out)[(long long)m * a.out_cs + a.out_choff + co] = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
                 }
             }
         }

@@ -1021,6 +1021,16 @@ int pa_model_plan_bytes(pa_model* m, size_t* arena_bytes, size_t* logical_bytes)
     return 0;
 }
 
+int pa_model_fill_arena(pa_model* m, int byte_value) {
+    if (!m) return 1;
+    pa_engine* e = m->e;
+    if (!m->planned || !m->arena) PA_FAIL(e, "pa_model_fill_arena: no plan yet");
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipMemsetAsync(m->arena, byte_value & 0xFF, m->arena_bytes, e->stream));
+    PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
 int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on_device, float* out, int out_on_device) {
     if (!m) return 1;
     pa_engine* e = m->e;

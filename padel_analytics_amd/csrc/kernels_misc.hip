@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
                     h4 hv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[r] = (_Float16)v[r];
+                    for (int r = 0; r < 4; ++r) hv[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);
                     *reinterpret_cast<h4*>(oh) = hv;
                 } else {
                     *reinterpret_cast<f32x4*>(a.out + o) = v;

@@ -83,7 +83,7 @@ ABI_SYMBOLS = [
     "pa_engine_bcast", "pa_engine_allreduce_max",
     "pa_bytetrack_create", "pa_bytetrack_destroy", "pa_bytetrack_reset", "pa_bytetrack_update_batch",
     "pa_model_take_overflow", "pa_yolo_postprocess", "pa_host_register", "pa_host_unregister",
-    "pa_engine_bcast_weights_from",
+    "pa_engine_bcast_weights_from", "pa_model_fill_arena",
 ]
 
 
@@ -153,6 +153,7 @@ def load_library():
     lib.pa_bytetrack_reset.argtypes = [vp]
     lib.pa_bytetrack_reset.restype = None
     lib.pa_bytetrack_update_batch.argtypes = [vp, vp, vp, vp, i32, i32, vp]
+    lib.pa_model_fill_arena.argtypes = [vp, i32]
     lib.pa_host_register.argtypes = [vp, vp, sz]
     lib.pa_host_unregister.argtypes = [vp, vp]
     lib.pa_model_take_overflow.argtypes = [vp, C.POINTER(i32)]
@@ -388,6 +389,10 @@ class Model:
         self.engine._check(self.engine.lib.pa_yolo_postprocess(self.handle, ptrs, n, h, w, C.byref(p), boxes.ctypes.data,
                                                                kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
         return boxes, kpts, counts
+
+    def fill_arena(self, byte_value: int = 0xFF) -> None:
+        """Tests: overwrite the planned activation arena (0xFF = NaN patterns): a following inference must not notice."""
+        self.engine._check(self.engine.lib.pa_model_fill_arena(self.handle, int(byte_value)))
 
     def take_overflow(self) -> bool:
         """h2 models: True if an activation written since the last call did not fit the fp16 range (clears the flag)."""

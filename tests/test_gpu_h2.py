@@ -230,3 +230,37 @@ def test_h2_helper_kernels(gpu_engine):
         ys.append(F.max_pool2d(ys[-1], 5, 1, 2))
     want = torch.cat(ys, 1).permute(0, 2, 3, 1).numpy()
     assert np.array_equal(got, want), float(np.abs(got - want).max())
+
+
+@pytest.mark.parametrize("mode", ["h2", "bx3"])
+def test_stale_arena_bytes_cannot_reach_results(gpu_engine, mode):
+    """activation buffers alias inside one arena, so whatever a conv reads beyond what its producers wrote
+    (pad channels, partial groups, absorbed-upsample slices) would be stale data of another layer — NaN if that layer
+    overflowed.  The h2 / fp32 kernels read no such byte: fill the arena with NaN patterns between two identical
+    inferences (YOLOv8 detect with its concat buffers and absorbed upsamples; the TrackNet U-Net) — results unchanged."""
+    from oracle import tracknet_ref as tr
+    from padel_analytics_amd import synth, yolo_arch
+    frames = synth.synthetic_frames(2, 360, 640, seed=4)
+    sd = yolo_arch.synth_state_dict("n", 80, None, seed=2, cls_bias=-1.0)
+    m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None, dtype=E.graph_dtype(mode)))
+    m.set_max_batch(2)
+    kw = dict(imgsz=640, conf=0.25, iou=0.7)
+    b0, _, c0 = m.yolo_infer(frames, 2, 360, 640, **kw)
+    h0 = [m.read_head(l, 2) for l in range(3)]
+    m.fill_arena(0xFF)
+    b1, _, c1 = m.yolo_infer(frames, 2, 360, 640, **kw)
+    h1 = [m.read_head(l, 2) for l in range(3)]
+    assert np.array_equal(c0, c1) and np.array_equal(b0, b1)
+    for a, b in zip(h0, h1):
+        assert np.isfinite(b).all() and np.array_equal(a, b)
+    m.close()
+    g = G.build_tracknet(tr.synth_tracknet_state_dict(2), dtype=E.graph_dtype(mode))
+    t = E.Model(gpu_engine, g)
+    t.set_max_batch(1)
+    x = np.random.default_rng(0).uniform(0, 1, (1, 64, 96, 32)).astype(np.float32)
+    x[..., 27:] = 0
+    y0 = t.tracknet_infer(x)
+    t.fill_arena(0xFF)
+    y1 = t.tracknet_infer(x)
+    assert np.isfinite(y1).all() and np.array_equal(y0, y1)
+    t.close()
