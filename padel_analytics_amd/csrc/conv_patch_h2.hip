@@ -49,7 +49,9 @@ __device__ __forceinline__ void hp_lds_fence() { asm volatile("s_waitcnt lgkmcnt
 // issues the operand reads of T + 1 into a SECOND register set, then runs the main products of step T under their
 // latency.  Costs 40 more VGPRs (2 waves per SIMD instead of 3).  Same products in the same order per accumulator:
 // bitwise equal to the plain schedule.
-template <int NF, bool TAIL, bool UP, bool PIPE>
+// PROBE (builds with -DPADEL_H2P_PROBES only; WRONG results, ceilings for tools/conv_bench.py): bit 0 no barrier on tap
+// steps 1..8, bit 1 no weight reads there, bit 2 no weight requests there, bit 3 no patch reads there, bit 4 no MFMAs
+template <int NF, bool TAIL, bool UP, bool PIPE, int PROBE = 0>
 __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h2p_kernel(const ConvArgs a) {
     constexpr int MF = 2;
     constexpr bool TWOL = NF <= 4;               // two-level main accumulation (part -> acc once per chunk) where registers allow
@@ -164,7 +166,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
 #define PADEL_HP_READA(T_)                                                                                        \
     do {                                                                                                          \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
-            const char* p_ = ldsb + hp_off(rd_pix + (f + (T_) / 3) * kHPW + (T_) % 3, lq);                        \
+            const char* p_ = ldsb + hp_off(rd_pix + (f + h2_tap_ky(T_)) * kHPW + h2_tap_kx(T_), lq);                        \
             ah[f] = *reinterpret_cast<const h16x8*>(p_);                                                          \
             am[f] = *reinterpret_cast<const h16x8*>(p_ + kHPlaneB);                                               \
         }                                                                                                         \
@@ -175,7 +177,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
     do {                                                                                                          \
         constexpr int ta_ = 2 * (JT_), tb_ = 2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8;                               \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
-            const int pa_ = rd_pix + (f + ta_ / 3) * kHPW + ta_ % 3, pb_ = rd_pix + (f + tb_ / 3) * kHPW + tb_ % 3; \
+            const int pa_ = rd_pix + (f + h2_tap_ky(ta_)) * kHPW + h2_tap_kx(ta_), pb_ = rd_pix + (f + h2_tap_ky(tb_)) * kHPW + h2_tap_kx(tb_); \
             const char* p_ = ldsb + hp_tail_off((lq >> 1) ? pb_ : pa_, lq & 1);                                   \
             ah[f] = *reinterpret_cast<const h16x8*>(p_);                                                          \
             am[f] = *reinterpret_cast<const h16x8*>(p_ + kHPlaneB);                                               \
@@ -204,7 +206,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
 #define PADEL_HP_READA2(T_, S_)                                                                                   \
     do {                                                                                                          \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
-            const char* p_ = ldsb + hp_off(rd_pix + (f + (T_) / 3) * kHPW + (T_) % 3, lq);                        \
+            const char* p_ = ldsb + hp_off(rd_pix + (f + h2_tap_ky(T_)) * kHPW + h2_tap_kx(T_), lq);                        \
             ah2[S_][f] = *reinterpret_cast<const h16x8*>(p_);                                                     \
             am2[S_][f] = *reinterpret_cast<const h16x8*>(p_ + kHPlaneB);                                          \
         }                                                                                                         \
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
     do {                                                                                                          \
         constexpr int ta_ = 2 * (JT_), tb_ = 2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8;                               \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
-            const int pa_ = rd_pix + (f + ta_ / 3) * kHPW + ta_ % 3, pb_ = rd_pix + (f + tb_ / 3) * kHPW + tb_ % 3; \
+            const int pa_ = rd_pix + (f + h2_tap_ky(ta_)) * kHPW + h2_tap_kx(ta_), pb_ = rd_pix + (f + h2_tap_ky(tb_)) * kHPW + h2_tap_kx(tb_); \
             const char* p_ = ldsb + hp_tail_off((lq >> 1) ? pb_ : pa_, lq & 1);                                   \
             ah2[S_][f] = *reinterpret_cast<const h16x8*>(p_);                                                     \
             am2[S_][f] = *reinterpret_cast<const h16x8*>(p_ + kHPlaneB);                                          \
@@ -286,20 +288,22 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
     // additionally publishes the freshly written planes and requests the next chunk's patch
 #define PADEL_HP_STEP(T_)                                                                                         \
     do {                                                                                                          \
-        h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
-        if constexpr ((T_) > 0) PADEL_HP_READA(T_);     /* the planes are static inside a chunk: read under the wait */ \
-        wait_vm3<0>();                                                                                            \
-        if constexpr ((T_) == 0) hp_lds_fence();        /* this wave's plane writes have reached the LDS */         \
-        __builtin_amdgcn_s_barrier();                                                                             \
+        constexpr bool first_ = (T_) == 0;                                                                        \
+        if constexpr (!first_ && !(PROBE & 8)) PADEL_HP_READA(T_);   /* the planes are static inside a chunk: read under the wait */ \
+        if constexpr (first_ || !(PROBE & 4)) wait_vm3<0>();                                                      \
+        if constexpr (first_) hp_lds_fence();           /* this wave's plane writes have reached the LDS */         \
+        if constexpr (first_ || !(PROBE & 1)) __builtin_amdgcn_s_barrier();                                       \
         asm volatile("" ::: "memory");                                                                            \
-        PADEL_HP_READB(T_);                                                                                       \
-        if constexpr ((T_) == 0) PADEL_HP_READA(T_);                                                              \
+        if constexpr (first_ || !(PROBE & 2)) PADEL_HP_READB(T_);                                                 \
+        if constexpr (first_) PADEL_HP_READA(T_);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_HP_DMAB((T_) + 1, s_kb + ((T_) + 1) * 128u);                   \
+        if constexpr (first_ || (T_) == 8 || !(PROBE & 4)) {                                                      \
+            if ((T_) < 8 || c + 1 < nch || TAIL) PADEL_HP_DMAB((T_) + 1, s_kb + ((T_) + 1) * 128u);               \
+        }                                                                                                         \
         if ((T_) == 0 && c + 1 < nch) PADEL_HP_LOAD(c + 1);                                                       \
         if constexpr (TAIL) { if ((T_) == 0 && c + 1 == nch) PADEL_HP_TLOAD(); }                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_HP_MFMA();                                                                                          \
+        if constexpr (!(PROBE & 16)) PADEL_HP_MFMA();                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 
@@ -317,7 +321,6 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
     } while (0)
 #define PADEL_HP_TSTEP(JT_)                                                                                       \
     do {                                                                                                          \
-        h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
         wait_vm3<0>();                                                                                            \
         hp_lds_fence();                                                                                           \
         __builtin_amdgcn_s_barrier();                                                                             \
@@ -392,6 +395,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
             }
         }
     } else {
+    h16x8 ah[MF], am[MF], wh[NF], wm[NF];
     for (int c = 0; c < nch; ++c) {
         if (c > 0) {                          // every wave is done with the taps of chunk c - 1: the planes may be overwritten
             __builtin_amdgcn_s_barrier();
@@ -462,14 +466,14 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
     h2_epilogue<MF, NF>(a, acc, cross, mpix, f0, lq, fast);
 }
 
-template <int NF, bool TAIL, bool UP, bool PIPE>
+template <int NF, bool TAIL, bool UP, bool PIPE, int PROBE = 0>
 static hipError_t launch_hpt(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
     const int batch = a.M / (a.Ho * a.Wo);
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + NF - 1) / NF;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP, PIPE>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP, PIPE, PROBE>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 
@@ -496,6 +500,13 @@ hipError_t launch_conv_h2p(const ConvArgs& a, int nf, hipStream_t s) {
         case 6: return launch_hp<6, false>(a, s);
         case 13: return launch_hp<3, true>(a, s);
         case 14: return launch_hp<4, true>(a, s);
+#ifdef PADEL_H2P_PROBES
+#define PADEL_HP_PROBE_CASE(P_) case 32 + (P_): if (a.in2 || (a.cin & 16)) return hipErrorNotSupported; return launch_hpt<3, false, false, false, (P_)>(a, s);
+        PADEL_HP_PROBE_CASE(1) PADEL_HP_PROBE_CASE(2) PADEL_HP_PROBE_CASE(3) PADEL_HP_PROBE_CASE(4) PADEL_HP_PROBE_CASE(5)
+        PADEL_HP_PROBE_CASE(7) PADEL_HP_PROBE_CASE(8) PADEL_HP_PROBE_CASE(10) PADEL_HP_PROBE_CASE(15) PADEL_HP_PROBE_CASE(16)
+        PADEL_HP_PROBE_CASE(17) PADEL_HP_PROBE_CASE(31)
+#undef PADEL_HP_PROBE_CASE
+#endif
     }
     return hipErrorNotSupported;
 }

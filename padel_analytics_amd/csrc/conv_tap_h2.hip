@@ -155,12 +155,12 @@ __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_ke
             vx[d] = (unsigned)(ox * a.stride - 1 + d) < (unsigned)a.W;
         }
 #pragma unroll
-        for (int t = 0; t < 9; ++t) voffA[p][t] = (vy[t / 3] && vx[t % 3]) ? off : kOORh;
+        for (int t = 0; t < 9; ++t) voffA[p][t] = (vy[h2_tap_ky(t)] && vx[h2_tap_kx(t)]) ? off : kOORh;
     }
     const i32x4 rsrcA = make_rsrc3(a.in + ((lin0 - (a.W + 1)) * a.in_cs + a.in_choff));
     unsigned tapoff[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((unsigned)((((t / 3) * a.W + (t % 3)) * a.in_cs) * 4));
+    for (int t = 0; t < 9; ++t) tapoff[t] = __builtin_amdgcn_readfirstlane((unsigned)(((h2_tap_ky(t) * a.W + h2_tap_kx(t)) * a.in_cs) * 4));
     // K walk: nfull 32-channel chunks x 9 taps, then — for cin % 32 == 16 — a TAIL block of 5 steps that pair taps
     const int nfull = a.cin >> 5;
     PADEL_H2T_WEIGHTS(nfull * 9 + (half_tail ? 5 : 0))
@@ -170,13 +170,17 @@ __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_ke
     PADEL_H2T_DMA_R(rsrcA, SR_, (CH_) + tapoff[T_], KB_, voffA[0][T_], voffA[AP - 1][T_])
     // tail step JT_: lanes of slots 0, 1 fetch the group's parts at tap 2 JT_, lanes of slots 2, 3 at tap 2 JT_ + 1 (their
     // offsets carry + 64 for "second group of a chunk": taken back out; the tap distance goes in instead)
+    // (column-major taps: the second tap of a pair may lie BEFORE the first in memory — the scalar offset carries the smaller
+    //  of the two tap offsets, each lane group adds its own distance: lane offsets stay non-negative)
+#define PADEL_H2T_TB(JT_) (2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8)
+#define PADEL_H2T_TMIN(JT_) min(tapoff[2 * (JT_)], tapoff[PADEL_H2T_TB(JT_)])
 #define PADEL_H2T_TV(P_, JT_)                                                                                      \
-    (sc_hi ? (2 * (JT_) + 1 < 9 ? voffA[P_][2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] + (tapoff[2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8] - tapoff[2 * (JT_)]) - 64u : kOORh) \
-           : voffA[P_][2 * (JT_)])
+    (sc_hi ? (2 * (JT_) + 1 < 9 ? voffA[P_][PADEL_H2T_TB(JT_)] + (tapoff[PADEL_H2T_TB(JT_)] - PADEL_H2T_TMIN(JT_)) - 64u : kOORh) \
+           : voffA[P_][2 * (JT_)] + (tapoff[2 * (JT_)] - PADEL_H2T_TMIN(JT_)))
 #define PADEL_H2T_REQ_TAIL(SR_, CH_, KB_, JT_)                                                                     \
     do {                                                                                                          \
         const unsigned v0_ = PADEL_H2T_TV(0, JT_), v1_ = PADEL_H2T_TV(AP - 1, JT_);                                \
-        PADEL_H2T_DMA_R(rsrcA, SR_, (CH_) + tapoff[2 * (JT_)], KB_, v0_, v1_);                                     \
+        PADEL_H2T_DMA_R(rsrcA, SR_, (CH_) + PADEL_H2T_TMIN(JT_), KB_, v0_, v1_);                                   \
     } while (0)
     bool nxt_tail = false;       // the block after the current full chunk is the tail block
 
@@ -227,6 +231,8 @@ __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_ke
 #undef PADEL_H2T_REQ_FULL
 #undef PADEL_H2T_REQ_TAIL
 #undef PADEL_H2T_TV
+#undef PADEL_H2T_TMIN
+#undef PADEL_H2T_TB
 }
 
 // =====================================================================================================  1x1
@@ -322,6 +328,10 @@ static hipError_t launch_h2t(const ConvArgs& a_in, hipStream_t s) {
 // not apply, its tap sibling
 hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
     if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16 || !a.w || !a.oscale || !a.ovf_flag) return hipErrorNotSupported;
+    if (variant == 323) {                  // the quad patch kernel (conv_patch_h2q.hip); where it does not apply, the 48-channel patch tile
+        if (conv_h2q_supported(a)) return launch_conv_h2q(a, s);
+        variant = 303;
+    }
     if (variant >= 300 && variant < 400) {
         const int nf = variant - 300;
         if (conv_h2p_supported(a)) return launch_conv_h2p(a, nf, s);
@@ -372,6 +382,16 @@ int choose_conv_h2_variant(const ConvArgs& a) {
             const long long per_cu = (blocks + 255) / 256;
             const float sc = v.sp * fill * (float)blocks / (256.f * (float)per_cu);
             if (sc > best) { best = sc; bv = 300 + v.nf; }
+        }
+        // the quad patch kernel (conv_patch_h2q.hip: 8 x 16 pixels x 96 channels per workgroup, 2 workgroups per CU) measured
+        // 1.02-1.05 x the 48-channel tile where the channels fill its tiles (profiles/r3k_sweep_h2q.txt); bitwise the same results
+        if (conv_h2q_supported(a) && n16 % 6 == 0) {
+            const int ntiles = n16 / 6;
+            const float fill = (float)M / (float)(patches * 128);
+            const long long blocks = patches * ntiles;
+            const long long per_cu = (blocks + 255) / 256;
+            const float sc = 1.21f * fill * (float)blocks / (256.f * (float)per_cu);
+            if (sc > best) { best = sc; bv = 323; }
         }
         // cin % 32 == 16 (yolov8m's 48-channel P2 layers): 14 short steps per tile — there the software-pipelined schedule
         // (313: operand reads of the next step under this step's main products) measured +6..9 % although it runs 2 waves

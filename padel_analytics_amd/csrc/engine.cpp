@@ -714,7 +714,8 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             const bool use_tap = e->t.impl == 0 || f16;
             const bool use_bx3 = a.w3 != nullptr;
             int bm = 0, bn = 0;
-            if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
+            if (h2 && lv == 323) { bm = 128; bn = 96; }                       // quad patch kernel: 8 x 16 pixels x 96 channels
+            else if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
             else if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
             else if (lv >= 300) { bm = 128; bn = (lv - 300) * 16; }          // patch kernel: 8 x 16 pixels x nf fragments
             else conv_variant_shape(lv >= 200 ? lv - 200 : lv, &bm, &bn);   // profile rows carry BM, BN of the workgroup tile
@@ -723,8 +724,13 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             // tuning only ("timeline"): collect the s_memtime timeline of this launch into timeline_path
             unsigned long long* dbg_dev = nullptr;
             size_t dbg_bytes = 0;
-            if (e->t.timeline && use_tap && lv == 7 && o.ksize == 3 && !e->timeline_path.empty()) {
+            if (e->t.timeline && h2 && lv == 323 && conv_h2q_supported(a) && !e->timeline_path.empty()) {
+                const size_t patches = (size_t)n * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);          // conv_patch_h2q.hip: one record per workgroup of its 1-D grid
+                dbg_bytes = 8 * ((patches + 7) / 8) * (size_t)((a.n16 + 5) / 6) * (8 + 4 * 32 * 5) * 8;
+            } else if (e->t.timeline && !h2 && use_tap && lv == 7 && o.ksize == 3 && !e->timeline_path.empty()) {
                 dbg_bytes = (size_t)((a.M + 63) / 64) * ((o.npad + 95) / 96) * kConvDbgWords * 8;
+            }
+            if (dbg_bytes) {
                 if (hipMalloc(&dbg_dev, dbg_bytes) == hipSuccess) (void)hipMemsetAsync(dbg_dev, 0, dbg_bytes, s);
                 else dbg_dev = nullptr;
                 a.dbg = dbg_dev;

@@ -30,6 +30,12 @@ constexpr float kH2Max = 65504.0f;
 constexpr float kH2Scale = 2048.0f, kH2InvScale = 1.0f / 2048.0f;
 constexpr unsigned kOORh = 0x80000000u;      // out-of-range lane offset that stays out of range under small positive additions
 
+// 3x3 taps are walked COLUMN-major by every h2 kernel and in the packed weights (graph.py:pack_conv_weight_h2): k-step t
+// of a channel chunk is tap (ky, kx) = (t % 3, t / 3).  The quad patch kernel (conv_patch_h2q.hip) keeps the input rows of
+// one kx in registers across its three ky; one order for all kernels keeps their results bitwise identical.
+__host__ __device__ constexpr int h2_tap_ky(int t) { return t % 3; }
+__host__ __device__ constexpr int h2_tap_kx(int t) { return t / 3; }
+
 // byte offset, inside a pixel, of the h part of channels [c, c + 4) (c % 4 == 0); the m part sits 32 bytes further
 __device__ __forceinline__ long long h2_chan_off(int c) { return (long long)(c >> 4) * 64 + (c & 15) * 2; }
 

@@ -167,8 +167,9 @@ def h2_row_scale(w2d: np.ndarray) -> np.ndarray:
 
 def pack_conv_weight_h2(w: np.ndarray):
     """(Cout, Cin, k, k) fp32, Cout % 16 == 0, Cin % 16 == 0 -> (uint16 [Cout][k-step][h|m][32], fp32 [Cout] = 1 / row
-    scale).  K-steps are ``bx3_ksteps`` (tap pairing for the 16-channel tail of a 3x3); the 32 slots of a step are in
-    natural order: an MFMA lane group q holds slots 8q..8q+7."""
+    scale).  K-steps are ``bx3_ksteps`` (tap pairing for the 16-channel tail of a 3x3) with the taps of a 3x3 walked
+    COLUMN-major (tap t = (ky, kx) = (t % 3, t // 3), csrc/h2_common.h:h2_tap_ky); the 32 slots of a step are in natural
+    order: an MFMA lane group q holds slots 8q..8q+7."""
     cout, cin, k, _ = w.shape
     assert cout % 16 == 0 and cin % 16 == 0
     sc = h2_row_scale(w.reshape(cout, -1))
@@ -178,7 +179,7 @@ def pack_conv_weight_h2(w: np.ndarray):
         blk = np.zeros((cout, 32), np.float32)
         for i, sl in enumerate(slots):
             if sl is not None:
-                blk[:, i] = w[:, sl[0], sl[1] // k, sl[1] % k]
+                blk[:, i] = w[:, sl[0], sl[1] % k, sl[1] // k]       # taps column-major: k-step t = (ky, kx) = (t % 3, t // 3)
         h, m = h2_split(blk * sc[:, None])
         out[:, s, 0], out[:, s, 1] = h.view(np.uint16), m.view(np.uint16)
     return out, (1.0 / sc).astype(np.float32)

@@ -43,7 +43,7 @@ def unpack_conv_h2(blob, o):
     for s, slots in enumerate(steps):
         for i, sl in enumerate(slots):
             if sl is not None:
-                w[:, sl[0], sl[1] // k, sl[1] % k] = val[:, s, i]
+                w[:, sl[0], sl[1] % k, sl[1] // k] = val[:, s, i]        # taps column-major (graph.py:pack_conv_weight_h2)
     return w, blob[o["b_off"]:o["b_off"] + npad]
 
 

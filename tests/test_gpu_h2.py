@@ -18,7 +18,7 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 303, 304, 306, 313, 314)      # 31x: the patch kernel with the 3-stage weight ring
+H2_TILES = (207, 209, 211, 213, 220, 225, 303, 304, 306, 313, 314, 323)      # 31x: software-pipelined patch schedule; 323: the quad patch kernel
 H2_SINGLE_LEVEL = (306,)        # patch tile with 6 fragments: main product accumulated in one level (registers)
 
 

@@ -1,5 +1,9 @@
 #!/usr/bin/env python
-"""Per-wave s_memtime timeline of the 64x96 LDS conv tile (tuning tool, GPU only).
+"""Per-wave s_memtime timeline of an instrumented conv kernel (tuning tool, GPU only).
+
+--kernel h2q: the quad patch kernel of h2 graphs (conv_patch_h2q.hip, tile 323; needs a library built with
+-DPADEL_H2P_PROBES); --kernel tap: the fp32-MFMA tap kernel, 64x96 tile.
+
 
 Runs the yolov8m P4 bottleneck conv (192->192 3x3, batch 64) through the DIAG-16 instantiation of
 conv_lds_kernel (every wave stamps 5 points of every k-step: loop top / fragments in registers / last MFMA issued /
@@ -18,20 +22,26 @@ STEPS, WORDS = 64, 8 + 4 * 64 * 5
 
 
 def run_conv(dump, kernel="lds", B=64, H=48, W=80, cin=192, cout=192):
-    if kernel != "tap":
+    if kernel not in ("tap", "h2q"):
         raise SystemExit("the LDS kernel's DIAG instantiations were retired with round 2 (tools/legacy_conv/); use --kernel tap")
     from padel_analytics_amd import engine as E, graph as G
     eng = E.default_engine(0)
     eng.set_profiling(True)
-    eng.set_tuning(impl=0, variant=7, timeline=1)
+    h2 = kernel == "h2q"
+    eng.set_tuning(impl=0, variant=323 if h2 else 7, timeline=1)
     eng.lib.pa_engine_set_timeline_path(eng.handle, dump.encode())
     rng = np.random.default_rng(0)
-    g = G.Graph(task=G.TASK_TRACKNET)
+    g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2 if h2 else G.DTYPE_F32)
     b0 = g.buf(0, cin)
     b1 = g.buf(0, G.pad16(cout))
     w = rng.normal(0, (2.0 / (cin * 9)) ** 0.5, (cout, cin, 3, 3)).astype(np.float32)
-    g.conv((b0, 0, cin), (b1, 0), w, np.zeros(cout, np.float32), 3, 1, 1)
-    g.head_buf = (b1, -1, -1)
+    g.conv((b0, 0, cin), (b1, 0), w, np.zeros(cout, np.float32), 3, 1, 1, out_width=G.pad16(cout) if h2 else None)
+    if h2:                             # the measured conv writes pairs; a tiny fp32 head keeps pa_tracknet_infer's contract
+        hd = g.buf(0, 16)
+        g.conv((b1, 0, G.pad16(cout)), (hd, 0), np.zeros((1, G.pad16(cout), 1, 1), np.float32), np.zeros(1, np.float32), 1, 1, 0)
+        g.head_buf = (hd, -1, -1)
+    else:
+        g.head_buf = (b1, -1, -1)
     m = E.Model(eng, g)
     m.set_max_batch(B)
     x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32)
@@ -46,20 +56,30 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/timeline.txt")
     ap.add_argument("--dump", default="/tmp/padel_conv_timeline.bin")
-    ap.add_argument("--kernel", default="tap", choices=["lds", "tap"],
-                    help="lds = conv_lds_kernel (v2) DIAG 16; tap = conv_tap_kernel (v5) timeline instantiation")
+    ap.add_argument("--kernel", default="tap", choices=["lds", "tap", "h2q"],
+                    help="tap = conv_tap_kernel (v5) timeline instantiation; h2q = conv_h2q_kernel (h2 quad patch kernel)")
+    ap.add_argument("--cin", type=int, default=192)
+    ap.add_argument("--cout", type=int, default=192)
+    ap.add_argument("--hw", default="48x80")
     a = ap.parse_args()
-    ms = run_conv(a.dump, a.kernel)
+    global STEPS, WORDS
+    h2q = a.kernel == "h2q"
+    if h2q:
+        STEPS, WORDS = 32, 8 + 4 * 32 * 5
+    H_, W_ = (int(v) for v in a.hw.split("x"))
+    ms = run_conv(a.dump, a.kernel, H=H_, W=W_, cin=a.cin, cout=a.cout)
     raw = np.fromfile(a.dump, dtype=np.uint64)
     nblk = raw.size // WORDS
     raw = raw[: nblk * WORDS].reshape(nblk, WORDS)
+    raw = raw[raw[:, 5] != 0]                           # grid padding: workgroups that returned at once wrote nothing
+    nblk = raw.shape[0]
     hdr = raw[:, :8]
     st = raw[:, 8:].reshape(nblk, 4, STEPS, 5).astype(np.int64)
     nks = int(hdr[0, 6])
     out = []
     P = out.append
-    P(f"kernel: {'conv_tap_kernel<2,2,2,3> (v5)' if a.kernel == 'tap' else 'conv_lds_kernel<2,2,2,3,3,1> (v2)'}")
-    P(f"conv 192->192 3x3, M = 245760, tile 64x96, {nblk} workgroups, {nks} k-steps, instrumented kernel time {ms:.3f} ms")
+    P(f"kernel: {'conv_h2q_kernel<3> (h2 quad patch)' if h2q else 'conv_tap_kernel<2,2,2,3> (v5)' if a.kernel == 'tap' else 'conv_lds_kernel<2,2,2,3,3,1> (v2)'}")
+    P(f"conv {a.cin}->{a.cout} 3x3 on 64 x {a.hw}, {nblk} workgroups, {nks} k-steps, instrumented kernel time {ms:.3f} ms")
     life = (hdr[:, 5].astype(np.int64) - hdr[:, 4].astype(np.int64))
     P(f"workgroup lifetime (s_memtime ticks): mean {life.mean():.0f}  p10 {np.percentile(life, 10):.0f}  p90 {np.percentile(life, 90):.0f}"
       f"  -> {life.mean() / nks:.0f} ticks per k-step incl. prologue/epilogue")
@@ -68,7 +88,26 @@ def main():
     sl = steps & (STEPS - 1)
     t = st[:, :, sl, :]                                     # (blk, wave, step, 5)
     nxt = st[:, :, (steps + 1) & (STEPS - 1), 0]
-    if a.kernel == "tap":
+    if h2q:
+        seg = {
+            "t0->t1 row reads issued + wait own requests (vmcnt 0)": t[..., 1] - t[..., 0],
+            "t1->t2 barrier": t[..., 2] - t[..., 1],
+            "t2->t3 weight reads + DMA requests + all operands in registers": t[..., 3] - t[..., 2],
+            "t3->t4 36 MFMAs issued (576 if alone)": t[..., 4] - t[..., 3],
+            "t4->t0' to the next step (chunk flush after tap 8)": nxt - t[..., 4],
+            "whole tap step": nxt - t[..., 0],
+        }
+        for wv in range(4):
+            v = (nxt - t[..., 0])[:, wv].reshape(-1)
+            m_ = (t[..., 4] - t[..., 3])[:, wv].reshape(-1)
+            r_ = (t[..., 3] - t[..., 2])[:, wv].reshape(-1)
+            P(f"  wave {wv}: whole step mean {v.mean():.0f}  MFMA issue {m_.mean():.0f}  reads+requests {r_.mean():.0f}")
+        for tp in range(9):
+            sel = (steps % 9) == tp
+            if sel.any():
+                P(f"  tap {tp}: whole step mean {(nxt - t[..., 0])[:, :, sel].mean():.0f}  wait {(t[..., 1] - t[..., 0])[:, :, sel].mean():.0f}"
+                  f"  barrier {(t[..., 2] - t[..., 1])[:, :, sel].mean():.0f}  reads {(t[..., 3] - t[..., 2])[:, :, sel].mean():.0f}  mfma {(t[..., 4] - t[..., 3])[:, :, sel].mean():.0f}")
+    elif a.kernel == "tap":
         seg = {
             "t0->t1 wait own requests of this step (vmcnt n)": t[..., 1] - t[..., 0],
             "t1->t2 barrier": t[..., 2] - t[..., 1],
@@ -93,7 +132,7 @@ def main():
     # prologue / epilogue (ring keeps steps nks-64 ..): epilogue = last MFMA issued -> end stamp
     first = max(nks - STEPS, 0)
     t_first = st[:, 0, first & (STEPS - 1), 0]
-    t_lastm = st[:, 0, (nks - 1) & (STEPS - 1), 4 if a.kernel == "tap" else 2]
+    t_lastm = st[:, 0, (nks - 1) & (STEPS - 1), 4 if a.kernel in ("tap", "h2q") else 2]
     tb, te = hdr[:, 4].astype(np.int64), hdr[:, 5].astype(np.int64)
     epi = te - t_lastm
     mainloop = (t_lastm - t_first) / (nks - first)
@@ -130,7 +169,7 @@ def main():
             for s in steps:
                 e = st[b, wv, s & (STEPS - 1)]
                 n0 = st[b, wv, (s + 1) & (STEPS - 1), 0]
-                segs = (((e[0], e[1], "w"), (e[1], e[2], "b"), (e[2], e[3], "l"), (e[3], e[4], "M"), (e[4], n0, ".")) if a.kernel == "tap"
+                segs = (((e[0], e[1], "w"), (e[1], e[2], "b"), (e[2], e[3], "l"), (e[3], e[4], "M"), (e[4], n0, ".")) if a.kernel in ("tap", "h2q")
                         else ((e[0], e[1], "l"), (e[1], e[2], "M"), (e[2], e[3], "w"), (e[3], e[4], "b"), (e[4], n0, ".")))
                 for (lo, hi, ch) in segs:
                     c0, c1 = int((lo - t_lo) // res), int((hi - t_lo) // res)
@@ -138,7 +177,7 @@ def main():
                         row[c] = ch
             P(f"     wg {int(hdr[b, 7]):5d} simd {simd}: " + "".join(row))
     P("  legend: " + ("w = counted vmcnt wait, b = barrier, l = DMA requests + ds_read wait, M = MFMA burst being issued"
-                     if a.kernel == "tap" else
+                     if a.kernel in ("tap", "h2q") else
                      "l = prefetch issue + ds_read wait, M = MFMA burst being issued, w = vmcnt wait, b = ds_write + barrier")
       + f"; 1 column = {res} ticks")
     # compact copy of 16 CUs for offline analysis
