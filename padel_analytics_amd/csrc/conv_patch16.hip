@@ -8,12 +8,13 @@
 //     ahead (out-of-image pixels are zeros by the buffer range check; the XOR swizzle of conv_patch_bx3.hip is applied on
 //     the global side: the lane that fills physical 16-byte slot s of pixel p fetches logical chunk s ^ 2*((p>>2)&1));
 //   * the 9 taps are shifted 16-pixel windows of that image, read as ready-made MFMA operands (conflict-free);
-//   * the weights travel through a 2-stage LDS-DMA ring whose stage holds THREE taps: one barrier per 3 taps,
+//   * the weights travel through a 2-stage LDS-DMA ring whose stage holds the THREE taps of one kernel column: one barrier per 3 taps,
 //     6 (2 + NF) ds_read_b128 and 6 NF MFMAs per wave between barriers.
 // Weights are the fp16 [Npad][Ktot] rows of the tap kernels (K order: 64-channel chunk, tap, 32-channel half; a
 // 32-channel tail block of 9 k-steps when cin % 64 == 32), fp32 accumulation, same epilogue (fp16 or fp32 output).
 // LDS: 2 x 12 KB patch + 2 x 3 x BN x 64 B: 48 KB for BN = 64 -> 3 workgroups per CU; 60 KB for BN = 96 -> 2.
 #include "kernels.h"
+#include "act_fast.h"
 #include <cmath>
 #include <cstdint>
 
@@ -47,12 +48,26 @@ __device__ __forceinline__ void p16_dma(unsigned voff, p16_i32x4 rsrc, unsigned 
                  : [lb] "s"(lds_wave), [imm] "n"(LDS_IMM), [vo] "v"(voff), [rs] "s"(rsrc), [so] "s"(soff)
                  : "memory", "scc");
 }
+// request k of a wave of the quad kernel: LDS span (wave + 3 k) -> immediate 3072 k on top of the wave's base
+template <int NF>
+__device__ __forceinline__ void q16_dma_k(int k, unsigned voff, p16_i32x4 rsrc, unsigned soff, unsigned lds_wave) {
+    switch (k) {
+        case 0: p16_dma<0>(voff, rsrc, soff, lds_wave); break;
+        case 1: p16_dma<3072>(voff, rsrc, soff, lds_wave); break;
+        case 2: p16_dma<6144>(voff, rsrc, soff, lds_wave); break;
+        case 3: p16_dma<9216>(voff, rsrc, soff, lds_wave); break;
+        case 4: p16_dma<12288>(voff, rsrc, soff, lds_wave); break;
+        case 5: p16_dma<15360>(voff, rsrc, soff, lds_wave); break;
+    }
+}
 __device__ __forceinline__ void p16_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned p16_off(int p, int q) { return (unsigned)(p * 64 + ((q ^ (((p >> 2) & 1) << 1)) << 4)); }
+// activation: act_fast.h (11 VALU for SiLU instead of the 28+ of expf() and an IEEE division; with one MFMA per product the
+// fp16 kernels spend as many cycles in their epilogues as in their matrix work)
 __device__ __forceinline__ float p16_act(float v, int act) {
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_SILU) return fast_act<ACT_SILU>(v);
     if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
-    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == ACT_SIGMOID) return fast_act<ACT_SIGMOID>(v);
     return v;
 }
 
@@ -85,9 +100,15 @@ __device__ __forceinline__ void p16_epilogue_case(const ConvArgs& a, const p16_f
                 if (a.out_f32) {
                     *reinterpret_cast<p16_f32x4*>(a.out + (long long)m * a.out_cs + a.out_choff + co0) = v;
                 } else {
-                    p16_h4 o;
+                    typedef float p16_f2 __attribute__((ext_vector_type(2)));
+                    typedef _Float16 p16_h2 __attribute__((ext_vector_type(2)));
+                    p16_h4 o;                                  // saturate (no infinities in HBM), packed round-to-nearest conversion
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);     // saturate: no infinities in HBM
+                    for (int r = 0; r < 2; ++r) {
+                        const p16_f2 x = {__builtin_amdgcn_fmed3f(v[2 * r], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(v[2 * r + 1], -65504.0f, 65504.0f)};
+                        const p16_h2 hh = __builtin_convertvector(x, p16_h2);
+                        o[2 * r] = hh[0]; o[2 * r + 1] = hh[1];
+                    }
                     *reinterpret_cast<p16_h4*>(reinterpret_cast<_Float16*>(a.out) + (long long)m * a.out_cs + a.out_choff + co0) = o;
                 }
             } else {
@@ -205,12 +226,13 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 3 : 2) conv_p16_kernel(const Co
         if constexpr (BFULL >= 1) p16_dma<(TI_) * BTAP_B>(voffB[0], rsrcB, so_, (LW_));                           \
         if constexpr (BP > BFULL) { if (b_last) p16_dma<(TI_) * BTAP_B + BFULL * 4096>(voffB[BP - 1], rsrcB, so_, (LW_)); } \
     } while (0)
-    // weight stage S_ (taps 3 S_ .. 3 S_ + 2) of chunk C_ into ring stage LW_
+    // weight stage S_ = kernel COLUMN S_ (taps (ky, kx) = (0..2, S_): rows of the weight matrix keep the row-major tap order of
+    // the tap kernels, the walk is column-major like the quad kernel's below) of chunk C_ into ring stage LW_
 #define PADEL_P16_DMAB(LW_, C_, S_)                                                                               \
     do {                                                                                                          \
-        PADEL_P16_DMAB_TAP(LW_, 0, PADEL_P16_KS(C_, 3 * (S_)));                                                   \
-        PADEL_P16_DMAB_TAP(LW_, 1, PADEL_P16_KS(C_, 3 * (S_) + 1));                                               \
-        PADEL_P16_DMAB_TAP(LW_, 2, PADEL_P16_KS(C_, 3 * (S_) + 2));                                               \
+        PADEL_P16_DMAB_TAP(LW_, 0, PADEL_P16_KS(C_, (S_)));                                                       \
+        PADEL_P16_DMAB_TAP(LW_, 1, PADEL_P16_KS(C_, 3 + (S_)));                                                   \
+        PADEL_P16_DMAB_TAP(LW_, 2, PADEL_P16_KS(C_, 6 + (S_)));                                                   \
     } while (0)
 #define PADEL_P16_DMAP(LW_, C_)                                                                                   \
     do {                                                                                                          \
@@ -234,9 +256,8 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 3 : 2) conv_p16_kernel(const Co
         const float* const br_ = ((S_) & 1) ? b_rd1 : b_rd0;                                                      \
         p16_h8 av[3][MF], bv[3][NF];                                                                              \
         _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                           \
-            const int tap = 3 * (S_) + t;                                                                         \
             _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
-                av[t][f] = *reinterpret_cast<const p16_h8*>(pA0 + p16_off(rd_pix + (f + tap / 3) * kPW16 + tap % 3, lq)); \
+                av[t][f] = *reinterpret_cast<const p16_h8*>(pA0 + p16_off(rd_pix + (f + t) * kPW16 + (S_), lq));  \
             _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                        \
                 bv[t][j] = __builtin_bit_cast(p16_h8, *reinterpret_cast<const p16_f32x4*>(br_ + t * (BTAP_B / 4) + j * 256)); \
         }                                                                                                         \
@@ -275,6 +296,190 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 3 : 2) conv_p16_kernel(const Co
     p16_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
 }
 
+// ---- the quad variant: a workgroup owns 16 x 16 output pixels x BN channels, a wave 4 rows x 16 pixels x ALL NF fragments.
+// The 8 x 16 kernel above reads 3 (2 + NF) operands per 6 NF MFMAs and wave (0.67 per MFMA at NF = 6): 4 waves x 24 reads x
+// 8 clocks = 768 LDS clocks per stage against 576 matrix-pipe cycles — it is LDS-bound.  Here the three taps of a kernel
+// column share their input rows (rows r .. r + 5 of the wave's window, read once per column) and every weight fragment
+// feeds 4 pixel fragments: 6 + 3 NF reads per 12 NF MFMAs (0.33 per MFMA at NF = 6, 72 MFMAs between barriers).  The
+// 18 x 18 patch is requested by wave 3 (a third per stage), the weights by waves 0..2: vmcnt is in-order per wave, so no
+// weight wait ever waits for patch data.  Same K walk (32-channel chunk, column, row) as the kernel above: bitwise equal.
+// LDS: 2 x 21 KB patch (324 pixels, padded to 21 spans of 16) + 2 stages x 3 taps x BN x 64 B: 78 KB for BN = 96.
+constexpr int kQ16PW = 18, kQ16NPix = 18 * 18;
+constexpr int kQ16Spans = (kQ16NPix + 15) / 16;          // 21
+constexpr int kQ16PatchB = kQ16Spans * 1024;
+
+template <int NF>
+__global__ void __launch_bounds__(256, 2) conv_p16q_kernel(const ConvArgs a) {
+    constexpr int MF = 4;
+    constexpr int BN = NF * 16;
+    constexpr int BTAP_B = BN * 64;
+    constexpr int BSTAGE_B = 3 * BTAP_B;
+    static_assert(2 * kQ16PatchB + 2 * BSTAGE_B <= 80 * 1024, "2 workgroups per CU");
+    static_assert(kQ16Spans == 21, "7 patch spans per stage");
+    __shared__ __attribute__((aligned(16))) float lds[(2 * kQ16PatchB + 2 * BSTAGE_B) / 4];
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+
+    // XCD-aware 1-D tile map (conv_patch_bx3.hip)
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;
+    const int bid = blockIdx.x;
+    const int q8 = nmt >> 3, r8 = nmt & 7, xcd = bid & 7, idx = bid >> 3;
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;
+    if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
+    const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
+    const int txN = (a.Wo + 15) >> 4, tyN = (a.Ho + 15) >> 4;
+    const int tpi = tyN * txN;
+    const int n = mt / tpi, rt = mt - n * tpi;
+    const int ty = rt / txN, tx = rt - ty * txN;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int f0 = nt * NF;
+
+    // ---- patch (wave 3): span s = 16 pixels x 64 bytes, lane i -> pixel 16 s + i / 4, physical slot i & 3 = logical chunk
+    // (i & 3) ^ 2 ((p >> 2) & 1) of that pixel's 64 bytes
+    const _Float16* const in16 = reinterpret_cast<const _Float16*>(a.in);
+    const p16_i32x4 rsrcP = p16_rsrc(in16 + (((long long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.in_cs + a.in_choff);
+    const int p_lane = lane >> 2;
+    const unsigned p_piece = (unsigned)(((lane & 3) ^ (((lane >> 4) & 1) << 1)) * 16);
+    const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+#define PADEL_Q16_PSPAN(S_)                                                                                       \
+    do {                                                                                                          \
+        const int pp_ = (S_) * 16 + pl_;                                                                          \
+        const int py_ = pp_ / kQ16PW, px_ = pp_ - py_ * kQ16PW;                                                   \
+        const bool ok_ = pp_ < kQ16NPix && (unsigned)(y0 - 1 + py_) < (unsigned)a.H && (unsigned)(x0 - 1 + px_) < (unsigned)a.W; \
+        p16_dma<(S_) * 1024>(ok_ ? (unsigned)((py_ * a.W + px_) * a.in_cs * 2) + p_piece : kOOR16, rsrcP, so_, lb_); \
+    } while (0)
+    // spans 7 G_ .. 7 G_ + 6 (a third) of the patch of chunk CH_ into buffer BUF_
+#define PADEL_Q16_PATCH(CH_, BUF_, G_)                                                                            \
+    do {                                                                                                          \
+        const unsigned so_ = (unsigned)(CH_) * 64u;                                                               \
+        const unsigned lb_ = lp0 + (unsigned)(BUF_) * (unsigned)kQ16PatchB;                                       \
+        int pl_ = p_lane;                                  /* recomputed per use: hoisted lane offsets would cost 21 registers */ \
+        asm volatile("" : "+v"(pl_));                                                                             \
+        PADEL_Q16_PSPAN(7 * (G_)); PADEL_Q16_PSPAN(7 * (G_) + 1); PADEL_Q16_PSPAN(7 * (G_) + 2); PADEL_Q16_PSPAN(7 * (G_) + 3); \
+        PADEL_Q16_PSPAN(7 * (G_) + 4); PADEL_Q16_PSPAN(7 * (G_) + 5); PADEL_Q16_PSPAN(7 * (G_) + 6);              \
+    } while (0)
+
+    // ---- weights (waves 0..2): a stage = 3 taps x NF spans of 16 rows x 64 bytes; wave w requests the spans w, w + 3, ...
+    // (span s = tap s / NF, row group s % NF); fp16 rows of Ktot = 9 cin halves, k-step (32 channels of one tap) = 64 bytes
+    const int nch = a.cin >> 5;
+    const int nfull64 = a.cin >> 6;
+    const unsigned rowb = (unsigned)a.cin * 18u;
+    const int b_row = lane >> 2;
+    const int b_sc = (lane & 3) ^ ((4 - ((b_row >> 2) & 3)) & 3);
+    unsigned voffB[NF];
+    int tapB[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+        const int sp = min(wave, 2) + 3 * k;
+        const int g = sp % NF;
+        tapB[k] = __builtin_amdgcn_readfirstlane(sp / NF);
+        const int frag = min(f0 + g, a.n16 - 1);
+        voffB[k] = (unsigned)(((frag - f0) * 16 + b_row) * rowb + b_sc * 16);
+    }
+    const p16_i32x4 rsrcB = p16_rsrc(reinterpret_cast<const char*>(a.w) + (long long)f0 * 16 * rowb);
+    unsigned lwB0 = __builtin_amdgcn_readfirstlane(lp0 + 2u * kQ16PatchB + (unsigned)min(wave, 2) * 1024u);
+    unsigned lwB1 = __builtin_amdgcn_readfirstlane(lwB0 + (unsigned)BSTAGE_B);
+    // byte offset of k-step (chunk C_, tap T_) inside a weight row (taps row-major in memory: T_ = 3 ky + kx)
+#define PADEL_Q16_KS(C_, T_) ((unsigned)(((C_) >> 1) < nfull64 ? ((C_) >> 1) * 18 + (T_) * 2 + ((C_) & 1) : nfull64 * 18 + (T_)) * 64u)
+    // column KX_ of chunk C_ into ring stage LW_: this wave's NF spans
+#define PADEL_Q16_DMAB(LW_, C_, KX_)                                                                              \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int k = 0; k < NF; ++k) q16_dma_k<NF>(k, voffB[k], rsrcB, PADEL_Q16_KS(C_, 3 * tapB[k] + (KX_)), (LW_)); \
+    } while (0)
+    const int ld_off = lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);
+    const float* b_rd0 = lds + (2 * kQ16PatchB) / 4 + ld_off;
+    const float* b_rd1 = b_rd0 + BSTAGE_B / 4;
+    const int rd_pix = 4 * wave * kQ16PW + lr;              // patch pixel of the wave's row 0, kx = 0
+
+    p16_f32x4 acc[MF][NF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[f][j] = (p16_f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // stage S_ = kernel column S_ of the current chunk: everything requested one stage earlier has landed for every wave
+    // after the barrier, which also releases the other weight stage and (at S_ == 0) the other patch buffer
+#define PADEL_Q16_STAGE(S_)                                                                                       \
+    do {                                                                                                          \
+        int rp_ = rd_pix;                                  /* row addresses recomputed per stage */                \
+        asm volatile("" : "+v"(rp_));                                                                             \
+        p16_h8 av[6], bv[NF];                                                                                     \
+        if constexpr ((S_) > 0) {                          /* the patch is static inside a chunk: read under the wait */ \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                         \
+                av[r] = *reinterpret_cast<const p16_h8*>(pbuf + p16_off(rp_ + r * kQ16PW + (S_), lq));            \
+        }                                                                                                         \
+        if ((S_) == 0 || wave != 3) p16_wait_all();                                                               \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        asm volatile("" ::: "memory");                                                                            \
+        const float* const br_ = ((S_) & 1) ? b_rd1 : b_rd0;                                                      \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) bv[j] = __builtin_bit_cast(p16_h8, *reinterpret_cast<const p16_f32x4*>(br_ + j * 256)); \
+        if constexpr ((S_) == 0) {                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                         \
+                av[r] = *reinterpret_cast<const p16_h8*>(pbuf + p16_off(rp_ + r * kQ16PW, lq));                   \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        const unsigned lwn_ = ((S_) & 1) ? lwB0 : lwB1;                                                           \
+        if (wave != 3) {                                                                                          \
+            if constexpr ((S_) < 2) { PADEL_Q16_DMAB(lwn_, c, (S_) + 1); }                                        \
+            else { if (c + 1 < nch) PADEL_Q16_DMAB(lwn_, c + 1, 0); }                                             \
+        } else if (c + 1 < nch) {                                                                                 \
+            PADEL_Q16_PATCH(c + 1, (c + 1) & 1, S_);                                                              \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                            \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                           \
+            if (t > 0) {                                                                                          \
+                _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                    \
+                    bv[j] = __builtin_bit_cast(p16_h8, *reinterpret_cast<const p16_f32x4*>(br_ + t * (BTAP_B / 4) + j * 256)); \
+            }                                                                                                     \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
+                _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                    \
+                    acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv[j], av[f + t], acc[f][j], 0, 0, 0);     \
+        }                                                                                                         \
+        __builtin_amdgcn_s_setprio(0);                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+
+    if (wave == 3) { PADEL_Q16_PATCH(0, 0, 0); PADEL_Q16_PATCH(0, 0, 1); PADEL_Q16_PATCH(0, 0, 2); }
+    else PADEL_Q16_DMAB(lwB0, 0, 0);
+    for (int c = 0; c < nch; ++c) {
+        const char* const pbuf = ldsb + (c & 1) * kQ16PatchB;
+        PADEL_Q16_STAGE(0); PADEL_Q16_STAGE(1); PADEL_Q16_STAGE(2);
+        // 3 stages per chunk: the weight stages swap roles
+        { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lwB0; lwB0 = lwB1; lwB1 = u_; }
+    }
+    p16_wait_all();
+#undef PADEL_Q16_STAGE
+#undef PADEL_Q16_DMAB
+#undef PADEL_Q16_KS
+#undef PADEL_Q16_PATCH
+#undef PADEL_Q16_PSPAN
+
+    int mpix[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int oy = y0 + 4 * wave + f, ox = x0 + lr;
+        mpix[f] = (oy < a.Ho && ox < a.Wo) ? (n * a.Ho + oy) * a.Wo + ox : -1;
+    }
+    const bool fast = y0 + 16 <= a.Ho && x0 + 16 <= a.Wo && (f0 + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
+                      (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
+    p16_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
+}
+
+template <int NF>
+static hipError_t launch_p16q(const ConvArgs& a_in, hipStream_t s) {
+    ConvArgs a = a_in;
+    const int batch = a.M / (a.Ho * a.Wo);
+    a.n_mtiles = batch * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
+    a.n_ntiles = (a.n16 + NF - 1) / NF;
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    hipLaunchKernelGGL((conv_p16q_kernel<NF>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 template <int NF>
 static hipError_t launch_p16(const ConvArgs& a_in, hipStream_t s) {
     ConvArgs a = a_in;
@@ -290,13 +495,16 @@ bool conv_p16_supported(const ConvArgs& a) {
     return a.ksize == 3 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 32 && a.Ho == a.H && a.Wo == a.W;
 }
 
-// nf = channel fragments (of 16) per workgroup: 4 (3 workgroups per CU) or 6
+// nf = channel fragments (of 16) per workgroup: 3, 4 (3 workgroups per CU) or 6; + 20: the quad kernel (16 x 16 pixels)
 hipError_t launch_conv_p16(const ConvArgs& a, int nf, hipStream_t s) {
     if (!conv_p16_supported(a)) return hipErrorNotSupported;
     switch (nf) {
         case 3: return launch_p16<3>(a, s);
         case 4: return launch_p16<4>(a, s);
         case 6: return launch_p16<6>(a, s);
+        case 23: return launch_p16q<3>(a, s);       // quad: 16 x 16 pixels x 48 channels
+        case 24: return launch_p16q<4>(a, s);       //                       x 64
+        case 26: return launch_p16q<6>(a, s);       //                       x 96
     }
     return hipErrorNotSupported;
 }

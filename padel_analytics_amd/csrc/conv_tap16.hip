@@ -20,6 +20,7 @@
 //   * convs that feed the Detect/Pose decode write fp32 (ConvArgs::out_f32): the head maps stay fp32, so DFL
 //     softmax / box decode / NMS are the same kernels and the same arithmetic as on the fp32 path.
 #include "kernels.h"
+#include "act_fast.h"
 #include <cmath>
 #include <cstdint>
 
@@ -61,9 +62,9 @@ __device__ __forceinline__ int fastdiv16(int n, unsigned magic, unsigned shift) 
 }
 
 __device__ __forceinline__ float act16(float v, int act) {
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_SILU) return fast_act<ACT_SILU>(v);        // act_fast.h: 11 VALU instead of expf() + an IEEE division
     if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
-    if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == ACT_SIGMOID) return fast_act<ACT_SIGMOID>(v);
     return v;
 }
 
@@ -707,6 +708,17 @@ int choose_conv_tap16_variant(const ConvArgs& a) {
             const long long per_cu = (blocks + 255) / 256;
             const float sc = v.sp * (float)nch / (float)(nch + 1) * fill * (float)blocks / (256.f * (float)per_cu);
             if (sc > best) { best = sc; bv = 300 + v.nf; }
+        }
+        // the quad kernel (16 x 16 pixels x 96 channels per workgroup): 749-770 vs 656-682 TFLOP/s on 96 -> 96, 885 vs 857 on
+        // 192 -> 192; behind on partial channel tiles and on maps that do not fill 16-row tiles (profiles/r3s_sweep_p16q.txt)
+        {
+            const long long qpatches = (long long)(M / (a.Ho * a.Wo)) * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
+            const int ntiles = (n16 + 5) / 6;
+            const float fill = (float)n16 / (float)(ntiles * 6) * (float)M / (float)(qpatches * 256);
+            const long long blocks = qpatches * ntiles;
+            const long long per_cu = (blocks + 255) / 256;
+            const float sc = 1.72f * (float)nch / (float)(nch + 1) * fill * (float)blocks / (256.f * (float)per_cu);
+            if (sc > best) { best = sc; bv = 326; }
         }
     }
     return bv;

@@ -18,6 +18,7 @@
 // (LDS-DMA straight into the operand planes, no VALU in the K loop).
 #pragma once
 #include "bx3_common.h"
+#include "act_fast.h"
 
 namespace padel {
 
@@ -57,29 +58,9 @@ __device__ __forceinline__ void h2_encode4(const f32x4 v, h16x4& h, h16x4& m, bo
     }
 }
 
-// SiLU / sigmoid for the epilogues: e^-x through v_exp_f32 on a compensated argument (the product x * log2(e) carried as
-// hi + lo), the quotient through v_rcp_f32 + one Newton step on the remainder.  11 VALU instead of the 28 of
-// expf() + IEEE division, at the accuracy of the fp32 formula itself (max 2.7 ulp / mean 0.37 ulp against 2.4 / 0.35 for
-// correctly rounded exp + division, measured over 2.5 M arguments in [-90, 90]; profiles/h2_silu_accuracy_r3.txt).
-__device__ __forceinline__ float h2_exp_neg(float x) {           // e^-x, finite for every finite x (clamped at 2^126)
-    const float t = -x * 1.4426950216293335f;
-    float tl = fmaf(-x, 1.4426950216293335f, -t);
-    tl = fmaf(-x, 1.9259629911783190e-8f, tl);
-    const float e0 = __builtin_amdgcn_exp2f(fminf(t, 126.0f));
-    return fmaf(e0, tl * 0.6931471805599453f, e0);
-}
-__device__ __forceinline__ float h2_div(float num, float d) {     // num / d for d in [1, 2^127)
-    const float r = __builtin_amdgcn_rcpf(d);
-    const float y = num * r;
-    return fmaf(fmaf(-y, d, num), r, y);
-}
+// SiLU / sigmoid of the epilogues: act_fast.h (shared with the fp16 kernels)
 template <int ACT>
-__device__ __forceinline__ float h2_act(float x) {
-    if (ACT == ACT_SILU) return h2_div(x, 1.0f + h2_exp_neg(x));
-    if (ACT == ACT_RELU) return x > 0.0f ? x : 0.0f;
-    if (ACT == ACT_SIGMOID) return h2_div(1.0f, 1.0f + h2_exp_neg(x));
-    return x;
-}
+__device__ __forceinline__ float h2_act(float x) { return fast_act<ACT>(x); }
 __device__ __forceinline__ f32x4 h2_decode4(const h16x4 h, const h16x4 m) {
     f32x4 v;
 #pragma unroll

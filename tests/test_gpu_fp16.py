@@ -39,7 +39,7 @@ VARIANTS = (6, 7, 9, 11, 12, 20, 30, 31, 32, 46, 47, 49, 51, 60, 70, 71, 72)
 # fp16 patch kernel (csrc/conv_patch16.hip; stride-1 3x3 only, elsewhere these ids fall back to tap tiles): it walks K as
 # (32-channel chunk, tap) instead of (64-channel chunk, tap, half), so its fp32 sums round differently from the tap
 # kernels' — bitwise equal among its own tiles, same error bound against fp64
-PATCH_VARIANTS = (303, 304, 306)
+PATCH_VARIANTS = (303, 304, 306, 323, 324, 326)       # 32x: the quad kernel (16 x 16 pixels per workgroup)
 
 
 def _run(eng, case, x16, w, b, wr):
