@@ -42,6 +42,7 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0     # same guide: BF16/FP16 MFMA, dense (not the 
 PEAK_BX3_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 6.0, 1)
 # h2 path (default since round 3): activations as fp16 pairs, every fp32 multiply costs 3 f16 products on the same pipe
 PEAK_H2_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 3.0, 1)
+SUSTAINED_FP16_MFMA_TFLOPS = 1750.0     # measured, profiles/r3n_mfma_f16_ubench.txt (reported beside the nominal peak, never instead of it)
 PEAK_BY_IMPL = {"h2": PEAK_H2_TFLOPS, "bx3": PEAK_BX3_TFLOPS, "tap": PEAK_FP32_MFMA_TFLOPS, "lds": PEAK_FP32_MFMA_TFLOPS}
 
 # tracker table: name -> (scale, nc, kpt_shape, imgsz, conf, classes, pre_mode, channel_reverse)
@@ -485,11 +486,13 @@ def main():
                            "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"), "static": True,
                            "source": "profiles/r3_traffic.json: " + tj["source"]}
         out["roofline"] = {
-            "kernel": ("conv_tap16_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x32_f16)"
+            "kernel": ("conv_p16_kernel<NF> / conv_p16q_kernel<NF> (stride-1 3x3 conv+BN+SiLU: input patch in LDS, taps as shifted "
+                       "windows) + conv_tap16_kernel<WM,WN,MF,NF> (stride-2 3x3 implicit GEMM: LDS-DMA ring); v_mfma_f32_16x16x32_f16"
                        if a.dtype == "f16" else
-                       "conv_h2p_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch of fp16-pair activations staged once per "
-                       "32-channel chunk as h / m planes in LDS, 9 shifted-window taps) + conv_h2_kernel<...> (stride-2 3x3: "
-                       "LDS-DMA ring); 3 x v_mfma_f32_16x16x32_f16 per 16x16x32 block, output encoded to pairs in the epilogue"
+                       "conv_h2p_kernel<NF> / conv_h2q_kernel<3> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch of fp16-pair activations "
+                       "staged once per 32-channel chunk as h / m planes in LDS, 9 shifted-window taps; 48 or 96 channels per "
+                       "workgroup) + conv_h2_kernel<...> (stride-2 3x3: LDS-DMA ring); 3 x v_mfma_f32_16x16x32_f16 per 16x16x32 "
+                       "block, output encoded to pairs in the epilogue"
                        if a.impl == "h2" else
                        "conv_bx3p_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch split once per 32-channel chunk into "
                        "bf16 hi/mid/lo planes in LDS, 9 shifted-window taps) + conv_bx3_kernel<...> (stride-2 3x3: LDS-DMA ring, "
@@ -501,6 +504,12 @@ def main():
                           "peak this replaces is 157.3" if (a.dtype == "f32" and a.impl == "bx3") else None),
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
             "frac": round(ach / PEAK, 4), "traffic": traffic if a.dtype == "f32" else None,
+            # what a kernel of nothing but v_mfma_f32_16x16x32_f16 sustains on this chip with random operands (clock under
+            # matrix load; 2.2 PFLOP/s with all-zero operands, 2.5 nominal): tools/mfma_f16_ubench.hip, static like `traffic`
+            "sustained_mfma_peak": ({"value": round(SUSTAINED_FP16_MFMA_TFLOPS / (3.0 if a.dtype == "f32" else 1.0), 1), "unit": "TFLOP/s",
+                                     "frac": round(ach / (SUSTAINED_FP16_MFMA_TFLOPS / (3.0 if a.dtype == "f32" else 1.0)), 4), "static": True,
+                                     "source": "profiles/r3n_mfma_f16_ubench.txt: 1.70-1.80 PFLOP/s at 2-3 waves per SIMD"}
+                                    if (a.dtype == "f16" or a.impl == "h2") else None),
             "launches": len(c3), "avg_launch_ms": round(ms3 / max(len(c3), 1), 4),
             "flops_per_step": fl3, "kernel_ms_per_step": round(ms3, 3),
             "conv1x1": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0, "ms_per_step": round(ms1, 3),

@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256, 2) conv_p16q_kernel(const ConvArgs a) {
     do {                                                                                                          \
         int rp_ = rd_pix;                                  /* row addresses recomputed per stage */                \
         asm volatile("" : "+v"(rp_));                                                                             \
-        p16_h8 av[6], bv[NF];                                                                                     \
+        p16_h8 av[6], bv[2][NF];                           /* weights of the tap in flight / of the next tap */       \
         if constexpr ((S_) > 0) {                          /* the patch is static inside a chunk: read under the wait */ \
             _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                         \
                 av[r] = *reinterpret_cast<const p16_h8*>(pbuf + p16_off(rp_ + r * kQ16PW + (S_), lq));            \
@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(256, 2) conv_p16q_kernel(const ConvArgs a) {
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
         const float* const br_ = ((S_) & 1) ? b_rd1 : b_rd0;                                                      \
-        _Pragma("unroll") for (int j = 0; j < NF; ++j) bv[j] = __builtin_bit_cast(p16_h8, *reinterpret_cast<const p16_f32x4*>(br_ + j * 256)); \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) bv[0][j] = __builtin_bit_cast(p16_h8, *reinterpret_cast<const p16_f32x4*>(br_ + j * 256)); \
         if constexpr ((S_) == 0) {                                                                                \
             _Pragma("unroll") for (int r = 0; r < 6; ++r)                                                         \
                 av[r] = *reinterpret_cast<const p16_h8*>(pbuf + p16_off(rp_ + r * kQ16PW, lq));                   \
@@ -431,13 +431,13 @@ __global__ void __launch_bounds__(256, 2) conv_p16q_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                           \
-            if (t > 0) {                                                                                          \
+            if (t < 2) {                                   /* next tap's weights under this tap's MFMAs */           \
                 _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                    \
-                    bv[j] = __builtin_bit_cast(p16_h8, *reinterpret_cast<const p16_f32x4*>(br_ + t * (BTAP_B / 4) + j * 256)); \
+                    bv[(t + 1) & 1][j] = __builtin_bit_cast(p16_h8, *reinterpret_cast<const p16_f32x4*>(br_ + (t + 1) * (BTAP_B / 4) + j * 256)); \
             }                                                                                                     \
             _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
                 _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                    \
-                    acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv[j], av[f + t], acc[f][j], 0, 0, 0);     \
+                    acc[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bv[t & 1][j], av[f + t], acc[f][j], 0, 0, 0); \
         }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                        \

@@ -717,7 +717,7 @@ int choose_conv_tap16_variant(const ConvArgs& a) {
             const float fill = (float)n16 / (float)(ntiles * 6) * (float)M / (float)(qpatches * 256);
             const long long blocks = qpatches * ntiles;
             const long long per_cu = (blocks + 255) / 256;
-            const float sc = 1.72f * (float)nch / (float)(nch + 1) * fill * (float)blocks / (256.f * (float)per_cu);
+            const float sc = 1.78f * (float)nch / (float)(nch + 1) * fill * (float)blocks / (256.f * (float)per_cu);
             if (sc > best) { best = sc; bv = 326; }
         }
     }

@@ -198,6 +198,9 @@ class TrackingRunner:
             for c in clips:
                 c.free()
 
+        import sys
+        interval = sys.getswitchinterval()                 # see Tracker._predict_batches: the device stage must get the GIL back quickly
+        sys.setswitchinterval(min(interval, 2e-4))
         with ThreadPoolExecutor(max_workers=1) as post:
             pending = []
             for sample in batches():
@@ -213,6 +216,7 @@ class TrackingRunner:
                     t.results.update(f.result())
             for t, f in pending:
                 t.results.update(f.result())
+        sys.setswitchinterval(interval)
         # stream trackers (TrackNet needs the clip's background median before its first window): their own pass —
         # over the same HBM-resident handles when the clip lives in HBM, else a second read of the source
         for t in stream:

@@ -22,6 +22,8 @@ Written from scratch; host logic only (the numeric engines live behind ``padel_a
 """
 from __future__ import annotations
 
+import sys
+
 import json
 from abc import ABC, abstractmethod
 from concurrent.futures import ThreadPoolExecutor
@@ -181,15 +183,23 @@ class Tracker(ABC):
             for sample in _sampler(frame_generator, self.batch_size):
                 update(self.predict_sample(sample, **kwargs))
             return
-        with ThreadPoolExecutor(max_workers=1) as pool:
-            pending = []
-            for sample in _sampler(frame_generator, self.batch_size):
-                raw = self.infer_sample(sample, **kwargs)
-                pending.append(pool.submit(self.post_sample, raw, **kwargs))
-                while len(pending) > 1:                 # keep one host stage in flight behind the device stage
-                    update(pending.pop(0).result())
-            for f in pending:
-                update(f.result())
+        # The device stage blocks inside the C library with the GIL released; when it returns, this thread has to take the
+        # GIL back from the worker, which hands it over only every sys.getswitchinterval() (5 ms by default — the length of
+        # a whole device stage of the small models): a short interval for the duration of the loop
+        interval = sys.getswitchinterval()
+        sys.setswitchinterval(min(interval, 2e-4))
+        try:
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                pending = []
+                for sample in _sampler(frame_generator, self.batch_size):
+                    raw = self.infer_sample(sample, **kwargs)
+                    pending.append(pool.submit(self.post_sample, raw, **kwargs))
+                    while len(pending) > 1:                 # keep one host stage in flight behind the device stage
+                        update(pending.pop(0).result())
+                for f in pending:
+                    update(f.result())
+        finally:
+            sys.setswitchinterval(interval)
 
     def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:
         try:
