@@ -189,9 +189,15 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
                 if (OM == 2) {
                     h16x4 hv, mv;
                     h2_encode4(v, hv, mv, bad);
+#ifdef PADEL_STEM_PROBE            /* ceiling probe (WRONG layout): one 16-byte store per lane, 64 contiguous bytes per pixel and instruction */
+                    char* op = reinterpret_cast<char*>(a.out) + (long long)p * a.out_cs * 4 + (long long)((a.out_choff >> 4) + j) * 64 + lq * 16;
+                    h16x8 both = {hv[0], hv[1], hv[2], hv[3], mv[0], mv[1], mv[2], mv[3]};
+                    *reinterpret_cast<h16x8*>(op) = both;
+#else
                     char* op = reinterpret_cast<char*>(a.out) + (long long)p * a.out_cs * 4 + h2_chan_off(a.out_choff + j * 16 + lq * 4);
                     *reinterpret_cast<h16x4*>(op) = hv;
                     *reinterpret_cast<h16x4*>(op + 32) = mv;
+#endif
                 } else if (OM == 1) {
                     _Float16* oh = reinterpret_cast<_Float16*>(a.out) + o;
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
