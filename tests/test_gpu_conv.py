@@ -27,6 +27,7 @@ CASES = [
     (3, 17, 23, 96, 96, 3, 1, G.ACT_SILU, True),      # odd spatial size: M tail + borders in every tile, residual
     (2, 16, 20, 80, 48, 3, 1, G.ACT_SILU, False),     # two full chunks + tail (cin 80), 48 outputs (128x48 tile)
     (2, 18, 26, 16, 32, 3, 1, G.ACT_SILU, False),     # stride 1 with the tail block only (n-scale's 16 channels), partial patches
+    (2, 20, 24, 64, 192, 3, 1, G.ACT_SILU, True),     # two full 96-channel tiles (quad patch kernel: both channel halves), partial patches in y and x
 ]
 
 LDS_VARIANTS = tuple(range(13))

@@ -34,6 +34,7 @@ CASES = [
     (1, 8, 12, 576, 192, 3, 1, G.ACT_SILU, False),    # long K
     (3, 17, 23, 160, 96, 3, 1, G.ACT_SILU, True),     # two chunks + tail, odd spatial size
     (2, 16, 16, 64, 39, 1, 1, G.ACT_NONE, False),     # cout not a multiple of 4: element-wise epilogue
+    (2, 20, 40, 64, 192, 3, 1, G.ACT_SILU, True),     # two 96-channel tiles, 16-row tiles with a partial last row block (quad patch kernel)
 ]
 VARIANTS = (6, 7, 9, 11, 12, 20, 30, 31, 32, 46, 47, 49, 51, 60, 70, 71, 72)
 # fp16 patch kernel (csrc/conv_patch16.hip; stride-1 3x3 only, elsewhere these ids fall back to tap tiles): it walks K as
