@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const StemArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float x = acc[j][r] + bias4[j][r];
-                    v[r] = OM == 2 ? h2_act<ACT_SILU>(x) : x / (1.0f + expf(-x));
+                    v[r] = OM != 0 ? h2_act<ACT_SILU>(x) : x / (1.0f + expf(-x));     // fast SiLU (act_fast.h) for the h2 and fp16 models
                 }
                 const long long o = (long long)p * a.out_cs + a.out_choff + j * 16 + lq * 4;
                 if (OM == 2) {
