@@ -120,3 +120,39 @@ def test_bf16x3_split_is_exact_and_packed_in_lane_order():
     assert steps[13][16:] == [None] * 16
     assert len(G.bx3_ksteps(48, 1)) == 2 and len(G.bx3_ksteps(16, 3)) == 5 and len(G.bx3_ksteps(96, 3)) == 27
     assert sorted(G.BX3_PERM.tolist()) == list(range(32))
+
+
+def test_h2_pairs_and_column_major_weight_pack():
+    """h2 (csrc/h2_common.h): a value as an fp16 pair h + m / 2048 keeps 22-23 bits; weight rows are scaled by a power of
+    two so that both planes sit in the normal fp16 range; the k-steps of a 3x3 walk the taps COLUMN-major (k-step t of a
+    chunk = tap (ky, kx) = (t % 3, t // 3)) and the 16-channel tail pairs consecutive taps of that order."""
+    rng = np.random.default_rng(5)
+    x = (rng.normal(size=4096) * 10.0 ** rng.integers(-3, 4, 4096)).astype(np.float32)
+    x = x[np.abs(x) < 6.0e4]
+    h, m = G.h2_split(x)
+    back = G.h2_value(h, m)
+    big = np.abs(x) > 1.2e-4
+    assert np.all(np.abs(back[big] - x[big]) <= np.abs(x[big]) * 2.0 ** -22)
+    assert np.all(np.abs(back[~big] - x[~big]) <= 3e-11)
+    w = (rng.normal(size=(32, 48, 3, 3)) * 10.0 ** rng.integers(-4, 2, (32, 1, 1, 1))).astype(np.float32)
+    planes, inv = G.pack_conv_weight_h2(w)                    # cin 48: one full chunk x 9 taps + 5 tap-paired tail steps
+    assert planes.shape == (32, 14, 2, 32) and inv.shape == (32,)
+    sc = 1.0 / inv
+    assert np.all(np.log2(sc) == np.round(np.log2(sc)))       # powers of two: the scaling itself is exact
+    top = np.abs(w.reshape(32, -1)).max(1) * sc
+    assert np.all((top >= 2.0 ** 12) & (top < 2.0 ** 13))
+    val = G.h2_value(planes[:, :, 0].view(np.float16), planes[:, :, 1].view(np.float16)) * inv[:, None, None]      # (32, 14, 32)
+    for t in range(9):                                        # full chunk, k-step t: channels 0..31 at tap (t % 3, t // 3)
+        want = w[:, :32, t % 3, t // 3]
+        assert np.all(np.abs(val[:, t] - want) <= np.abs(want) * 2.0 ** -21 + 1e-12), t
+    for jt in range(5):                                       # tail: slots 0..15 = channels 32..47 at tap 2 jt, 16..31 = at tap 2 jt + 1
+        ta, tb = 2 * jt, 2 * jt + 1
+        assert np.all(np.abs(val[:, 9 + jt, :16] - w[:, 32:, ta % 3, ta // 3]) <= np.abs(w[:, 32:, ta % 3, ta // 3]) * 2.0 ** -21 + 1e-12)
+        if tb < 9:
+            assert np.all(np.abs(val[:, 9 + jt, 16:] - w[:, 32:, tb % 3, tb // 3]) <= np.abs(w[:, 32:, tb % 3, tb // 3]) * 2.0 ** -21 + 1e-12)
+        else:
+            assert np.all(val[:, 9 + jt, 16:] == 0.0)
+    o = dict(ksize=3, cin=48, npad=32, w_off=0, reserved=planes.size // 2, b_off=planes.size // 2 + 32)
+    blob = np.concatenate([planes.reshape(-1).view(np.float32), inv, np.zeros(32, np.float32)])
+    wu, _ = graph_interp.unpack_conv_h2(blob, o)
+    assert np.all(np.abs(wu - w) <= np.abs(w) * 2.0 ** -21 + 1e-12)
