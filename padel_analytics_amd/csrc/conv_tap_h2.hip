@@ -328,6 +328,10 @@ static hipError_t launch_h2t(const ConvArgs& a_in, hipStream_t s) {
 // not apply, its tap sibling
 hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
     if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16 || !a.w || !a.oscale || !a.ovf_flag) return hipErrorNotSupported;
+    if (variant >= 341 && variant <= 343) {  // the wide patch kernel for 16 / 32 / 48 input channels (conv_patch_h2w.hip), 1..3 channel fragments
+        if (conv_h2w_supported(a)) return launch_conv_h2w(a, variant - 340, s);
+        variant = 303;
+    }
     if (variant == 323) {                  // the quad patch kernel (conv_patch_h2q.hip); where it does not apply, the 48-channel patch tile
         if (conv_h2q_supported(a)) return launch_conv_h2q(a, s);
         variant = 303;
@@ -352,6 +356,9 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
 
 // Per-layer tile choice.  Relative speeds start from the bf16x3 measurements (profiles/conv_bx3_sweep_r2*.txt) and are
 // re-measured for h2 in profiles/conv_h2_sweep_r3*.txt; the rest is padding waste and the fill of the last round.
+static const float kH2WSpeed[3] = {1.28f, 1.42f, 1.46f};  // relative speed of the wide patch kernel with 1 / 2 / 3 fragments: 16 -> 16: 121 vs 42 TFLOP/s,
+                                                           // 32 -> 32: 185 vs 148, 48 -> 48: 244 vs 211 for the best 8 x 16 / tap tile (profiles/r3_sweep_h2w.txt)
+
 int choose_conv_h2_variant(const ConvArgs& a) {
     const int M = a.M, n16 = a.n16, ksize = a.ksize;
     struct V { int id, bm, nf; float s3, s1; };
@@ -392,6 +399,19 @@ int choose_conv_h2_variant(const ConvArgs& a) {
             const long long per_cu = (blocks + 255) / 256;
             const float sc = 1.21f * fill * (float)blocks / (256.f * (float)per_cu);
             if (sc > best) { best = sc; bv = 323; }
+        }
+        // few input channels (16 / 32 / 48: 5-14 k-steps): the wide patch kernel keeps the whole K extent of a 16 x 16 pixel
+        // tile in LDS (conv_patch_h2w.hip; measured against the 8 x 16 tiles in profiles/r3_sweep_h2w.txt)
+        if (conv_h2w_supported(a)) {
+            const long long wpatches = (long long)(M / (a.Ho * a.Wo)) * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
+            for (int nf = 1; nf <= 3; ++nf) {
+                const int ntiles = (n16 + nf - 1) / nf;
+                const float fill = (float)n16 / (float)(ntiles * nf) * (float)M / (float)(wpatches * 256);
+                const long long blocks = wpatches * ntiles;
+                const long long per_cu = (blocks + 255) / 256;
+                const float sc = kH2WSpeed[nf - 1] * fill * (float)blocks / (256.f * (float)per_cu);
+                if (sc > best) { best = sc; bv = 340 + nf; }
+            }
         }
         // cin % 32 == 16 (yolov8m's 48-channel P2 layers): 14 short steps per tile — there the software-pipelined schedule
         // (313: operand reads of the next step under this step's main products) measured +6..9 % although it runs 2 waves

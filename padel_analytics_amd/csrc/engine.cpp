@@ -714,7 +714,8 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             const bool use_tap = e->t.impl == 0 || f16;
             const bool use_bx3 = a.w3 != nullptr;
             int bm = 0, bn = 0;
-            if (h2 && lv == 323) { bm = 128; bn = 96; }                       // quad patch kernel: 8 x 16 pixels x 96 channels
+            if (h2 && lv == 323) { bm = 128; bn = 96; }
+            else if (h2 && lv >= 341 && lv <= 343) { bm = 256; bn = (lv - 340) * 16; }      // wide patch kernel: 16 x 16 pixels                       // quad patch kernel: 8 x 16 pixels x 96 channels
             else if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
             else if (f16) conv_tap16_variant_shape(lv, &bm, &bn);
             else if (lv >= 300) { bm = 128; bn = (lv - 300) * 16; }          // patch kernel: 8 x 16 pixels x nf fragments

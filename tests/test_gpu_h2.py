@@ -18,7 +18,7 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 303, 304, 306, 313, 314, 323)      # 31x: software-pipelined patch schedule; 323: the quad patch kernel
+H2_TILES = (207, 209, 211, 213, 220, 225, 303, 304, 306, 313, 314, 323, 341, 342, 343)      # 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
 H2_SINGLE_LEVEL = (306,)        # patch tile with 6 fragments: main product accumulated in one level (registers)
 
 
