@@ -489,7 +489,7 @@ def main():
             "kernel": ("conv_p16_kernel<NF> / conv_p16q_kernel<NF> (stride-1 3x3 conv+BN+SiLU: input patch in LDS, taps as shifted "
                        "windows) + conv_tap16_kernel<WM,WN,MF,NF> (stride-2 3x3 implicit GEMM: LDS-DMA ring); v_mfma_f32_16x16x32_f16"
                        if a.dtype == "f16" else
-                       "conv_h2p_kernel<NF> / conv_h2q_kernel<3> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch of fp16-pair activations "
+                       "conv_h2p_kernel<NF> / conv_h2q_kernel<3> / conv_h2w_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16- or 16x16-pixel patch of fp16-pair activations "
                        "staged once per 32-channel chunk as h / m planes in LDS, 9 shifted-window taps; 48 or 96 channels per "
                        "workgroup) + conv_h2_kernel<...> (stride-2 3x3: LDS-DMA ring); 3 x v_mfma_f32_16x16x32_f16 per 16x16x32 "
                        "block, output encoded to pairs in the epilogue"

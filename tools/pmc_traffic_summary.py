@@ -31,7 +31,7 @@ def main():
     wl, ops_csv, d_fetch, d_write = sys.argv[1:5]
     impl = sys.argv[5] if len(sys.argv) > 5 else "tap"
     # bx3: stride-1 layers run the patch kernel (conv_patch_bx3.hip), stride-2 layers the tap kernel
-    KERNEL = {"tap": ("conv_tap_kernel",), "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel"), "h2": ("conv_h2p_kernel", "conv_h2q_kernel", "conv_h2_kernel")}[impl]
+    KERNEL = {"tap": ("conv_tap_kernel",), "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel"), "h2": ("conv_h2p_kernel", "conv_h2q_kernel", "conv_h2w_kernel", "conv_h2_kernel")}[impl]
     fetch_kib, n_f = per_kernel(d_fetch, "FETCH_SIZE")
     write_kib, n_w = per_kernel(d_write, "WRITE_SIZE")
     alg, n_ops = 0.0, 0
