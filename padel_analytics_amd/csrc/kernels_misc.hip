@@ -263,13 +263,15 @@ __global__ void __launch_bounds__(256) pool5_kernel(typename VecT<V>::E* buf, in
     const int x = (int)(t % W); t /= W;
     const int y = (int)(t % H);
     const int n = (int)(t / H);
-    V m = *reinterpret_cast<const V*>(buf + (((long long)n * H + y) * W + x) * cs + src_off + c4 * VN);   // the centre is always inside
+    // window coordinates are CLAMPED to the map instead of skipped: a clamped tap re-reads a pixel of the window, which cannot
+    // change a maximum, and 25 unconditional loads issue back to back where 25 guarded ones wait for each other
+    V m = *reinterpret_cast<const V*>(buf + (((long long)n * H + y) * W + x) * cs + src_off + c4 * VN);
+#pragma unroll
     for (int dy = -2; dy <= 2; ++dy) {
-        const int yy = y + dy;
-        if ((unsigned)yy >= (unsigned)H) continue;
+        const int yy = min(max(y + dy, 0), H - 1);
+#pragma unroll
         for (int dx = -2; dx <= 2; ++dx) {
-            const int xx = x + dx;
-            if ((unsigned)xx >= (unsigned)W) continue;
+            const int xx = min(max(x + dx, 0), W - 1);
             m = vmax(m, *reinterpret_cast<const V*>(buf + (((long long)n * H + yy) * W + xx) * cs + src_off + c4 * VN));
         }
     }
@@ -307,12 +309,13 @@ __global__ void __launch_bounds__(256) pool5_h2_kernel(float* buf, int cs, int s
     const int y = (int)(t % H);
     const int n = (int)(t / H);
     H2Unit m = h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + y) * W + x, cs, src_off, u));
+    // clamped window (see pool5_kernel): a re-read pixel compares equal (strict >: the earlier pair stays), the result is the same
+#pragma unroll
     for (int dy = -2; dy <= 2; ++dy) {
-        const int yy = y + dy;
-        if ((unsigned)yy >= (unsigned)H) continue;
+        const int yy = min(max(y + dy, 0), H - 1);
+#pragma unroll
         for (int dx = -2; dx <= 2; ++dx) {
-            const int xx = x + dx;
-            if ((unsigned)xx >= (unsigned)W) continue;
+            const int xx = min(max(x + dx, 0), W - 1);
             m = h2_max_unit(h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + yy) * W + xx, cs, src_off, u)), m);
         }
     }
