@@ -179,11 +179,12 @@ class PlayerTracker(Tracker):
             sel = sel & (ids >= 0)
         else:
             ids = None
-        out = []
-        for i in range(n):
-            idx = np.nonzero(sel[i])[0]
-            out.append(Players(rows=boxes[i, idx], ids=None if ids is None else ids[i, idx].astype(int)))
-        return out
+        # one gather for the whole batch, then per-frame views (row-major boolean indexing keeps frame and row order)
+        rows = boxes[sel]
+        cuts = np.cumsum(sel.sum(axis=1))[:-1]
+        rows_f = np.split(rows, cuts)
+        ids_f = [None] * n if ids is None else np.split(ids[sel].astype(int), cuts)
+        return [Players(rows=rows_f[i], ids=ids_f[i]) for i in range(n)]
 
     def post_sample(self, raw, **kwargs) -> list:
         boxes, counts = raw
