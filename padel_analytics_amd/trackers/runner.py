@@ -201,22 +201,24 @@ class TrackingRunner:
         import sys
         interval = sys.getswitchinterval()                 # see Tracker._predict_batches: the device stage must get the GIL back quickly
         sys.setswitchinterval(min(interval, 2e-4))
-        with ThreadPoolExecutor(max_workers=1) as post:
-            pending = []
-            for sample in batches():
-                for t in batch:
-                    for sub in _sampler(iter(sample), t.batch_size):
-                        if t._has_stages():
-                            raw = t.infer_sample(sub)
-                            pending.append((t, post.submit(t.post_sample, raw)))
-                        else:
-                            t.results.update(t.predict_sample(sub))
-                while len(pending) > len(batch):           # host stages trail the device stages by one batch
-                    t, f = pending.pop(0)
+        try:
+            with ThreadPoolExecutor(max_workers=1) as post:
+                pending = []
+                for sample in batches():
+                    for t in batch:
+                        for sub in _sampler(iter(sample), t.batch_size):
+                            if t._has_stages():
+                                raw = t.infer_sample(sub)
+                                pending.append((t, post.submit(t.post_sample, raw)))
+                            else:
+                                t.results.update(t.predict_sample(sub))
+                    while len(pending) > len(batch):           # host stages trail the device stages by one batch
+                        t, f = pending.pop(0)
+                        t.results.update(f.result())
+                for t, f in pending:
                     t.results.update(f.result())
-            for t, f in pending:
-                t.results.update(f.result())
-        sys.setswitchinterval(interval)
+        finally:
+            sys.setswitchinterval(interval)
         # stream trackers (TrackNet needs the clip's background median before its first window): their own pass —
         # over the same HBM-resident handles when the clip lives in HBM, else a second read of the source
         for t in stream:
