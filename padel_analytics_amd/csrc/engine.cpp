@@ -32,6 +32,7 @@ struct Tuning {
     int graph = 0;       // 1: replay the op list of a (model, batch) from a captured hipGraph
     int timeline = 0;    // 1: 3x3 tap launches of the 64x96 tile run the s_memtime-instrumented instantiation
     int alias = 1;       // 1: activation buffers share one arena by liveness, 0: disjoint ranges
+    int fuse_stem = 0;   // 1: h2 YOLOv8 graphs run model.0 (stem) + model.1 (3x3 stride 2) as ONE kernel (stem_l1_h2.hip; opt-in)
     int fold_up = 1;     // 1: an nn.Upsample(2) whose only reader is a bf16x3 1x1 conv is never materialised (the conv
                          // fetches those channels at [y >> 1][x >> 1] of the coarse map), 0: run the upsample kernel
 };
@@ -144,6 +145,7 @@ int pa_engine_create(int device_id, pa_engine** out) {
     e->t.tune = env_int("PADEL_CONV_TUNE", 1);
     e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
     e->t.graph = env_int("PADEL_GRAPH", 0);
+    e->t.fuse_stem = env_int("PADEL_FUSE_STEM", 0);
     e->t.alias = env_int("PADEL_ALIAS", 1);
     e->t.fold_up = env_int("PADEL_FOLD_UP", 1);
     *out = e;
@@ -161,6 +163,7 @@ int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     else if (k == "timeline") e->t.timeline = value ? 1 : 0;
     else if (k == "alias") e->t.alias = value ? 1 : 0;
     else if (k == "fold_up") e->t.fold_up = value ? 1 : 0;
+    else if (!strcmp(key, "fuse_stem")) e->t.fuse_stem = value;
     else PA_FAIL(e, "pa_engine_set_tuning: unknown key '%s'", key);
     e->tuning_epoch++;
     return 0;
@@ -697,6 +700,24 @@ static int conv_launch_args(const pa_model* m, size_t i, int n, ConvArgs& a) {
     return lv;
 }
 
+// op i is the stem, op i + 1 a 3x3 stride-2 conv over exactly the stem's channels, and nothing else reads the stem's output
+static bool stem_fusable(const pa_model* m, size_t i) {
+    if (i + 1 >= m->ops.size()) return false;
+    const pa_op_desc& st = m->ops[i];
+    const pa_op_desc& c = m->ops[i + 1];
+    if (c.kind != PA_OP_CONV || c.ksize != 3 || c.stride != 2 || c.in_buf != st.out_buf || c.in_choff != st.out_choff || c.cin != st.cout ||
+        c.res_buf >= 0)
+        return false;
+    for (int l = 0; l < 3; ++l) if (m->d.head_buf[l] == st.out_buf) return false;
+    for (size_t k = 0; k < m->ops.size(); ++k) {
+        if (k == i || k == i + 1) continue;
+        const pa_op_desc& o = m->ops[k];
+        if (o.kind != PA_OP_STEM && o.in_buf == st.out_buf) return false;
+        if (o.kind == PA_OP_CONV && o.res_buf == st.out_buf) return false;
+    }
+    return true;
+}
+
 // replay the op list for `n` images (prof records appended starting at *pi)
 static int run_ops(pa_model* m, int n, size_t* pi) {
     pa_engine* e = m->e;
@@ -763,6 +784,19 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             a.out_f16 = m->d.dtype == PA_DTYPE_F16 ? 1 : m->d.dtype == PA_DTYPE_H2 ? 2 : 0;
             a.ovf_flag = m->d_ovf;
             pr = prof_begin(m, (*pi)++, o.kind, 3, 2.0 * n * Ho * Wo * (double)o.cout * 27);
+            // tuning "fuse_stem": the stem and the stride-2 3x3 behind it (its only reader) as one kernel; the conv's own
+            // turn in this loop is skipped (the profile shows both under the stem's record)
+            if (e->t.fuse_stem && m->d.dtype == PA_DTYPE_H2 && stem_fusable(m, i)) {
+                ConvArgs ca{};
+                conv_launch_args(m, i + 1, n, ca);
+                if (stem_l1_h2_supported(a, ca)) {
+                    r = launch_stem_l1_h2(a, ca, s);
+                    prof_end(m, pr);
+                    if (r != hipSuccess) PA_FAIL(e, "fused stem + layer 1 launch failed: %s", hipGetErrorString(r));
+                    ++i;
+                    continue;
+                }
+            }
             r = launch_stem(a, s);
         } else if (o.kind == PA_OP_SPPF_POOL) {
             pr = prof_begin(m, (*pi)++, o.kind, 5, 0.0);

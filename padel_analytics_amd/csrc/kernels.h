@@ -105,6 +105,9 @@ struct StemArgs {
     unsigned howo_magic, howo_shift, wo_magic, wo_shift;   // filled by launch_stem (fill_fastdiv): pixel index -> (n, oy, ox)
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
+struct ConvArgs;
+bool stem_l1_h2_supported(const StemArgs& st, const ConvArgs& cv);        // stem_l1_h2.hip: stem + the 3x3 stride-2 conv behind it, one kernel
+hipError_t launch_stem_l1_h2(const StemArgs& st, const ConvArgs& cv, hipStream_t s);
 
 // SPPF: three chained MaxPool2d(5,1,2) of slice [choff, choff+c) written to the next three slices
 // (f16 == 1 in these three: the buffers hold _Float16 elements; cs / choff / c count elements, c % 8 == 0;

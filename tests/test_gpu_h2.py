@@ -264,3 +264,38 @@ def test_stale_arena_bytes_cannot_reach_results(gpu_engine, mode):
     y1 = t.tracknet_infer(x)
     assert np.isfinite(y1).all() and np.array_equal(y0, y1)
     t.close()
+
+
+@pytest.mark.parametrize("scale,hw,imgsz", [("n", (360, 640), 640), ("s", (180, 320), 288), ("m", (180, 320), 288), ("m", (360, 640), 640)],
+                         ids=["n-640", "s-288", "m-288", "m-640"])
+def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
+    """Tuning "fuse_stem" (csrc/stem_l1_h2.hip, opt-in): model.0 + model.1 as one kernel — the stem map stays in LDS.  Same
+    arithmetic in the same order as the two kernels it replaces: head maps and detections are bitwise those of the unfused
+    run (c = 16: tail-only K walk; 32: one chunk; 48: chunk + tail with the LDS region reused; partial tiles at 288)."""
+    from padel_analytics_amd import synth, yolo_arch
+    h, w = hw
+    frames = synth.synthetic_frames(3, h, w, seed=9)
+    sd = yolo_arch.synth_state_dict(scale, 80, None, seed=3, cls_bias=-1.0)
+    m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None, dtype="h2"))
+    m.set_max_batch(3)
+    kw = dict(imgsz=imgsz, conf=0.25, iou=0.7)
+    gpu_engine.set_profiling(True)
+    try:
+        b0, _, c0 = m.yolo_infer(frames, 3, h, w, **kw)
+        h0 = [m.read_head(l, 3) for l in range(3)]
+        n_convs0 = sum(1 for r in m.profile_rows() if r["kind"] == 2)
+        assert not m.take_overflow()
+        gpu_engine.set_tuning(fuse_stem=1)
+        b1, _, c1 = m.yolo_infer(frames, 3, h, w, **kw)
+        h1 = [m.read_head(l, 3) for l in range(3)]
+        n_convs1 = sum(1 for r in m.profile_rows() if r["kind"] == 2)
+        assert not m.take_overflow()
+    finally:
+        gpu_engine.set_tuning(fuse_stem=0)
+        gpu_engine.set_profiling(False)
+        m.close()
+    assert n_convs1 == n_convs0 - 1, "the fused kernel did not run (layer 1 was launched on its own)"
+    for l, (x, y) in enumerate(zip(h0, h1)):
+        assert np.isfinite(y).all()
+        assert np.array_equal(x, y), f"head {l}: max difference {np.abs(x - y).max():.3e}"
+    assert np.array_equal(c0, c1) and np.array_equal(b0, b1)
