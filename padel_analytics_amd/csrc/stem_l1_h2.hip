@@ -41,10 +41,12 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
     constexpr int BPLANE_B = BN * 64, BSTAGE_B = 2 * BPLANE_B;
     constexpr int S_B = CHUNK ? 2 * kFPlaneB : 2 * kFTPlaneB;      // the tail planes of c = 48 reuse the chunk's region
     constexpr int NSTEPS = (CHUNK ? 9 : 0) + (TAIL ? 5 : 0);
-    static_assert(S_B + 2 * BSTAGE_B + 1024 <= 80 * 1024, "2 workgroups per CU");
-    __shared__ __attribute__((aligned(16))) float lds[(S_B + 2 * BSTAGE_B + 1024) / 4];
+    constexpr int NSTG = 3;                          // weight ring: step T + 2 is requested while step T computes (a layer-1 step
+                                                     // is 18 MFMAs per wave: with a 2-stage ring every step waited out a DMA round trip)
+    static_assert(S_B + NSTG * BSTAGE_B + 1024 <= 80 * 1024, "2 workgroups per CU");
+    __shared__ __attribute__((aligned(16))) float lds[(S_B + NSTG * BSTAGE_B + 1024) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
-    float* const lut = lds + (S_B + 2 * BSTAGE_B) / 4;
+    float* const lut = lds + (S_B + NSTG * BSTAGE_B) / 4;
     const int tid = threadIdx.x;
     lut[tid] = (float)tid / 255.0f;
     const int lane = tid & 63;
@@ -81,14 +83,16 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
     const i32x4 rsrcB = make_rsrc3(a.w);
     const unsigned lw0 = __builtin_amdgcn_readfirstlane(lp0 + (unsigned)S_B + (unsigned)wave * 1024u);
     const unsigned lw1 = __builtin_amdgcn_readfirstlane(lw0 + (unsigned)BSTAGE_B);
+    const unsigned lw2 = __builtin_amdgcn_readfirstlane(lw1 + (unsigned)BSTAGE_B);
 #define PADEL_FS_DMAB(ST_)                                                                                        \
     do {                                                                                                          \
-        const unsigned lw_ = ((ST_) & 1) ? lw1 : lw0;                                                             \
+        const unsigned lw_ = ((ST_) % 3) == 0 ? lw0 : ((ST_) % 3) == 1 ? lw1 : lw2;                               \
         dma3<0>(voffB[0], rsrcB, (unsigned)(ST_) * 128u, lw_);                                                    \
         if constexpr (NF >= 2) dma3<4096>(voffB[NF >= 2 ? 1 : 0], rsrcB, (unsigned)(ST_) * 128u, lw_);            \
         if constexpr (NF >= 3) dma3<8192>(voffB[NF >= 3 ? 2 : 0], rsrcB, (unsigned)(ST_) * 128u, lw_);            \
     } while (0)
     PADEL_FS_DMAB(0);
+    PADEL_FS_DMAB(1);
     __syncthreads();                                 // the u8 -> float table
 
     // ---- phase 1 operands: per owned fragment i (global fragment wave + 4 i) the 8 K slots of this lane (k = 4 kk + lq ->
@@ -172,6 +176,7 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
     const int ld_off = (wc * NF) * 256 + lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);      // floats
     const float* const b_rd0 = lds + S_B / 4 + ld_off;
     const float* const b_rd1 = b_rd0 + BSTAGE_B / 4;
+    const float* const b_rd2 = b_rd1 + BSTAGE_B / 4;
     f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
 #pragma unroll
     for (int f = 0; f < MF; ++f)
@@ -182,7 +187,7 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
 #define PADEL_FS_ENT(F_, T_) fs_entry(2 * (2 * wr + (F_)) + h2_tap_ky(T_), 2 * lr + h2_tap_kx(T_))
 #define PADEL_FS_READB(ST_)                                                                                       \
     do {                                                                                                          \
-        const float* const br_ = ((ST_) & 1) ? b_rd1 : b_rd0;                                                     \
+        const float* const br_ = ((ST_) % 3) == 0 ? b_rd0 : ((ST_) % 3) == 1 ? b_rd1 : b_rd2;                     \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
             wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256));     \
@@ -199,16 +204,17 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
             part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], part[f][j], 0, 0, 0);               \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
-    // step ST_ of the K walk: barrier = this step's weights (requested one step earlier) have landed for every wave and the
-    // other stage is free for the request of step ST_ + 1
+    // step ST_ of the K walk: this wave's requests of the step (issued TWO steps earlier; vmcnt is in-order: the NF requests
+    // of step ST_ + 1 may stay in flight) have landed; barrier = they have for every wave, and the stage read in step ST_ - 1
+    // is free for the request of step ST_ + 2
 #define PADEL_FS_SYNC(ST_)                                                                                        \
     do {                                                                                                          \
-        wait_vm3<0>();                                                                                            \
+        if constexpr ((ST_) + 1 < NSTEPS) wait_vm3<NF>(); else wait_vm3<0>();                                     \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
         PADEL_FS_READB(ST_);                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        if ((ST_) + 1 < NSTEPS) PADEL_FS_DMAB((ST_) + 1);                                                         \
+        if constexpr ((ST_) + 2 < NSTEPS) PADEL_FS_DMAB((ST_) + 2);                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 #define PADEL_FS_READA(T_)                                                                                        \
