@@ -94,11 +94,15 @@ def parse():
                     help="fp32-equivalent conv arithmetic: h2 (default: activations as fp16 pairs, 3 products on the f16 matrix "
                          "pipe, corrections in their own accumulator), bx3 (exact 3-way bf16 split, 6 products; the full-range "
                          "fallback of h2), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
+    ap.add_argument("--quick", action="store_true", help="tuning runs: runner + engine-only + roofline only (no CPU leg, host-frames leg, reference-default leg)")
     ap.add_argument("--no-tight", action="store_true", help="skip the low-noise-head parity leg of the CPU baseline section")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the parity path (the reference runs half=False) — the headline; f16: fp16 activations / "
                          "weights with fp32 accumulation (BASELINE configs[4]), reports its own L-inf vs the fp32 oracle")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.quick:
+        a.no_cpu_baseline = a.no_host_frames = a.no_reference_default = True
+    return a
 
 
 def source_for_oracle(cfg, frames):
@@ -404,12 +408,11 @@ def main():
                            "objects_total": total, "build_all_ms": round(1e3 * (time.perf_counter() - t1_), 2)}
             out["objects_materialised"] = om
         if not a.no_host_frames and not a.engine_only:
-            hclip = video.ArrayClip(frames, repeat=max(K, 1)).pin(eng)        # a decoder writing into page-locked memory
-            run_runner(hclip, 1)
-            dt_s, _ = run_runner(hclip, K)
-            run_runner(hclip, 1, fanout=True, engine=eng)
-            dt_f, _ = run_runner(hclip, K, fanout=True, engine=eng)
-            hclip.unpin()
+            with video.ArrayClip(frames, repeat=max(K, 1)).pin(eng) as hclip:     # a decoder writing into page-locked memory
+                run_runner(hclip, 1)
+                dt_s, _ = run_runner(hclip, K)
+                run_runner(hclip, 1, fanout=True, engine=eng)
+                dt_f, _ = run_runner(hclip, K, fanout=True, engine=eng)
             out["host_frames"] = {"sequential_frames_per_s": round(world * B * K / dt_s, 2),
                                   "fanout_frames_per_s": round(world * B * K / dt_f, 2), "pinned": True,
                                   "what": "clip in page-locked host memory (hipHostRegister), PCIe-inclusive: one upload per "

@@ -55,6 +55,19 @@ def broadcast_flag(value: bool, src: int = 0) -> bool:
     return bool(box[0])
 
 
+def any_flag(value: bool) -> bool:
+    """True on every rank iff `value` is true on at least one (a collective: every rank must call it)."""
+    import torch
+    import torch.distributed as dist
+    if world_size() == 1:
+        return bool(value)
+    t = torch.tensor([1 if value else 0], dtype=torch.int32)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(int(t.cpu()[0]))
+
+
 def share_unique_id(make_id) -> bytes:
     """RCCL bootstrap for ``Engine.comm_init``: rank 0 calls ``make_id()`` (``engine.comm_unique_id``), the 128
     bytes reach the other ranks through the process group's store (TCP, out of band of the data path)."""

@@ -157,11 +157,15 @@ def h2_decode_nhwc(e: np.ndarray) -> np.ndarray:
 
 def h2_row_scale(w2d: np.ndarray) -> np.ndarray:
     """Per output channel power of two s with max |w| * s in [2^12, 2^13): keeps both planes of a weight row in the
-    normal fp16 range whatever the magnitude of the folded weights; all-zero (padding) rows get 1."""
+    normal fp16 range whatever the magnitude of the folded weights; all-zero (padding) and denormal rows get 1."""
     mx = np.abs(w2d).max(axis=1)
     s = np.ones_like(mx, dtype=np.float32)
-    nz = mx > 0
-    s[nz] = np.exp2(12.0 - np.floor(np.log2(mx[nz].astype(np.float64)))).astype(np.float32)
+    # rows whose largest weight is below the smallest normal fp32 number (dead BN-folded channels: gamma ~ 0) count as
+    # all-zero: their scale would leave the fp32 range (inf * 0 = NaN planes, 1 / inf = 0).  The exponent is clamped so that
+    # both s and 1 / s are normal fp32 numbers for every other row
+    nz = mx >= np.float32(np.finfo(np.float32).tiny)
+    e = np.clip(12.0 - np.floor(np.log2(mx[nz].astype(np.float64))), -100.0, 100.0)
+    s[nz] = np.exp2(e).astype(np.float32)
     return s
 
 

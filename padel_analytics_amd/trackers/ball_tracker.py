@@ -109,6 +109,18 @@ class BallTracker(Tracker):
 
     def restart(self) -> None: self.results.restart()
 
+    @property
+    def full_range(self) -> bool:
+        return self.graph.dtype != G.DTYPE_H2
+
+    def use_full_range(self) -> None:
+        if self.graph.dtype == G.DTYPE_H2:
+            if self._model is not None:
+                self._model.close()
+                self._model = None
+            self.fp32_mode = "bx3"
+            self.graph = G.build_tracknet(self._state_dict, dtype="f32")
+
     def to(self, device: str) -> None:
         if str(device).startswith("cuda"):
             if self._model is None:
@@ -214,10 +226,7 @@ class BallTracker(Tracker):
         if self.graph.dtype == G.DTYPE_H2 and self._model.take_overflow():
             # activations beyond the fp16 range: the stream has been consumed, so the caller (TrackingRunner) restarts
             # this tracker; from now on it runs the full-range bf16x3 arithmetic
-            self._model.close()
-            self._model = None
-            self.fp32_mode = "bx3"
-            self.graph = G.build_tracknet(self._state_dict, dtype="f32")
+            self.use_full_range()
             raise E.RangeOverflow("TrackNet activations left the fp16 range: tracker switched to the bf16x3 path, run it again")
         if len(out) < n_fed:                       # fewer than 8 frames fed: no window, no detection (reference :688-696)
             out += [None] * (n_fed - len(out))

@@ -44,7 +44,9 @@ class TrackingRunner:
         self.total_frames = self.video_info.total_frames if end is None else end - start
         # frames actually available from `start` on (the reference reports the whole clip's length when end is None,
         # runner.py:52; the sharded path must split what the generator really yields)
-        self.n_available = max(0, self.video_info.total_frames - start) if end is None else max(0, end - start)
+        # (an `end` beyond the clip is clamped: the shards must add up to what the generator yields, or the last ranks come
+        # up short and the others wait in the gather for ever)
+        self.n_available = max(0, (self.video_info.total_frames if end is None else min(end, self.video_info.total_frames)) - start)
         self.trackers = {}
         for tracker in trackers:
             self.trackers[str(tracker)] = tracker.video_info_post_init(self.video_info)
@@ -122,8 +124,29 @@ class TrackingRunner:
         head, tail = min(ch, lo), min(ct, n - hi)
         if ch or ct:
             self._share_background(tracker)
-        partial = tracker.predict_partial(self._frames(lo - head, hi + tail), first_frame=lo, head_context=head,
-                                          tail_context=tail, total_frames=hi - lo) if hi > lo else []
+        from .. import engine as E
+
+        def attempt():
+            if hi <= lo:
+                return [], False
+            try:
+                return tracker.predict_partial(self._frames(lo - head, hi + tail), first_frame=lo, head_context=head,
+                                               tail_context=tail, total_frames=hi - lo), False
+            except E.RangeOverflow as ex:                  # a stream tracker switched itself to the full-range kernels
+                print(f"{str(tracker)}: {ex}")
+                return None, True
+
+        was_full = tracker.full_range
+        partial, over = attempt()
+        # h2 -> bx3 is decided for ALL ranks at once: a rank whose shard overflowed (stream trackers raise, batch trackers
+        # switch inside the offending batch) must not leave the others waiting in the gather, and the merged result must
+        # come from one arithmetic.  Every rank enters this collective
+        if D.any_flag(over or (not was_full and tracker.full_range)):
+            print(f"{str(tracker)}: activations left the fp16 range on some rank — every rank repeats its shard on the bf16x3 path")
+            tracker.use_full_range()
+            tracker.to(tracker.DEVICE)
+            partial, over = attempt()
+            assert not over
         assert len(partial) == hi - lo, (str(tracker), len(partial), lo, hi)
         allp = D.gather_results(partial, dst=0)
         if rank == 0:

@@ -160,6 +160,23 @@ class Tracker(ABC):
     def to(self, device: str) -> None:
         """Move the tracker's model(s) to ``device`` (weights go to HBM on "cuda")."""
 
+    # ---- arithmetic of the fp32-equivalent path (engine.fp32_mode): the default "h2" covers |x| <= 65504 and switches a
+    # model to the full-range "bx3" kernels when an activation leaves that range.  A sharded run must take that decision
+    # for ALL ranks at once (TrackingRunner._predict_sharded), so trackers expose it
+    @property
+    def full_range(self) -> bool:
+        """True when the tracker's model(s) cannot overflow any more (bx3 / fp16 models, or nothing to switch)."""
+        m = getattr(self, "model", None)
+        if m is not None and hasattr(m, "fp32_mode"):
+            return bool(getattr(m, "half", False)) or m.fp32_mode != "h2"
+        return True
+
+    def use_full_range(self) -> None:
+        """Put the tracker on the full-range arithmetic (rebuilds the packed graph; the HBM model follows on next use)."""
+        m = getattr(self, "model", None)
+        if m is not None and hasattr(m, "set_fp32_mode"):
+            m.set_fp32_mode("bx3")
+
     @abstractmethod
     def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> Optional[list]: ...
 

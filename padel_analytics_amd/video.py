@@ -125,12 +125,28 @@ class ArrayClip:
         if self._pinned_by is None:
             engine.pin(self.array)
             self._pinned_by = engine
+        elif self._pinned_by is not engine:
+            raise ValueError("ArrayClip is page-locked through another engine: unpin() it first")
         return self
 
     def unpin(self) -> None:
         if self._pinned_by is not None:
-            self._pinned_by.unpin(self.array)
-            self._pinned_by = None
+            eng, self._pinned_by = self._pinned_by, None
+            eng.unpin(self.array)
+
+    # a page-locked range must be unregistered before numpy frees it (a stale registration makes later registrations /
+    # copies of recycled pages fail): `with ArrayClip(...).pin(eng) as clip:` or let the finaliser do it
+    def __enter__(self) -> "ArrayClip":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.unpin()
+
+    def __del__(self):
+        try:
+            self.unpin()
+        except Exception:
+            pass
 
     @property
     def total_frames(self) -> int:

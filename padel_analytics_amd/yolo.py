@@ -86,6 +86,9 @@ class YOLO:
         self._engine = engine
         self._model: Optional[E.Model] = None
         self.max_batch = 64
+        #: set when an h2 model overflowed and this object rebuilt itself on the bx3 kernels (infer_frames); callers that
+        #: hold the old E.Model handle (bench, tests) or coordinate several ranks (TrackingRunner) read it
+        self.fell_back = False
 
     def _graph_dtype(self) -> str:
         return "f16" if self.half else ("h2" if self.fp32_mode == "h2" else "f32")
@@ -196,6 +199,7 @@ class YOLO:
             # an activation left the fp16 range: this checkpoint needs the full-range arithmetic from now on
             print(f"padel_analytics_amd: activations beyond the fp16 range — switching this model to the bf16x3 path")
             self.set_fp32_mode("bx3")
+            self.fell_back = True
             boxes, kpts, counts = self._ensure_model().yolo_infer(src, n, h, w, **kw)
         return boxes, kpts, counts, (h, w), int(imgsz), pre_mode
 

@@ -1,5 +1,10 @@
 """Worker of tests/test_distributed_gloo.py (one process per rank, gloo).  Modes:
   blob   — broadcast_blob / shard_range / gather_results plumbing;
+  overflow / fullrange — the runner mode with models that carry the fp32-equivalent arithmetic switch (h2 -> bx3): in
+           "overflow" ONE rank's models leave the fp16 range in the middle of their shard (a batch tracker switches itself
+           inside the offending batch, the stream tracker raises engine.RangeOverflow); every rank must then repeat its
+           shard on the full-range path, and the merged predictions must equal a run that was on that path from the start
+           ("fullrange") — ADVICE r3: the other ranks used to block in the gather for ever;
   runner — the REAL tracker host logic (TrackingRunner, PlayerTracker + PolygonZone + native ByteTrack,
            PlayerKeypointsTracker, BallTracker with the 7-frame TrackNet halo + InpaintNet, BallDetectTracker) over
            a FAKE engine whose per-frame outputs are a deterministic function of the frame pixels and whose ball
@@ -22,6 +27,10 @@ def frame_seed(f) -> int:
     return int(a[::7, ::5].astype(np.int64).sum() % 2147483647)
 
 
+OVERFLOW_RANK = -1        # "overflow" mode: the rank whose models leave the fp16 range once
+MY_RANK = 0
+
+
 class FakeYOLO:
     """Stands in for padel_analytics_amd.yolo.YOLO: same infer_frames contract, outputs keyed on frame content."""
 
@@ -29,13 +38,28 @@ class FakeYOLO:
         self.task = "pose" if "pose" in str(model_path) else "detect"
         self.kpt_shape = (13, 3) if self.task == "pose" else None
         self.names = {0: "person"}
+        self.calls = 0
 
     def to(self, device): return self
+
+    # the arithmetic switch of yolo.YOLO, present only in the overflow / fullrange modes (FakeYOLO.fp32_mode is set there)
+    def set_fp32_mode(self, mode): self.fp32_mode = mode
+
+    def _shift(self):
+        """What the arithmetic does to the numbers (visible, so that a merge of two arithmetics cannot pass): the second
+        call of the overflowing rank's h2 model switches to bx3 like yolo.YOLO.infer_frames does."""
+        if not hasattr(self, "fp32_mode"):
+            return 0.0
+        self.calls += 1
+        if self.fp32_mode == "h2" and MY_RANK == OVERFLOW_RANK and self.calls == 2:
+            self.fp32_mode, self.fell_back = "bx3", True
+        return 0.25 if self.fp32_mode == "bx3" else 0.0
 
     def infer_frames(self, frames, conf, iou, imgsz, classes=None, max_det=300, *, channel_reverse, pil_stretch=False):
         frames = list(frames)
         n = len(frames)
         h, w = frames[0].shape[:2]
+        shift = self._shift()
         boxes = np.zeros((n, max_det, 6), np.float32)
         counts = np.zeros(n, np.int32)
         nk = 39 if self.task == "pose" else 0
@@ -47,8 +71,8 @@ class FakeYOLO:
             k = min(max_det, 5 + int(rng.integers(0, 3)))
             c = np.concatenate([base + rng.normal(0, 1.5, base.shape), rng.uniform([0, 0], [w, h], (max(k - 5, 0), 2))])[:k]
             wh = np.array([w * 0.08, h * 0.25])
-            boxes[i, :k, :2] = c - wh / 2
-            boxes[i, :k, 2:4] = c + wh / 2
+            boxes[i, :k, :2] = c - wh / 2 + shift
+            boxes[i, :k, 2:4] = c + wh / 2 + shift
             boxes[i, :k, 4] = np.sort(rng.uniform(max(conf, 0.3), 0.95, k))[::-1]
             counts[i] = 0 if (self.task == "detect" and max_det == 1 and rng.random() < 0.2) else k
             if nk:
@@ -58,19 +82,29 @@ class FakeYOLO:
 
 
 class FakeModel:
-    def __init__(self, engine, graph, blob=None, **kw): self.max_batch = 64
+    overflows_left = 0        # "overflow" mode: how many h2 TrackNet runs of this process still leave the fp16 range
+
+    def __init__(self, engine, graph, blob=None, **kw): self.max_batch = 64; self.graph = graph
     def set_max_batch(self, n): self.max_batch = int(n)
     def close(self): pass
-    def take_overflow(self): return False
+
+    def take_overflow(self):
+        from padel_analytics_amd import graph as G
+        if FakeModel.overflows_left > 0 and self.graph.dtype == G.DTYPE_H2:
+            FakeModel.overflows_left -= 1
+            return True
+        return False
 
 
 class FakeBallSession:
     """pa_ball_feed's stream semantics on scalar 'heat maps': window g slot s = f(frame g+s, g)."""
 
     def __init__(self, model, h, w):
+        from padel_analytics_amd import graph as G
         self.max_feed = model.max_batch
         self.h, self.w = h, w
         self.u, self.bg = [], 0.0
+        self.shift = 0.0 if model.graph.dtype == G.DTYPE_H2 else 0.013       # the arithmetic is visible in the heat maps
 
     def set_background(self, med): self.bg = float(np.asarray(med, np.float64).mean()) / 255.0; self.u = []
 
@@ -83,7 +117,7 @@ class FakeBallSession:
     def feed(self, frames, flush=False, want_heat=False, want_rects=False, want_masks=True, n=None):
         from oracle import ball_ref
         if frames is not None:
-            self.u += [(frame_seed(f) % 1000) / 1000.0 for f in frames]
+            self.u += [(frame_seed(f) % 1000) / 1000.0 + self.shift for f in frames]
         rects = np.zeros((0, 4), np.int32)
         if flush and len(self.u) >= 8:
             F = len(self.u)
@@ -100,8 +134,10 @@ class FakeBallSession:
     def close(self): pass
 
 
-def run_runner(rank, world, out):
+def run_runner(rank, world, out, mode="runner"):
     import tempfile
+    global OVERFLOW_RANK, MY_RANK
+    MY_RANK = rank
     from oracle import tracknet_ref as tr
     from padel_analytics_amd import checkpoint, detections as D, engine as E, yolo
     from padel_analytics_amd.trackers import (BallDetectTracker, BallTracker, PlayerKeypointsTracker, PlayerTracker,
@@ -111,6 +147,10 @@ def run_runner(rank, world, out):
         mod.YOLO = FakeYOLO
     E.Model, E.BallSession = FakeModel, FakeBallSession
     E.default_engine = lambda *a, **k: None
+    if mode in ("overflow", "fullrange"):
+        FakeYOLO.fp32_mode, FakeYOLO.half, FakeYOLO.fell_back = "h2", False, False
+        if mode == "overflow":
+            OVERFLOW_RANK = world - 1
     src = "synthetic://?n=45&h=72&w=128&fps=30&seed=3"
     tmp = Path(tempfile.mkdtemp())
     checkpoint.save_checkpoint(tmp / "tracknet.pt", tr.synth_tracknet_state_dict(9), "tracknet",
@@ -122,8 +162,17 @@ def run_runner(rank, world, out):
         ball = (BallTracker(str(tmp / "tracknet.pt"), str(tmp / "inpaint.pt"), batch_size=8, median_max_sample_num=20)
                 if ball_cls == "tracknet" else BallDetectTracker("ball.pt", batch_size=8))
         trackers = [PlayerTracker("players.pt", zone, batch_size=8), PlayerKeypointsTracker("pose.pt", 640, batch_size=8), ball]
+        if mode == "fullrange":
+            for t in trackers:
+                t.use_full_range()
+                assert t.full_range
+        elif mode == "overflow":
+            assert not any(t.full_range for t in trackers)
+            FakeModel.overflows_left = 1 if rank == OVERFLOW_RANK else 0
         runner = TrackingRunner(trackers, src, tmp / "out.mp4", distributed=world > 1)
         runner.run()
+        if mode == "overflow":
+            assert all(t.full_range for t in trackers), "every rank ends on the full-range arithmetic"
         if rank == 0:
             res[ball_cls] = {str(t): [o.serialize() for o in t.results.predictions] for t in trackers}
     if rank == 0:
@@ -150,7 +199,10 @@ def main():
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    (run_runner if mode == "runner" else run_blob)(rank, world, out)
+    if mode == "blob":
+        run_blob(rank, world, out)
+    else:
+        run_runner(rank, world, out, mode)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

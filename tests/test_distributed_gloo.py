@@ -70,3 +70,27 @@ def test_sharded_runner_equals_single_process(single_process_reference, tmp_path
     assert any(p["id"] for fr in ref["tracknet"]["players_tracker"] for p in fr)
     assert sum(b["visibility"] for b in ref["tracknet"]["ball_tracker"]) > 5
     assert sum(b["visibility"] for b in ref["detect"]["ball_tracker"]) > 5
+
+
+def test_sharded_runner_agrees_on_the_full_range_fallback(tmp_path):
+    """One rank's models leave the fp16 range in the middle of its shard: nobody hangs, every rank repeats its
+    shard on the bf16x3 path and the merged predictions are those of a run that was on that path from the first frame."""
+    want = _launch("fullrange", 1, tmp_path / "full.json")
+    got = _launch("overflow", 2, tmp_path / "over.json")
+    plain = _launch("runner", 1, tmp_path / "plain.json")
+    for variant in ("tracknet", "detect"):
+        for name in ("players_tracker", "players_keypoints_tracker", "ball_tracker"):
+            assert got[variant][name] == want[variant][name], (variant, name)
+    # the fake arithmetic is visible: the h2 run differs, so a result merged from two arithmetics could not have passed
+    assert plain["detect"]["players_tracker"] != want["detect"]["players_tracker"]
+
+
+def test_runner_clamps_end_beyond_the_clip():
+    """n_available is what the generator will yield: an `end` past the last frame must not inflate the shards."""
+    from padel_analytics_amd.trackers import TrackingRunner
+    src = "synthetic://?n=20&h=36&w=64&fps=30&seed=1"
+    assert TrackingRunner([], src, "out.mp4", start=0, end=50).n_available == 20
+    assert TrackingRunner([], src, "out.mp4", start=5, end=50).n_available == 15
+    assert TrackingRunner([], src, "out.mp4", start=5, end=12).n_available == 7
+    assert TrackingRunner([], src, "out.mp4", start=5).n_available == 15
+    assert TrackingRunner([], src, "out.mp4", start=30, end=50).n_available == 0

@@ -156,3 +156,24 @@ def test_h2_pairs_and_column_major_weight_pack():
     blob = np.concatenate([planes.reshape(-1).view(np.float32), inv, np.zeros(32, np.float32)])
     wu, _ = graph_interp.unpack_conv_h2(blob, o)
     assert np.all(np.abs(wu - w) <= np.abs(w) * 2.0 ** -21 + 1e-12)
+
+
+def test_h2_row_scale_survives_denormal_and_huge_rows():
+    """A dead BN-folded channel (weights ~ 1e-40) used to get the scale 2^12 / 2^-133 = inf: NaN planes, 1 / s = 0
+    (ADVICE r3).  Denormal rows count as all-zero; every scale and its inverse are normal fp32 numbers."""
+    w = np.zeros((16, 16, 1, 1), np.float32)
+    w[0] = 1e-40
+    w[1] = 3.0e38
+    w[2] = 1e-30
+    w[3, 0] = 1.0
+    sc = G.h2_row_scale(w.reshape(16, -1))
+    assert np.all(np.isfinite(sc)) and np.all(sc > 0) and np.all(np.isfinite(1.0 / sc)) and np.all(1.0 / sc > 0)
+    assert sc[0] == 1.0 and sc[4] == 1.0 and sc[3] == 2.0 ** 12
+    planes, inv = G.pack_conv_weight_h2(w)
+    assert np.all(np.isfinite(inv)) and np.all(inv > 0)
+    val = G.h2_value(planes[:, :, 0].view(np.float16), planes[:, :, 1].view(np.float16))
+    assert np.all(np.isfinite(val))
+    back = val[:, 0, :16] * inv[:, None]
+    assert np.all(back[0] == 0.0)                                   # the denormal row contributes nothing (as in fp16 it cannot)
+    assert np.all(np.abs(back[2] - 1e-30) <= 1e-30 * 2.0 ** -21)     # 2^100 keeps a 1e-30 row in the normal fp16 range
+    assert np.all(np.abs(back[3, 0] - 1.0) <= 2.0 ** -21)
