@@ -94,14 +94,26 @@ def parse():
                     help="fp32-equivalent conv arithmetic: h2 (default: activations as fp16 pairs, 3 products on the f16 matrix "
                          "pipe, corrections in their own accumulator), bx3 (exact 3-way bf16 split, 6 products; the full-range "
                          "fallback of h2), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
+    ap.add_argument("--fake-engine", action="store_true",
+                    help="TEST ONLY (tests/test_bench_gloo.py): run main() over tests/fake_engine.py with the gloo backend — the "
+                         "launcher contract, barriers, max-over-ranks timing and the weight broadcast without a GPU; the line "
+                         "carries \"fake_engine\": true and is not a measurement")
+    ap.add_argument("--traffic", default="live", choices=["live", "static", "none"],
+                    help="roofline.traffic: live = two rocprofv3 --pmc passes over this script's engine-only step (needs rocprofv3; "
+                         "falls back to static), static = the committed measurement profiles/r4_traffic.json")
+    ap.add_argument("--no-eager", action="store_true", help="skip the eager-result-objects leg (value_eager_objects)")
     ap.add_argument("--quick", action="store_true", help="tuning runs: runner + engine-only + roofline only (no CPU leg, host-frames leg, reference-default leg)")
     ap.add_argument("--no-tight", action="store_true", help="skip the low-noise-head parity leg of the CPU baseline section")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16"],
                     help="f32: the parity path (the reference runs half=False) — the headline; f16: fp16 activations / "
                          "weights with fp32 accumulation (BASELINE configs[4]), reports its own L-inf vs the fp32 oracle")
     a = ap.parse_args()
+    if a.fake_engine:
+        a.quick = a.no_roofline = True
     if a.quick:
-        a.no_cpu_baseline = a.no_host_frames = a.no_reference_default = True
+        a.no_cpu_baseline = a.no_host_frames = a.no_reference_default = a.no_eager = a.no_compare = True
+        if a.traffic == "live":
+            a.traffic = "static"
     return a
 
 
@@ -118,15 +130,23 @@ def source_for_oracle(cfg, frames):
 _SD_CACHE = {}
 
 
-def make_state_dict(name, cfg, frames):
+def make_state_dict(name, cfg, frames, frac=0.01, seed_offset=0):
     """Setup (untimed): seeded synthetic checkpoint with data-calibrated BatchNorm statistics
     (oracle/synth_weights.py — weight synthesis, not part of the measured path).  1280-input models
     are calibrated on a 640x640 centre crop of the network input (same statistics, 4x cheaper)."""
     import zlib
     # (the fingerprint of the calibration frames is part of the key: tests build the same tracker for different clips)
-    key = (name, cfg["scale"], cfg["nc"], cfg["kpt"], cfg["imgsz"], zlib.crc32(np.ascontiguousarray(frames[:2]).tobytes()))
+    key = (name, cfg["scale"], cfg["nc"], cfg["kpt"], cfg["imgsz"], frac, seed_offset, zlib.crc32(np.ascontiguousarray(frames[:2]).tobytes()))
     if key in _SD_CACHE:
         return _SD_CACHE[key]
+    # the PMC passes of the roofline section re-run this script under rocprofv3: they find the checkpoints of the parent here
+    cdir = os.environ.get("PADEL_BENCH_SD_CACHE")
+    cfile = Path(cdir) / ("sd_" + "_".join(str(k) for k in key).replace(" ", "").replace("(", "").replace(")", "").replace(",", "x") + ".npz") if cdir else None
+    if cfile is not None and cfile.exists():
+        with np.load(cfile) as z:
+            sd = {k: z[k] for k in z.files}
+        _SD_CACHE[key] = sd
+        return sd
     from oracle import synth_weights, yolov8_ref as ref
     srcs = source_for_oracle(cfg, frames[:2])
     im = ref.preprocess(srcs, cfg["imgsz"])
@@ -134,9 +154,72 @@ def make_state_dict(name, cfg, frames):
         o = (im.shape[2] - 640) // 2
         im = im[:, :, o:o + 640, o:o + 640].contiguous()
     sd = synth_weights.calibrated_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], im, cfg["conf"],
-                                             seed=sum(map(ord, name)))
+                                             seed=sum(map(ord, name)) + seed_offset, frac=frac)
     _SD_CACHE[key] = sd
+    if cfile is not None:
+        np.savez(cfile, **{k: np.asarray(v) for k, v in sd.items()})
     return sd
+
+
+H2_CONV3_KERNELS = {"h2": ("conv_h2p_kernel", "conv_h2q_kernel", "conv_h2w_kernel", "conv_h2_kernel"),
+                    "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel"), "tap": ("conv_tap_kernel",), "lds": ("conv_lds_kernel",)}
+
+
+def measure_traffic(a, ops_rows, tmp):
+    """HBM bytes of the dominant kernels (every 3x3 conv launch of one step), per launch, from the PMC counters collected
+    exactly as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE in SEPARATE rocprofv3 --pmc
+    passes with --kernel-trace only, over this script's own engine-only step; FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies
+    the 128-byte requests of wide coalesced reads, `buffer_load ... lds` included, at 64 B), WRITE_SIZE (KiB) x 1024 as is.
+    Returns None when rocprofv3 is not there or a pass fails (the caller falls back to the committed measurement)."""
+    import csv
+    import glob
+    import shutil
+    if shutil.which("rocprofv3") is None:
+        return None
+    kernels = H2_CONV3_KERNELS[a.impl]
+    tot = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = Path(tmp) / f"pmc_{counter}"
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", str(d), "-o", "p", "--",
+               sys.executable, str(Path(__file__).resolve()), "--workload", a.workload, "--impl", a.impl, "--steps", "1", "--warmup", "1",
+               "--batch", str(a.batch), "--height", str(a.height), "--width", str(a.width), "--quick", "--engine-only", "--no-roofline"]
+        if a.scales:
+            cmd += ["--scales", a.scales]
+        env = dict(os.environ, TMPDIR="/tmp", PADEL_BENCH_SD_CACHE=str(tmp))
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+        except (subprocess.TimeoutExpired, OSError):
+            return None
+        if r.returncode != 0:
+            sys.stderr.write(f"bench: PMC pass {counter} failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-400:]}\n")
+            return None
+        v, disp = 0.0, set()
+        for f in glob.glob(f"{d}/**/*counter_collection.csv", recursive=True):
+            for row in csv.DictReader(open(f)):
+                if row["Counter_Name"] == counter and any(k + "<" in row["Kernel_Name"] for k in kernels):
+                    v += float(row["Counter_Value"])
+                    disp.add((f, row["Dispatch_Id"]))
+        if not disp:
+            return None
+        tot[counter] = (v, len(disp))
+        shutil.rmtree(d, ignore_errors=True)
+    alg, n_ops = 0.0, 0
+    for r in ops_rows:
+        if r["kind"] == 2 and r["ksize"] == 3:
+            st = r["stride"]
+            alg += r["M"] * st * st * r["cin"] * 4 + r["M"] * r["cout"] * 4 + 9 * r["cin"] * r["cout"] * (6 if a.impl == "bx3" else 4)
+            n_ops += 1
+    if not n_ops:
+        return None
+    fetch = tot["FETCH_SIZE"][0] * 1024 * 2 / tot["FETCH_SIZE"][1]
+    write = tot["WRITE_SIZE"][0] * 1024 / tot["WRITE_SIZE"][1]
+    return {"bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
+            "algorithmic_bytes_per_launch": round(alg / n_ops), "ratio_to_algorithmic": round((fetch + write) / (alg / n_ops), 3),
+            "launches_counted": {"FETCH_SIZE": tot["FETCH_SIZE"][1], "WRITE_SIZE": tot["WRITE_SIZE"][1], "ops_per_step": n_ops},
+            "static": False,
+            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over "
+                      "`bench.py --engine-only --steps 1` of the same workload; FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), "
+                      "WRITE_SIZE KiB x 1024"}
 
 
 def parity_low_noise_heads(eng, names, frames, sample, H, W, ref, parity):
@@ -212,7 +295,7 @@ def spawn_ranks(a) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False):
+def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False, frac=0.01, tag=""):
     """The three plugin classes exactly as main.py:126-161 constructs them, over synthetic checkpoints.  Only rank 0
     synthesises / "loads" real weights; the other ranks create their models from an architecture-only checkpoint
     with an EMPTY weight blob in HBM and receive rank 0's blob through pa_engine_bcast_weights."""
@@ -221,8 +304,8 @@ def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False):
     trackers, flops = {}, {}
     for name in names:
         cfg = TRACKERS[name]
-        sd = make_state_dict(name, cfg, frames) if rank == 0 else yolo_arch.synth_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], 0)
-        path = Path(tmp) / f"{name}_r{rank}.pt"
+        sd = make_state_dict(name, cfg, frames, frac[name] if isinstance(frac, dict) else frac) if rank == 0 else yolo_arch.synth_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], 0)
+        path = Path(tmp) / f"{name}{tag}_r{rank}.pt"
         checkpoint.save_checkpoint(path, sd, "pose" if cfg["kpt"] else "detect", cfg["nc"], cfg["kpt"], cfg["scale"],
                                    {0: "person" if name != "ball" else "ball"})
         if name == "players":
@@ -265,12 +348,19 @@ def main():
     import torch
     from padel_analytics_amd import dist as D, engine as E, synth, video
     from padel_analytics_amd.trackers import TrackingRunner
+    fake = None
+    if a.fake_engine:
+        from tests import fake_engine as fake
+        fake.install()
 
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # barriers of the contract
+        if fake is None:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))     # barriers of the contract
+        else:
+            dist.init_process_group("gloo")
         # setup (weight synthesis / packing) is host work in every rank: share the cores instead of oversubscribing
         torch.set_num_threads(max(1, min(64, (os.cpu_count() or 8) // world)))
 
@@ -293,19 +383,22 @@ def main():
     frames = synth.synthetic_frames(B, H, W, seed=1000 + rank)          # each rank its own shard
     clip = video.DeviceClip(eng, frames, repeat=max(K, Wm, 1))           # resident in HBM before timing
     tmp = tempfile.mkdtemp(prefix="padel_bench_")
+    os.environ.setdefault("PADEL_BENCH_SD_CACHE", tmp)      # calibrated checkpoints on disk: the PMC sub-runs (measure_traffic) reuse them
     with contextlib.redirect_stdout(sys.stderr):
         trackers, flops_per_frame = build_trackers(names, frames, rank, B, H, W, eng, tmp, half=a.dtype == "f16")
 
     def fence():
         eng.synchronize()
         if world > 1:
-            torch.cuda.synchronize()
+            if fake is None:
+                torch.cuda.synchronize()
             dist.barrier()
-            torch.cuda.synchronize()
+            if fake is None:
+                torch.cuda.synchronize()
 
-    def run_runner(source, n_batches, **kw):
+    def run_runner(source, n_batches, trk=None, **kw):
         """One TrackingRunner.run() over n_batches x B frames; returns seconds (max over ranks)."""
-        runner = TrackingRunner(list(trackers.values()), source, Path(tmp) / "out.mp4", start=0, end=n_batches * B, **kw)
+        runner = TrackingRunner(list((trk or trackers).values()), source, Path(tmp) / "out.mp4", start=0, end=n_batches * B, **kw)
         runner.restart()
         fence()
         t0 = time.perf_counter()
@@ -318,17 +411,42 @@ def main():
         tot = 0
         for name in names:
             cfg = TRACKERS[name]
-            boxes, kpts, counts = trackers[name].model._model.yolo_infer(
+            boxes, kpts, counts = trackers[name].model._ensure_model().yolo_infer(
                 clip.buffer, B, H, W, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7, classes=cfg["classes"],
                 max_det=1 if name == "ball" else 300,
                 pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg["rev"])
             tot += int(counts.sum())
         return tot
 
+    def fp32_mfma_leg():
+        """The same engine-only steps on the STRICT fp32 kernels (fp32 storage, v_mfma_f32_16x16x4_f32: fp32 in, fp32
+        accumulate, 157.3 TFLOP/s pipe) — the number that carries no equivalence argument.  h2 trackers are rebuilt on fp32
+        storage for it (so it runs last on that path)."""
+        for t_ in trackers.values():
+            t_.model.set_fp32_mode("bx3")                  # fp32 storage graphs (what the fp32-input kernels read)
+            t_.model.set_max_batch(B)
+        eng.set_tuning(impl=0)
+        engine_step()
+        fence()
+        t0_ = time.perf_counter()
+        for _ in range(K):
+            engine_step()
+        fence()
+        dt_m = eng.allreduce_max(time.perf_counter() - t0_)
+        eng.set_tuning(impl=IMPL[a.impl])
+        return {"value": round(world * B * K / dt_m, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_m / K, 3),
+                "what": "fp32 storage + fp32-input MFMA (v_mfma_f32_16x16x4_f32), engine-only; peak 157.3 TFLOP/s"}
+
     out = {
         "metric": "frames/sec (all trackers) on 1280x720", "value": None, "unit": "frames/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": None,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # what the path computes in: NOT plain fp32 arithmetic on the default path (VERDICT r3) — fp32-equivalent pairs of fp16
+        "dtype": ("f16" if a.dtype == "f16" else
+                  "f32-equivalent (h2: activations / weights as fp16 pairs h + m/2048, 3 x f16 MFMA products, fp32 accumulate)" if a.impl == "h2" else
+                  "f32 (bx3: exact 3-way bf16 split of fp32 operands, 6 x bf16 MFMA products, fp32 accumulate)" if a.impl == "bx3" else
+                  "f32 (fp32-input MFMA)"),
+        "data": "synthetic",
         "arithmetic": ("fp32-equivalent: every activation is an fp16 PAIR x ~ h + m/2048 (22-23 significant bits, 4 bytes per "
                        "channel) written once by its producer, weights pre-split the same way per scaled row; a product is "
                        "ah*wh + (ah*wm + am*wh)/2048 = 3 x v_mfma_f32_16x16x32_f16 with the corrections in their own fp32 "
@@ -365,17 +483,7 @@ def main():
         out["engine_only"] = {"value": round(world * B * K / dt_e, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_e / K, 3),
                               "what": "the same K steps calling pa_yolo_infer directly: no Detections / PolygonZone / ByteTrack / objects"}
         if a.dtype == "f32" and a.impl == "bx3" and not a.no_compare:
-            # the same engine-only steps on round 1's fp32-input MFMA kernels, for reference
-            eng.set_tuning(impl=0)
-            engine_step()
-            fence()
-            t0 = time.perf_counter()
-            for _ in range(K):
-                engine_step()
-            fence()
-            dt_m = eng.allreduce_max(time.perf_counter() - t0)
-            eng.set_tuning(impl=IMPL[a.impl])
-            out["engine_only"]["fp32_mfma_kernels"] = {"value": round(world * B * K / dt_m, 2), "ms_per_step": round(1e3 * dt_m / K, 3)}
+            out["engine_only"]["fp32_mfma_kernels"] = fp32_mfma_leg()
         out["config"]["detections_per_step_rank0"] = ndet
         # ---- through the runner (the metric's path)
         if not a.engine_only:
@@ -407,6 +515,45 @@ def main():
                 om[nm_] = {"containers": len(preds), "lazy": True, "objects_built_inside_timed_region": inside,
                            "objects_total": total, "build_all_ms": round(1e3 * (time.perf_counter() - t1_), 2)}
             out["objects_materialised"] = om
+        if not a.engine_only and not a.no_eager:
+            # The reference builds every Player / PlayerKeypoints object inside predict_sample (players_tracker.py:371-378,
+            # players_keypoints_tracker.py:303-320); `value` builds them on first access (none inside the timed region).  Same
+            # run with the containers in eager mode: (i) on the timed checkpoints, whose class bias is calibrated so that ~1 %
+            # of the anchors pass (hundreds of detections per frame: decode / NMS do real work, object construction is
+            # unrepresentatively heavy); (ii) on a second calibration of the same graphs with a court-like handful of
+            # detections per frame.
+            from padel_analytics_amd import trackers as T
+
+            def per_frame(trk):
+                return {n_: round(sum(len(p_) for p_ in t_.results.predictions) / max(len(t_.results.predictions), 1), 2)
+                        for n_, t_ in trk.items() if n_ != "ball"}
+            T.set_eager_objects(True)
+            try:
+                run_runner(clip, 1)
+                dt_g, _ = run_runner(clip, K)
+                ve = {"timed_checkpoints": {"value": round(world * B * K / dt_g, 2), "ms_per_step": round(1e3 * dt_g / K, 3),
+                                            "objects_per_frame": per_frame(trackers)}}
+                if world == 1:
+                    with contextlib.redirect_stdout(sys.stderr):
+                        rtrk, _ = build_trackers(names, frames, rank, B, H, W, eng, tmp, half=a.dtype == "f16",
+                                                 frac={"players": 0.0012, "ball": 0.002, "pose": 0.00024}, tag="_real")
+                    T.set_eager_objects(False)
+                    run_runner(clip, 1, trk=rtrk)
+                    dt_l, _ = run_runner(clip, K, trk=rtrk)
+                    T.set_eager_objects(True)
+                    run_runner(clip, 1, trk=rtrk)
+                    dt_r, _ = run_runner(clip, K, trk=rtrk)
+                    ve["realistic_detections"] = {"value": round(world * B * K / dt_r, 2), "ms_per_step": round(1e3 * dt_r / K, 3),
+                                                  "value_lazy_objects": round(world * B * K / dt_l, 2),
+                                                  "objects_per_frame": per_frame(rtrk),
+                                                  "what": "same graphs, class-bias calibrated for a handful of detections per frame"}
+                    for t_ in rtrk.values():
+                        t_.model.close()
+            finally:
+                T.set_eager_objects(False)
+            ve["what"] = ("TrackingRunner.run() with Player / PlayerKeypoints objects built inside predict_sample like the reference; "
+                          "`value` is the same run with those objects built on first access (objects_materialised)")
+            out["value_eager_objects"] = ve
         if not a.no_host_frames and not a.engine_only:
             with video.ArrayClip(frames, repeat=max(K, 1)).pin(eng) as hclip:     # a decoder writing into page-locked memory
                 run_runner(hclip, 1)
@@ -477,17 +624,24 @@ def main():
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         PEAK = PEAK_FP16_MFMA_TFLOPS if a.dtype == "f16" else PEAK_BY_IMPL[a.impl]
         traffic = None
-        # PMC FETCH_SIZE / WRITE_SIZE passes of this command line (tools/pmc_bench_traffic.sh): counters cannot be read from
-        # inside an un-profiled run, so the figure is the committed measurement, marked "static"
-        tpath = ROOT / "profiles" / "r3_traffic.json"
-        if tpath.exists():
+        # PMC FETCH_SIZE / WRITE_SIZE passes over this script's own engine-only step (measure_traffic); when rocprofv3 is not
+        # available (or --traffic static) the committed measurement of the same command line, marked "static"
+        if a.dtype == "f32" and a.traffic == "live" and world == 1:
+            os.environ.setdefault("PADEL_BENCH_SD_CACHE", str(tmp))
+            rows_all = []
+            for name in names:
+                rows_all += trackers[name].model._model.profile_rows()
+            with contextlib.redirect_stdout(sys.stderr):
+                traffic = measure_traffic(a, rows_all, tmp)
+        tpath = ROOT / "profiles" / "r4_traffic.json"
+        if traffic is None and a.traffic != "none" and tpath.exists():
             tj = json.loads(tpath.read_text()).get(f"{a.workload}-{a.impl}" if a.dtype == "f32" else "none")
             if tj:
                 traffic = {"bytes_per_launch": tj["bytes_per_launch"], "fetch_bytes_per_launch": tj["fetch_bytes_per_launch"],
                            "write_bytes_per_launch": tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                            "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"), "static": True,
-                           "source": "profiles/r3_traffic.json: " + tj["source"]}
+                           "source": "profiles/r4_traffic.json: " + tj["source"]}
         out["roofline"] = {
             "kernel": ("conv_p16_kernel<NF> / conv_p16q_kernel<NF> (stride-1 3x3 conv+BN+SiLU: input patch in LDS, taps as shifted "
                        "windows) + conv_tap16_kernel<WM,WN,MF,NF> (stride-2 3x3 implicit GEMM: LDS-DMA ring); v_mfma_f32_16x16x32_f16"
@@ -559,7 +713,7 @@ def main():
             tcpu += time.perf_counter() - t1
             # engine results on the same frames (B = 64 pass; bitwise equal to any other batch size —
             # tests/test_gpu_bench_config.py::test_batch_invariance)
-            boxes, kpts, counts = trackers[name].model._model.yolo_infer(
+            boxes, kpts, counts = trackers[name].model._ensure_model().yolo_infer(
                 clip.buffer, B, H, W, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7, classes=cfg["classes"],
                 pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg["rev"])
             boxes, counts = boxes[:ns], counts[:ns]
@@ -622,6 +776,23 @@ def main():
         out["cpu_baseline"] = {"value": round(ns / tcpu, 3), "unit": "frames/s", "cores": ncores, "kind": "port",
                                "sample": f"{ns} frames of the same workload through the torch-CPU fp32 oracle "
                                          f"(oracle/yolov8_ref.py), all {len(names)} trackers, torch threads={ncores}"}
+
+    if a.dtype == "f32" and a.impl == "h2" and not a.no_compare and world == 1:
+        # the strict-fp32 number beside `value`; last, because it rebuilds the trackers' graphs on fp32 storage
+        with contextlib.redirect_stdout(sys.stderr):
+            out["engine_only"]["fp32_mfma_kernels"] = fp32_mfma_leg()
+
+    if fake is not None:
+        # test hook: what every rank's models saw (weights only through the broadcast on ranks != 0) and computed
+        mine = {"rank": rank, "log": list(fake.LOG),
+                "weight_checksums": {n_: t_.model._ensure_model().weight_checksum() for n_, t_ in trackers.items()},
+                "first_boxes": {n_: [round(float(v), 3) for v in t_.model._ensure_model().yolo_infer(
+                    clip.buffer.view(0, clip.frame_bytes), 1, H, W, imgsz=TRACKERS[n_]["imgsz"], conf=TRACKERS[n_]["conf"], iou=0.7)[0][0, 0, :4]]
+                    for n_, t_ in trackers.items()}}
+        allr = D.gather_results([mine], dst=0)
+        if rank == 0:
+            out["fake_engine"] = True
+            out["ranks"] = allr
 
     if rank == 0:
         with os.fdopen(json_fd, "w") as f:

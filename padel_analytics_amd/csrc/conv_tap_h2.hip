@@ -19,7 +19,7 @@ namespace padel {
 #define PADEL_H2T_AR(ST_) (((ST_) & 1) ? a_rd1 : a_rd0)
 #define PADEL_H2T_BR(ST_) (((ST_) & 1) ? b_rd1 : b_rd0)
 #define PADEL_H2T_LW(SR_) (((SR_) & 1) ? lw1 : lw0)
-#define PADEL_H2T_COMPUTE(ST_)                                                                                    \
+#define PADEL_H2T_COMPUTE(ST_, FIRST_)                                                                                  \
     do {                                                                                                          \
         h16x8 ah[MF], am[MF], wh[NF], wm[NF];                                                                     \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
@@ -35,15 +35,20 @@ namespace padel {
             cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[f], cross[f][j], 0, 0, 0);             \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);             \
-        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
-            part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], part[f][j], 0, 0, 0);               \
+        if constexpr (FIRST_) {                /* first step of an accumulation block: the main chain starts from the constant 0 */ \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)         \
+                part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+        } else {                                                                                                  \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)         \
+                part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], part[f][j], 0, 0, 0);           \
+        }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
 
 #define PADEL_H2T_FLUSH()                                                                                         \
     do {                                                                                                          \
         _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                            \
-            _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];   /* (part restarts from 0 inside the next block's first MFMAs) */ \
     } while (0)
 #define PADEL_H2T_SWAP()                                                                                          \
     do { const float* t_ = a_rd0; a_rd0 = a_rd1; a_rd1 = t_; t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_;                \
@@ -112,7 +117,7 @@ namespace padel {
     (void)sc_hi; (void)nch;                                                                                       \
     f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];                                                               \
     _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                                \
-        _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; cross[f][j] = acc[f][j]; }
 
 // weight rows: nsteps * 128 bytes each (per k-step h | m planes of 32 fp16)
 #define PADEL_H2T_WEIGHTS(NSTEPS_)                                                                                \
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_ke
             else if (c + 1 < nfull) { PADEL_H2T_REQ_FULL((J) + 1, s_chunk + 128u, s_kb + ((J) + 1) * 128u, 0); }  \
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_H2T_COMPUTE(J);                                                                                     \
+        PADEL_H2T_COMPUTE(J, (J) == 0);                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 #define PADEL_H2T_TSTEP2(JT)                                                                                      \
@@ -207,7 +212,7 @@ __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_ke
         __builtin_amdgcn_s_barrier();                                                                             \
         if constexpr ((JT) + 1 < 5) { PADEL_H2T_REQ_TAIL((JT) + 1, s_chunk, s_kb + ((JT) + 1) * 128u, (JT) + 1 < 5 ? (JT) + 1 : 0); } \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_H2T_COMPUTE(JT);                                                                                    \
+        PADEL_H2T_COMPUTE(JT, (JT) == 0);                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
     if (nfull > 0) { PADEL_H2T_REQ_FULL(0, 0u, 0u, 0); } else { PADEL_H2T_REQ_TAIL(0, 0u, 0u, 0); }
@@ -287,7 +292,7 @@ __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_1_
         __builtin_amdgcn_s_barrier();                                                                             \
         if ((int)(s_k + (J) + 1) < nch) PADEL_H2T_1REQ((J) + 1, s_k + (J) + 1);                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_H2T_COMPUTE(J);                                                                                     \
+        PADEL_H2T_COMPUTE(J, (J) == 0);                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     }
     PADEL_H2T_1REQ(0, 0u);

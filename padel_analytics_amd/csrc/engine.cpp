@@ -32,7 +32,7 @@ struct Tuning {
     int graph = 0;       // 1: replay the op list of a (model, batch) from a captured hipGraph
     int timeline = 0;    // 1: 3x3 tap launches of the 64x96 tile run the s_memtime-instrumented instantiation
     int alias = 1;       // 1: activation buffers share one arena by liveness, 0: disjoint ranges
-    int fuse_stem = 0;   // 1: h2 YOLOv8 graphs run model.0 (stem) + model.1 (3x3 stride 2) as ONE kernel (stem_l1_h2.hip; opt-in)
+    int fuse_stem = 1;   // 1: h2 YOLOv8 graphs run model.0 (stem) + model.1 (3x3 stride 2) as ONE kernel (stem_l1_h2.hip; default since round 4, 0 = two kernels)
     int fold_up = 1;     // 1: an nn.Upsample(2) whose only reader is a bf16x3 1x1 conv is never materialised (the conv
                          // fetches those channels at [y >> 1][x >> 1] of the coarse map), 0: run the upsample kernel
 };
@@ -145,7 +145,7 @@ int pa_engine_create(int device_id, pa_engine** out) {
     e->t.tune = env_int("PADEL_CONV_TUNE", 1);
     e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
     e->t.graph = env_int("PADEL_GRAPH", 0);
-    e->t.fuse_stem = env_int("PADEL_FUSE_STEM", 0);
+    e->t.fuse_stem = env_int("PADEL_FUSE_STEM", 1);
     e->t.alias = env_int("PADEL_ALIAS", 1);
     e->t.fold_up = env_int("PADEL_FOLD_UP", 1);
     *out = e;
@@ -748,7 +748,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             size_t dbg_bytes = 0;
             if (e->t.timeline && h2 && lv == 323 && conv_h2q_supported(a) && !e->timeline_path.empty()) {
                 const size_t patches = (size_t)n * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);          // conv_patch_h2q.hip: one record per workgroup of its 1-D grid
-                dbg_bytes = 8 * ((patches + 7) / 8) * (size_t)((a.n16 + 5) / 6) * (8 + 4 * 32 * 5) * 8;
+                dbg_bytes = 8 * ((patches + 7) / 8) * (size_t)((a.n16 + 5) / 6) * (8 + 4 * 16 * 5) * 8;          // kQDbgWords of conv_patch_h2q.hip (16-step ring)
             } else if (e->t.timeline && !h2 && use_tap && lv == 7 && o.ksize == 3 && !e->timeline_path.empty()) {
                 dbg_bytes = (size_t)((a.M + 63) / 64) * ((o.npad + 95) / 96) * kConvDbgWords * 8;
             }

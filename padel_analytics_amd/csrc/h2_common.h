@@ -73,10 +73,108 @@ __device__ __forceinline__ void h2_raise(unsigned* flag, bool bad) {
 
 }  // namespace
 
-// acc = main + cross / 2048 per fragment; then * 1 / row scale + bias, activation, residual, store (h2 pairs, or plain fp32
-// for the Detect / Pose head maps and the TrackNet heat map)
-template <int MF, int NF, int ACT, bool RES, bool FAST>
-__device__ __forceinline__ void h2_epilogue_case(const ConvArgs& a, const f32x4 (&mainacc)[MF][NF], const f32x4 (&cross)[MF][NF],
+typedef unsigned h2_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned h2_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short h2_u16x2 __attribute__((ext_vector_type(2)));
+
+// The fast epilogue of every h2 kernel.  acc = main + cross / 2048 per fragment; then * 1 / row scale + bias, activation,
+// residual, store — as h2 pairs, or as plain fp32 for the Detect / Pose head maps and the TrackNet heat map (F32OUT).
+//
+// Round 4 rewrite.  The round-3 epilogue ran fragment by fragment: residual load -> s_waitcnt vmcnt(0) -> arithmetic ->
+// two 8-byte stores, with 64-bit address arithmetic and a branch on out_f32 per fragment — twelve dependent L2 round trips
+// per wave, 12.6 k cycles of a 112 k-cycle workgroup life on the 192 -> 192 layers (profiles/r3j_timeline_h2q.txt) and
+// a third of it on the 96 -> 96 ones.  Now
+//   * every residual piece, bias and scale vector of the wave is requested up front (one round trip);
+//   * a lane moves 16 bytes per fragment instead of 8 + 8: in the MFMA result layout lane (lr, lq) owns channels
+//     4 lq .. 4 lq + 3 of pixel lr, i.e. 8 bytes of the h half and 8 bytes of the m half of the pixel's 64-byte group
+//     [h x 16 | m x 16].  v_permlane16_swap_b32 (rows of 16 lanes: odd rows of the first operand <-> even rows of the
+//     second) on (h dword, m dword) leaves lane rows 0 / 1 / 2 / 3 with h[0..8) / m[0..8) / h[8..16) / m[8..16) of their
+//     pixel: one 16-byte store per fragment at byte (lq & 1) * 32 + (lq >> 1) * 16 of the group, half the store
+//     instructions for the same bytes (the epilogue was store-issue-bound; cdna_hip_programming.md T21).  The swap is an
+//     involution: the residual arrives through one 16-byte load per fragment and the same two swaps;
+//   * one 64-bit row pointer per pixel fragment, fragments of a row at immediate offsets (64 bytes apart);
+//   * the range check of the encoder runs on the packed h halves (one v_and + one v_pk_max_u16 per two values): the flag
+//     goes up when an h part IS the largest fp16 number, i.e. for |x| > 65488 (a shade earlier than |x| > 65504; NaN is
+//     clamped to -65504 by v_med3 and flagged too).
+// Arithmetic per value is unchanged (same operations in the same order): results are bitwise those of round 3.
+// Needs whole fragments inside the tensor, choff % 16 == 0 and cs % 16 == 0 (pairs) or % 4 (fp32 out); everything else takes
+// h2_epilogue_slow.
+template <int MF, int NF, int ACT, bool RES, bool F32OUT>
+__device__ __forceinline__ void h2_epilogue_fast(const ConvArgs& a, const f32x4 (&mainacc)[MF][NF], const f32x4 (&cross)[MF][NF],
+                                                 const int (&mpix)[MF], int fw, int lq, bool& bad) {
+    static_assert(!(RES && F32OUT), "fp32 head maps have no residual");
+    f32x4 b[NF], sc[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int co0 = (fw + j) * 16 + lq * 4;
+        b[j] = *reinterpret_cast<const f32x4*>(a.bias + co0);
+        sc[j] = *reinterpret_cast<const f32x4*>(a.oscale + co0);
+    }
+    if constexpr (F32OUT) {
+        float* op[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) op[f] = a.out + (long long)mpix[f] * a.out_cs + (a.out_choff + fw * 16 + lq * 4);
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = h2_act<ACT>(fmaf(fmaf(cross[f][j][r], kH2InvScale, mainacc[f][j][r]), sc[j][r], b[j][r]));
+                *reinterpret_cast<f32x4*>(op[f] + j * 16) = v;
+            }
+    } else {
+        const int piece = ((lq & 1) << 5) | ((lq >> 1) << 4);
+        char* op[MF];
+        h2_u32x4 rr[MF][NF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            op[f] = reinterpret_cast<char*>(a.out) + (long long)mpix[f] * a.out_cs * 4 + ((((a.out_choff >> 4) + fw) << 6) + piece);
+            if constexpr (RES) {
+                const char* rp = reinterpret_cast<const char*>(a.res) + (long long)mpix[f] * a.res_cs * 4 + ((((a.res_choff >> 4) + fw) << 6) + piece);
+#pragma unroll
+                for (int j = 0; j < NF; ++j) rr[f][j] = *reinterpret_cast<const h2_u32x4*>(rp + j * 64);
+            }
+        }
+        h2_u16x2 top = {0, 0};
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = h2_act<ACT>(fmaf(fmaf(cross[f][j][r], kH2InvScale, mainacc[f][j][r]), sc[j][r], b[j][r]));
+                if constexpr (RES) {
+                    const h2_u32x2 s0 = __builtin_amdgcn_permlane16_swap(rr[f][j][0], rr[f][j][2], false, false);
+                    const h2_u32x2 s1 = __builtin_amdgcn_permlane16_swap(rr[f][j][1], rr[f][j][3], false, false);
+                    const h2_u32x2 hd = {s0[0], s1[0]}, md = {s0[1], s1[1]};
+                    const f32x4 rv = h2_decode4(__builtin_bit_cast(h16x4, hd), __builtin_bit_cast(h16x4, md));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                }
+                h2_u32x2 hd, md;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const h2_f32x2 x = {__builtin_amdgcn_fmed3f(v[2 * p], -kH2Max, kH2Max), __builtin_amdgcn_fmed3f(v[2 * p + 1], -kH2Max, kH2Max)};
+                    const h2_h16x2 hh = __builtin_convertvector(x, h2_h16x2);
+                    const h2_f32x2 res = {(x[0] - (float)hh[0]) * kH2Scale, (x[1] - (float)hh[1]) * kH2Scale};
+                    const h2_h16x2 mm = __builtin_convertvector(res, h2_h16x2);
+                    hd[p] = __builtin_bit_cast(unsigned, hh);
+                    md[p] = __builtin_bit_cast(unsigned, mm);
+                    top = __builtin_elementwise_max(top, __builtin_bit_cast(h2_u16x2, hd[p] & 0x7FFF7FFFu));
+                }
+                const h2_u32x2 s0 = __builtin_amdgcn_permlane16_swap(hd[0], md[0], false, false);
+                const h2_u32x2 s1 = __builtin_amdgcn_permlane16_swap(hd[1], md[1], false, false);
+                const h2_u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                *reinterpret_cast<h2_u32x4*>(op[f] + j * 64) = o;
+            }
+        bad = bad || top[0] >= 0x7BFFu || top[1] >= 0x7BFFu;
+    }
+}
+
+// Partial tiles, channel counts that are not whole fragments, unaligned slices: element by element
+template <int MF, int NF, int ACT, bool RES>
+__device__ __forceinline__ void h2_epilogue_slow(const ConvArgs& a, const f32x4 (&mainacc)[MF][NF], const f32x4 (&cross)[MF][NF],
                                                  const int (&mpix)[MF], int fw, int lq, bool& bad) {
     char* const outb = reinterpret_cast<char*>(a.out);
     const char* const resb = reinterpret_cast<const char*>(a.res);
@@ -84,60 +182,32 @@ __device__ __forceinline__ void h2_epilogue_case(const ConvArgs& a, const f32x4 
     for (int j = 0; j < NF; ++j) {
         const int co0 = (fw + j) * 16 + lq * 4;
         f32x4 b, sc;
-        if (FAST) {
-            b = *reinterpret_cast<const f32x4*>(a.bias + co0);
-            sc = *reinterpret_cast<const f32x4*>(a.oscale + co0);
-        } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { b[r] = a.bias[min(co0 + r, a.n16 * 16 - 1)]; sc[r] = a.oscale[min(co0 + r, a.n16 * 16 - 1)]; }
-        }
+        for (int r = 0; r < 4; ++r) { b[r] = a.bias[min(co0 + r, a.n16 * 16 - 1)]; sc[r] = a.oscale[min(co0 + r, a.n16 * 16 - 1)]; }
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
             const int m = mpix[f];
-            if (!FAST && m < 0) continue;
-            f32x4 v;
+            if (m < 0) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = h2_act<ACT>(fmaf(fmaf(cross[f][j][r], kH2InvScale, mainacc[f][j][r]), sc[r], b[r]));
-            }
-            if (FAST) {
+                const int co = co0 + r;
+                if (co >= a.cout) continue;
+                float x = h2_act<ACT>(fmaf(fmaf(cross[f][j][r], kH2InvScale, mainacc[f][j][r]), sc[r], b[r]));
                 if (RES) {
-                    const char* rp = resb + (long long)m * a.res_cs * 4 + h2_chan_off(a.res_choff + co0);
-                    const f32x4 rv = h2_decode4(*reinterpret_cast<const h16x4*>(rp), *reinterpret_cast<const h16x4*>(rp + 32));
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += rv[r];
+                    const int rc = a.res_choff + co;
+                    const _Float16* rp = reinterpret_cast<const _Float16*>(resb + (long long)m * a.res_cs * 4 + (long long)(rc >> 4) * 64) + (rc & 15);
+                    x += fmaf((float)rp[16], kH2InvScale, (float)rp[0]);
                 }
                 if (a.out_f32) {
-                    *reinterpret_cast<f32x4*>(a.out + (long long)m * a.out_cs + a.out_choff + co0) = v;
+                    a.out[(long long)m * a.out_cs + a.out_choff + co] = x;
                 } else {
-                    h16x4 hv, mv;
-                    h2_encode4(v, hv, mv, bad);
-                    char* op = outb + (long long)m * a.out_cs * 4 + h2_chan_off(a.out_choff + co0);
-                    *reinterpret_cast<h16x4*>(op) = hv;
-                    *reinterpret_cast<h16x4*>(op + 32) = mv;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + r;
-                    if (co >= a.cout) continue;
-                    float x = v[r];
-                    if (RES) {
-                        const int rc = a.res_choff + co;
-                        const _Float16* rp = reinterpret_cast<const _Float16*>(resb + (long long)m * a.res_cs * 4 + (long long)(rc >> 4) * 64) + (rc & 15);
-                        x += fmaf((float)rp[16], kH2InvScale, (float)rp[0]);
-                    }
-                    if (a.out_f32) {
-                        a.out[(long long)m * a.out_cs + a.out_choff + co] = x;
-                    } else {
-                        bad |= !(fabsf(x) <= kH2Max);
-                        const float xc = __builtin_amdgcn_fmed3f(x, -kH2Max, kH2Max);
-                        const _Float16 hh = (_Float16)xc;
-                        const int oc = a.out_choff + co;
-                        _Float16* op = reinterpret_cast<_Float16*>(outb + (long long)m * a.out_cs * 4 + (long long)(oc >> 4) * 64) + (oc & 15);
-                        op[0] = hh;
-                        op[16] = (_Float16)((xc - (float)hh) * kH2Scale);
-                    }
+                    bad |= !(fabsf(x) <= kH2Max);
+                    const float xc = __builtin_amdgcn_fmed3f(x, -kH2Max, kH2Max);
+                    const _Float16 hh = (_Float16)xc;
+                    const int oc = a.out_choff + co;
+                    _Float16* op = reinterpret_cast<_Float16*>(outb + (long long)m * a.out_cs * 4 + (long long)(oc >> 4) * 64) + (oc & 15);
+                    op[0] = hh;
+                    op[16] = (_Float16)((xc - (float)hh) * kH2Scale);
                 }
             }
         }
@@ -148,13 +218,18 @@ __device__ __forceinline__ void h2_epilogue_case(const ConvArgs& a, const f32x4 
 template <int MF, int NF>
 __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x4 (&mainacc)[MF][NF], const f32x4 (&cross)[MF][NF],
                                             const int (&mpix)[MF], int fw, int lq, bool fast) {
+    // `fast` from the kernel: whole fragments inside the tensor and the channel matrix, slices 4-aligned; the 16-byte moves of
+    // the pair path need whole 16-channel groups on top of that, fp32 head maps have no residual path here
+    const bool wide = fast && (a.out_f32 ? !a.res : ((((a.out_choff | a.out_cs) & 15) == 0) && (!a.res || (((a.res_choff | a.res_cs) & 15) == 0))));
     bool bad = false;
 #define PADEL_H2_EPI(ACT_)                                                                                        \
     do {                                                                                                          \
-        if (a.res) { if (fast) h2_epilogue_case<MF, NF, ACT_, true, true>(a, mainacc, cross, mpix, fw, lq, bad);  \
-                     else h2_epilogue_case<MF, NF, ACT_, true, false>(a, mainacc, cross, mpix, fw, lq, bad); }    \
-        else       { if (fast) h2_epilogue_case<MF, NF, ACT_, false, true>(a, mainacc, cross, mpix, fw, lq, bad); \
-                     else h2_epilogue_case<MF, NF, ACT_, false, false>(a, mainacc, cross, mpix, fw, lq, bad); }   \
+        if (wide) {                                                                                               \
+            if (a.out_f32) h2_epilogue_fast<MF, NF, ACT_, false, true>(a, mainacc, cross, mpix, fw, lq, bad);     \
+            else if (a.res) h2_epilogue_fast<MF, NF, ACT_, true, false>(a, mainacc, cross, mpix, fw, lq, bad);    \
+            else h2_epilogue_fast<MF, NF, ACT_, false, false>(a, mainacc, cross, mpix, fw, lq, bad);              \
+        } else if (a.res) h2_epilogue_slow<MF, NF, ACT_, true>(a, mainacc, cross, mpix, fw, lq, bad);             \
+        else h2_epilogue_slow<MF, NF, ACT_, false>(a, mainacc, cross, mpix, fw, lq, bad);                         \
     } while (0)
     if (a.act == ACT_SILU) PADEL_H2_EPI(ACT_SILU);
     else if (a.act == ACT_RELU) PADEL_H2_EPI(ACT_RELU);

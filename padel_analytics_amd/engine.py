@@ -15,7 +15,8 @@ import numpy as np
 
 from . import graph as G
 
-_LIB_PATH = Path(__file__).resolve().parent / "libpadel_hip.so"
+# PADEL_LIB: tuning tools only (A/B runs against a second build of the library, e.g. tools/ab/*.so)
+_LIB_PATH = Path(os.environ["PADEL_LIB"]).resolve() if os.environ.get("PADEL_LIB") else Path(__file__).resolve().parent / "libpadel_hip.so"
 _lib = None
 
 

@@ -71,6 +71,9 @@ class PlayersKeypoints(Object):
     signature) or from the tracker's (n, K, 2) array of frame-pixel coordinates, in which case the per-keypoint
     objects are created on first access."""
 
+    #: True: build the per-keypoint objects in the constructor, inside ``predict_sample`` like the reference (:303-320)
+    EAGER = False
+
     def __init__(self, players_keypoints: Optional[list] = None, *, xy: Optional[np.ndarray] = None,
                  ratio: tuple = (1.0, 1.0)) -> None:
         super().__init__()
@@ -78,6 +81,8 @@ class PlayersKeypoints(Object):
         self._xy, self._ratio = xy, ratio
         if players_keypoints is None and xy is None:
             self._items = []
+        if self.EAGER:
+            self.players_keypoints
 
     @property
     def players_keypoints(self) -> list:

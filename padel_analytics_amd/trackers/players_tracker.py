@@ -71,6 +71,10 @@ class Players(Object):
     the tracker's arrays (``rows`` (k, 6) x1,y1,x2,y2,conf,cls + ``ids`` (k,)), in which case the ``Player``
     objects are created on first access."""
 
+    #: True: build the ``Player`` objects in the constructor, i.e. inside ``predict_sample`` like the reference does
+    #: (:371-378); False (default): on first access.  ``trackers.set_eager_objects`` flips it for every container class.
+    EAGER = False
+
     def __init__(self, players: Optional[list] = None, *, rows: Optional[np.ndarray] = None,
                  ids: Optional[np.ndarray] = None):
         super().__init__()
@@ -78,6 +82,8 @@ class Players(Object):
         self._rows, self._ids = rows, ids
         if players is None and rows is None:
             self._players = []
+        if self.EAGER:
+            self.players
 
     @property
     def players(self) -> list:

@@ -1,0 +1,132 @@
+"""A CPU stand-in for ``padel_analytics_amd.engine.Engine`` / ``Model`` / ``DeviceBuffer`` (TEST INFRASTRUCTURE).
+
+``python bench.py --fake-engine`` installs it so that ``bench.main()`` — the launcher contract, the barriers, the
+max-over-ranks timing, the one-JSON-line rule, the weight broadcast of ranks != 0 — can run under ``gloo`` with world 2
+on a box without a GPU (tests/test_bench_gloo.py).  Nothing here computes a network: ``FakeModel.yolo_infer``
+returns detections that are a deterministic function of the frame pixels AND of a checksum of the model's weight blob, so
+a rank whose weights did not arrive through the broadcast produces visibly different results.  The real host code runs on
+top of it unchanged: ``yolo.YOLO`` (checkpoint -> packed graph), the tracker classes, PolygonZone, the native ByteTrack
+(host C++ inside libpadel_hip.so), ``TrackingRunner``, ``video.DeviceClip``."""
+from __future__ import annotations
+
+import time
+
+import numpy as np
+
+LOG = []          # (rank-local) event log the test reads back through the JSON line: "bcast root=0 recv=True" ...
+
+
+class FakeBuffer:
+    def __init__(self, engine, nbytes, _arr=None):
+        self.engine, self.nbytes = engine, int(nbytes)
+        self.arr = np.zeros(self.nbytes, np.uint8) if _arr is None else _arr
+        self.owner = _arr is None
+        self.ptr = self.arr.ctypes.data
+
+    def view(self, offset, nbytes):
+        assert 0 <= offset and offset + nbytes <= self.nbytes
+        return FakeBuffer(self.engine, nbytes, _arr=self.arr[offset:offset + nbytes])
+
+    def upload(self, arr, copy_stream=False):
+        a = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        self.arr[:a.size] = a
+        return self
+
+    def download(self, arr):
+        arr.view(np.uint8).reshape(-1)[:] = self.arr[:arr.nbytes]
+        return arr
+
+    def free(self):
+        self.arr = None
+
+
+class FakeEngine:
+    def __init__(self, device_id=0):
+        self.device_id, self.comm = device_id, None
+
+    def synchronize(self): pass
+    def set_profiling(self, on): pass
+    def set_tuning(self, **kv): pass
+    def pin(self, arr): pass
+    def unpin(self, arr): pass
+    def close(self): pass
+    def alloc(self, nbytes): return FakeBuffer(self, nbytes)
+
+    def comm_init(self, unique_id, nranks, rank):
+        assert isinstance(unique_id, (bytes, bytearray)) and len(unique_id) == 128
+        self.comm = (bytes(unique_id), nranks, rank)
+        LOG.append(f"comm_init nranks={nranks} rank={rank}")
+
+    def bcast_weights(self, model, root=0):
+        """The one-time weight broadcast (pa_engine_bcast_weights): rank `root`'s blob reaches every rank's model."""
+        import torch
+        import torch.distributed as dist
+        assert self.comm is not None, "comm_init first"
+        LOG.append(f"bcast root={root} had_weights={model.has_weights}")
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.from_numpy(model.blob)
+            dist.broadcast(t, src=root)
+        model.has_weights = True
+
+    def allreduce_max(self, value):
+        import torch
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            t = torch.tensor([float(value)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0])
+        return float(value)
+
+
+class FakeModel:
+    STEP_SECONDS = 0.01           # what one yolo_infer "costs" (so that the timed region is not empty)
+
+    def __init__(self, engine, graph, blob=None, *, empty=False):
+        self.engine, self.graph = engine, graph
+        self.blob = np.zeros(graph.n_floats, np.float32) if empty else np.ascontiguousarray(graph.blob() if blob is None else blob, np.float32).copy()
+        self.has_weights = not empty
+        self.max_batch = 64
+        LOG.append(f"model created empty={empty} n_floats={graph.n_floats}")
+
+    def set_max_batch(self, n): self.max_batch = int(n)
+    def close(self): pass
+    def take_overflow(self): return False
+    def last_profile(self): return []
+    def profile_rows(self): return []
+    def plan_bytes(self): return (0, 0)
+
+    def weight_checksum(self) -> int:
+        return int(np.frombuffer(self.blob.tobytes(), np.uint32)[::97].astype(np.uint64).sum() % 1000003)
+
+    def yolo_infer(self, frames, n, h, w, *, imgsz, conf, iou, classes=None, max_det=300, pre_mode=0, channel_reverse=False,
+                   letterbox_auto=True):
+        assert self.has_weights, "inference on a model whose weights never arrived"
+        if isinstance(frames, FakeBuffer):
+            frames = frames.arr[:n * h * w * 3].reshape(n, h, w, 3)
+        time.sleep(self.STEP_SECONDS)
+        ck = self.weight_checksum()
+        nk = self.graph.nk
+        boxes = np.zeros((n, max_det, 6), np.float32)
+        kpts = np.zeros((n, max_det, nk), np.float32) if nk else None
+        counts = np.zeros(n, np.int32)
+        for i in range(n):
+            seed = (int(frames[i, ::37, ::41].astype(np.int64).sum()) * 31 + ck) % 2147483647
+            rng = np.random.default_rng(seed)
+            k = min(max_det, 4 + int(rng.integers(0, 3)))
+            c = rng.uniform([0.1 * w, 0.2 * h], [0.9 * w, 0.9 * h], (k, 2))
+            wh = np.array([w * 0.06, h * 0.2])
+            boxes[i, :k, :2], boxes[i, :k, 2:4] = c - wh / 2, c + wh / 2
+            boxes[i, :k, 4] = np.sort(rng.uniform(max(conf, 0.4), 0.95, k))[::-1]
+            counts[i] = k
+            if nk:
+                kpts[i, :k] = rng.uniform(0, imgsz, (k, nk)).astype(np.float32)
+        return boxes, kpts, counts
+
+
+def install():
+    """Point the engine module (and everything that resolves names through it) at the fakes."""
+    from padel_analytics_amd import engine as E
+    E.Engine, E.Model, E.DeviceBuffer = FakeEngine, FakeModel, FakeBuffer
+    E.comm_unique_id = lambda: bytes(range(128))
+    E.default_engine = lambda *a, **k: FakeEngine(0)
+    return E

@@ -140,3 +140,45 @@ GEOMETRY = [
     # 725 x 1280: r = 0.5 -> 640 x round(362.5) = 362 (banker's rounding of Python's round); dh = 278 % 32 = 22 -> 11 + 11
     ((725, 1280), (640, 362), (11, 11, 0, 0), (384, 640), 0.5, (0, 11)),
 ]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Heat-map decode ties (reference predict.py:21-33): ``predict_location`` keeps the FIRST rectangle of maximal w * h
+# (strict ``>``, bounding-box area, not pixel count) in the order ``cv2.findContours(mask, RETR_EXTERNAL, ...)`` returns the
+# contours.  cv2 is not installable here; the CHOSEN rule (oracle/ball_ref.py, trackers/ball_tracker.py:predict_location, the
+# device kernel csrc/tracknet_post.hip:ball_locate_kernel): contours come back in REVERSE raster-discovery order — a raster
+# scan (row by row, left to right) discovers a component at its first foreground pixel, the component discovered LAST is
+# returned first — so among equal-area rectangles the winner is the component whose first pixel comes LAST in raster order.
+# Every expectation below is worked out from that sentence alone.  (mask size 288 x 512; rectangles as (x, y, w, h).)
+def _paint(rects, extra=()):
+    import numpy as np
+    m = np.zeros((288, 512), np.uint8)
+    for x, y, w, h in rects:
+        m[y:y + h, x:x + w] = 255
+    for x, y in extra:
+        m[y, x] = 255
+    return m
+
+
+BALL_TIE_CASES = [
+    # two 4 x 4 squares, first pixels at (row 5, col 5) and (row 200, col 400): the lower one is discovered last -> wins
+    ("two equal squares", _paint([(5, 5, 4, 4), (400, 200, 4, 4)]), (400, 200, 4, 4)),
+    # same row of first pixels (row 50): the scan meets col 60 before col 300 -> the right one is discovered last -> wins
+    ("same first row", _paint([(60, 50, 4, 4), (300, 50, 4, 4)]), (300, 50, 4, 4)),
+    # three equal areas (16): 4x4 at row 50, 4x4 at row 50 further right, 8x2 at row 250: the 8x2 is discovered last
+    ("three equal areas, different shapes", _paint([(60, 50, 4, 4), (300, 50, 4, 4), (10, 250, 8, 2)]), (10, 250, 8, 2)),
+    # the component discovered last is SMALLER: strict '>' lets an earlier-returned... no — it is returned first but loses
+    # to the larger one found later in the list: 9 x 4 = 36 beats 3 x 3 = 9 wherever it sits
+    ("larger beats later", _paint([(20, 10, 9, 4), (300, 100, 3, 3)]), (20, 10, 9, 4)),
+    # tie on BOUNDING-BOX area, not pixel count: an L of 7 pixels spanning 4 x 4 (area 16) starting at row 20 and a full
+    # 4 x 4 square (16 pixels) starting at row 10: equal box areas -> the one discovered last (the L, row 20) wins
+    ("bounding box area, not pixel count", _paint([(100, 10, 4, 4), (200, 20, 1, 4), (200, 23, 4, 1)]), (200, 20, 4, 4)),
+    # discovery order is decided by the FIRST pixel, not by the rectangle's top-left corner: component P = a column
+    # x = 105, rows 10..13 plus a foot at (row 13, col 102..105) -> box (102, 10, 4, 4), first pixel (row 10, col 105);
+    # component Q = the square (103, 10, 4, 4) shifted right: box (300, 10, 4, 4), first pixel (row 10, col 300).
+    # Both first pixels are on row 10, col 105 < col 300 -> Q is discovered last -> Q wins although P's box starts further left
+    ("first pixel decides", _paint([(105, 10, 1, 4), (102, 13, 4, 1), (300, 10, 4, 4)]), (300, 10, 4, 4)),
+    # a diagonal link makes ONE component (8-connectivity): squares (10,10,3,3) and (13,13,3,3) touch at a corner -> box
+    # (10, 10, 6, 6) = 36 > the lone 5 x 5 = 25 further down
+    ("diagonal link merges", _paint([(10, 10, 3, 3), (13, 13, 3, 3), (200, 200, 5, 5)]), (10, 10, 6, 6)),
+]

@@ -80,3 +80,13 @@ def test_decode_rules():
     heat[1, 0, 0] = 0.5              # not > 0.5
     x, y, v = br.decode_heat(heat, (1280 / 512, 720 / 288))
     assert (x[0], y[0], v[0]) == (int(24 * 2.5), int(12 * 2.5), 1) and (x[1], y[1], v[1]) == (0, 0, 0)
+
+
+def test_decode_tie_rule_hand_derived():
+    """Equal-area rectangles: the chosen cv2.findContours order — reverse raster discovery — applied by hand
+    in tests/known_answers.py:BALL_TIE_CASES; oracle and product host code must return exactly those rectangles (the device
+    kernel meets the same cases in tests/test_gpu_ball.py)."""
+    from tests.known_answers import BALL_TIE_CASES
+    for why, mask, want in BALL_TIE_CASES:
+        assert br.predict_location(mask) == want, (why, br.predict_location(mask))
+        assert predict_location(mask) == want, (why, predict_location(mask))

@@ -101,6 +101,20 @@ def test_ball_locate_kernel_synthetic_masks(gpu_engine):
     sess.close(); m.close()
 
 
+def test_ball_locate_kernel_hand_derived_ties(gpu_engine):
+    """ball_locate_kernel on the equal-area cases whose winners are derived on paper from the chosen contour order
+    (tests/known_answers.py:BALL_TIE_CASES) — literal expectations, not "equal to the oracle"."""
+    from tests.known_answers import BALL_TIE_CASES
+    m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1), dtype=E.graph_dtype()))
+    m.set_max_batch(8)
+    sess = E.BallSession(m, 360, 640)
+    masks = np.stack([c[1] for c in BALL_TIE_CASES])
+    rects = sess.locate(masks)
+    for (why, _, want), got in zip(BALL_TIE_CASES, rects):
+        assert tuple(int(v) for v in got) == want, (why, got)
+    sess.close(); m.close()
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 16])
 def test_device_median_matches_numpy(gpu_engine, n):
     m = E.Model(gpu_engine, G.build_tracknet(tr.synth_tracknet_state_dict(1), dtype=E.graph_dtype()))

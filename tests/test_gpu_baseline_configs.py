@@ -96,48 +96,118 @@ def test_config4_1080p_fp16_all_trackers_through_the_runner(gpu_engine, tmp_path
     n_pose = sum(len(p) for p in trackers["pose"].results.predictions)
     assert n_players > 0 and n_pose > 0
     assert all(t.model.graph.dtype == G.DTYPE_F16 for t in trackers.values())
-    # ---- parity statement of this precision, in pixels, on low-noise heads (2 frames, vs the fp32 CPU oracle)
+    # ---- parity statement of this precision, in pixels, on low-noise heads, vs the fp32 CPU oracle: three independently
+    # seeded clips + checkpoints per tracker (2 frames each).  fp16 activations carry 11 bits: the statement is in pixels,
+    # not the fp32 path's 1e-3 px, and it is asserted at measured + margin (round 3 asserted "< 8 px")
     report = {"frames": B, "tracked_players": n_players, "pose_detections": n_pose, "low_noise_heads": {}}
-    sample = frames[:2]
+    # per tracker: bound on the geometric mean of the RMS error over the seeds, bound on the worst L-inf of any seed
+    BOUNDS = {"players": (0.35, 5.0), "ball": (0.12, 1.2), "pose": (0.08, 1.5)}
     for name in ("players", "ball", "pose"):
         cfg = bench.TRACKERS[name]
         f = 0.004 if cfg["imgsz"] > 640 else 0.02
-        sd = dict(bench.make_state_dict(name, cfg, frames))
-        for branch in ("cv2", "cv4"):
-            for l in range(3):
-                for nm in ("weight", "bias"):
-                    k = f"model.22.{branch}.{l}.2.{nm}"
-                    if k in sd:
-                        sd[k] = (sd[k] * np.float32(f)).astype(np.float16).astype(np.float32)
-        srcs = bench.source_for_oracle(cfg, sample)
-        r32 = ref.predict(ref.YoloV8Ref(sd, cfg["nc"], cfg["kpt"]), srcs, cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
-        m = E.Model(gpu_engine, G.build_yolov8(sd, cfg["nc"], cfg["kpt"], dtype="f16"))
-        m.set_max_batch(2)
-        boxes, kpts, counts = _infer(m, cfg, np.ascontiguousarray(sample), 2, H, W)
-        m.close()
-        tot = mt = 0
-        worst, sq, cnt = 0.0, 0.0, 0
-        for i, r in enumerate(r32):
-            gb = boxes[i, :counts[i]]
-            pairs, ru, gu = parity.match(r["boxes"], gb, tol_match=4.0)
-            tot += len(r["boxes"]); mt += len(pairs)
-            for i_r, i_g in pairs:
-                d = np.abs(gb[i_g, :4] - r["boxes"][i_r, :4]).astype(np.float64)
-                worst = max(worst, float(d.max())); sq += float((d ** 2).sum()); cnt += 4
-                if kpts is not None and r["kpts"] is not None:
-                    gk = kpts[i, i_g].reshape(*cfg["kpt"])
-                    dk = np.abs(gk[..., :2] - r["kpts"][i_r][..., :2]).astype(np.float64)
-                    worst = max(worst, float(dk.max())); sq += float((dk ** 2).sum()); cnt += dk.size
-        rms = (sq / max(cnt, 1)) ** 0.5
-        report["low_noise_heads"][name] = {"detections": tot, "matched": mt, "linf_px_vs_fp32_oracle": round(worst, 4),
-                                           "rms_px_vs_fp32_oracle": round(rms, 4)}
-        # fp16 activations carry 11 bits: pixels, not the fp32 path's 1e-3 px (measured 0.3-4 px L-inf on these heads)
-        assert tot > 0 and mt >= 0.9 * tot, (name, mt, tot)
-        assert worst < 8.0 and rms < 1.5, (name, worst, rms)
-    print("configs[4] (one GPU's 64 frames, fp16, 1080p):", report)
+        per_seed = []
+        for sidx in range(3):
+            sample = synth.synthetic_frames(2, H, W, seed=1000 + 17 * sidx)
+            sd = dict(bench.make_state_dict(name, cfg, sample, seed_offset=101 * sidx))
+            for branch in ("cv2", "cv4"):
+                for l in range(3):
+                    for nm in ("weight", "bias"):
+                        k = f"model.22.{branch}.{l}.2.{nm}"
+                        if k in sd:
+                            sd[k] = (sd[k] * np.float32(f)).astype(np.float16).astype(np.float32)
+            srcs = bench.source_for_oracle(cfg, sample)
+            r32 = ref.predict(ref.YoloV8Ref(sd, cfg["nc"], cfg["kpt"]), srcs, cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
+            m = E.Model(gpu_engine, G.build_yolov8(sd, cfg["nc"], cfg["kpt"], dtype="f16"))
+            m.set_max_batch(2)
+            boxes, kpts, counts = _infer(m, cfg, np.ascontiguousarray(sample), 2, H, W)
+            m.close()
+            tot = mt = 0
+            worst, sq, cnt = 0.0, 0.0, 0
+            for i, r in enumerate(r32):
+                gb = boxes[i, :counts[i]]
+                pairs, ru, gu = parity.match(r["boxes"], gb, tol_match=6.0)
+                tot += len(r["boxes"]); mt += len(pairs)
+                for i_r, i_g in pairs:
+                    d = np.abs(gb[i_g, :4] - r["boxes"][i_r, :4]).astype(np.float64)
+                    worst = max(worst, float(d.max())); sq += float((d ** 2).sum()); cnt += 4
+                    if kpts is not None and r["kpts"] is not None:
+                        gk = kpts[i, i_g].reshape(*cfg["kpt"])
+                        dk = np.abs(gk[..., :2] - r["kpts"][i_r][..., :2]).astype(np.float64)
+                        worst = max(worst, float(dk.max())); sq += float((dk ** 2).sum()); cnt += dk.size
+            rms = (sq / max(cnt, 1)) ** 0.5
+            per_seed.append({"detections": tot, "matched": mt, "linf_px_vs_fp32_oracle": round(worst, 4), "rms_px_vs_fp32_oracle": round(rms, 4)})
+            assert tot > 0 and mt >= 0.95 * tot, (name, sidx, mt, tot)
+        gm_rms = float(np.exp(np.mean(np.log([max(p_["rms_px_vs_fp32_oracle"], 1e-6) for p_ in per_seed]))))
+        worst_linf = max(p_["linf_px_vs_fp32_oracle"] for p_ in per_seed)
+        report["low_noise_heads"][name] = {"per_seed": per_seed, "geomean_rms_px": round(gm_rms, 4), "worst_linf_px": worst_linf,
+                                           "bounds": {"geomean_rms_px": BOUNDS[name][0], "worst_linf_px": BOUNDS[name][1]}}
     out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
     if os.path.isdir(out):
         json.dump(report, open(os.path.join(out, "config4_report.json"), "w"), indent=1)
+    for name, (b_rms, b_linf) in BOUNDS.items():
+        e = report["low_noise_heads"][name]
+        assert e["geomean_rms_px"] <= b_rms and e["worst_linf_px"] <= b_linf, (name, e)
+    print("configs[4] (one GPU's 64 frames, fp16, 1080p):", report)
     clip.free()
     for t in trackers.values():
         t.model.close()
+
+
+def test_config0_32_frames_640_yolov8n_through_the_player_tracker(gpu_engine, tmp_path):
+    """BASELINE configs[0] AS STATED: a 32-frame 640 x 640 clip through `PlayerTracker` (yolov8n, conf .5,
+    classes=[0], batch 8) driven by `TrackingRunner` from host frames — the reference's plumbing case.  Against the CPU
+    oracle on all 32 frames: identical detection sets and classes before the zone, coordinates as close to the exact (fp64)
+    evaluation as the fp32 oracle itself; then the plugin's own output: the zone keeps exactly the oracle's detections
+    whose bottom-centre anchor lies inside, ByteTrack ids equal those of the python twin fed with the ORACLE's boxes."""
+    import torch
+    from padel_analytics_amd import bytetrack as BT
+    H = W = 640
+    N, B = 32, 8
+    frames = synth.synthetic_frames(N, H, W, seed=77)
+    srcs = [f[..., ::-1] for f in frames]
+    from tests.helpers import calibrated_state_dict
+    sd = calibrated_state_dict("n", 80, None, srcs, 640, 0.5, seed=19, frac=0.004)
+    checkpoint.save_checkpoint(tmp_path / "yolov8n.pt", sd, "detect", 80, None, "n", {0: "person"})
+    zone = D.PolygonZone(np.array([[40, 60], [600, 60], [620, 630], [20, 630]]), frame_resolution_wh=(W, H))
+    t = PlayerTracker(str(tmp_path / "yolov8n.pt"), zone, batch_size=B, save_path=tmp_path / "players.json")
+    t.model.attach(gpu_engine)
+    # --- raw detections of the device stage, batch by batch as the runner feeds them
+    boxes = np.zeros((N, 300, 6), np.float32)
+    counts = np.zeros(N, np.int32)
+    for lo in range(0, N, B):
+        b, c = t.infer_sample(list(frames[lo:lo + B]))
+        boxes[lo:lo + B], counts[lo:lo + B] = b, c
+    r32 = ref.predict(ref.YoloV8Ref(sd, 80, None), srcs, 0.5, 0.7, 640, classes=[0])
+    r64 = ref.predict(ref.YoloV8Ref(sd, 80, None, dtype=torch.float64), srcs, 0.5, 0.7, 640, classes=[0])
+    b64 = np.zeros((N, 300, 6), np.float32)
+    c64 = np.zeros(N, np.int32)
+    for i, r in enumerate(r64):
+        c64[i] = len(r["boxes"])
+        b64[i, :c64[i]] = r["boxes"]
+    floor = parity.compare_batch(r32, b64, None, c64, 0.5, 0.7)
+    g32 = parity.compare_batch(r32, boxes, None, counts, 0.5, 0.7)          # raises on class / set mismatch
+    g64 = parity.compare_batch(r64, boxes, None, counts, 0.5, 0.7)
+    assert g32["n"] >= N, "the calibration should give at least a detection per frame"
+    assert g64["worst_px"] <= max(1e-3, 4 * floor["worst_px"]), (g64["worst_px"], floor["worst_px"])
+    assert g64["rms_px"] <= max(2e-4, 1.5 * floor["rms_px"]), (g64["rms_px"], floor["rms_px"])
+    # --- the plugin's output through the runner (host frames, batch 8)
+    runner = TrackingRunner([t], video.ArrayClip(frames), tmp_path / "out.mp4")
+    runner.run()
+    assert len(t) == N and len(json.loads((tmp_path / "players.json").read_text())) == N
+    twin = BT.ByteTrack(frame_rate=30)
+    n_ids = 0
+    for i, r in enumerate(r32):
+        ob = r["boxes"]
+        ob = ob[zone.trigger_boxes(ob[:, :4])] if len(ob) else ob
+        out = twin.update_with_detections(D.Detections(xyxy=ob[:, :4].copy(), confidence=ob[:, 4].copy(),
+                                                       class_id=ob[:, 5].astype(int)))
+        got = t.results.predictions[i]
+        assert len(got) == len(out), (i, len(got), len(out))
+        for p_, wb, wid in zip(got.players, out.xyxy, out.tracker_id):
+            assert np.abs(np.asarray(p_.xyxy, np.float64) - wb).max() <= max(1e-3, 5 * floor["worst_px"]), (i, p_.xyxy, wb)
+            assert (p_.id or 0) == int(wid), (i, p_.id, wid)
+            n_ids += 1
+    assert n_ids > 0
+    print(f"configs[0]: {g32['n']} detections on 32 frames, L-inf vs fp64 {g64['worst_px']:.2e} px (oracle floor {floor['worst_px']:.2e}), "
+          f"{n_ids} tracked boxes with ids equal to the python twin's")
+    t.model.close()

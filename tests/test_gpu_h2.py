@@ -269,7 +269,7 @@ def test_stale_arena_bytes_cannot_reach_results(gpu_engine, mode):
 @pytest.mark.parametrize("scale,hw,imgsz", [("n", (360, 640), 640), ("s", (180, 320), 288), ("m", (180, 320), 288), ("m", (360, 640), 640)],
                          ids=["n-640", "s-288", "m-288", "m-640"])
 def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
-    """Tuning "fuse_stem" (csrc/stem_l1_h2.hip, opt-in): model.0 + model.1 as one kernel — the stem map stays in LDS.  Same
+    """Tuning "fuse_stem" (csrc/stem_l1_h2.hip, on by default since round 4): model.0 + model.1 as one kernel — the stem map stays in LDS.  Same
     arithmetic in the same order as the two kernels it replaces: head maps and detections are bitwise those of the unfused
     run (c = 16: tail-only K walk; 32: one chunk; 48: chunk + tail with the LDS region reused; partial tiles at 288)."""
     from padel_analytics_amd import synth, yolo_arch
@@ -281,6 +281,7 @@ def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
     kw = dict(imgsz=imgsz, conf=0.25, iou=0.7)
     gpu_engine.set_profiling(True)
     try:
+        gpu_engine.set_tuning(fuse_stem=0)
         b0, _, c0 = m.yolo_infer(frames, 3, h, w, **kw)
         h0 = [m.read_head(l, 3) for l in range(3)]
         n_convs0 = sum(1 for r in m.profile_rows() if r["kind"] == 2)
@@ -291,7 +292,7 @@ def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
         n_convs1 = sum(1 for r in m.profile_rows() if r["kind"] == 2)
         assert not m.take_overflow()
     finally:
-        gpu_engine.set_tuning(fuse_stem=0)
+        gpu_engine.set_tuning(fuse_stem=1)           # the default
         gpu_engine.set_profiling(False)
         m.close()
     assert n_convs1 == n_convs0 - 1, "the fused kernel did not run (layer 1 was launched on its own)"

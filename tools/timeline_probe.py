@@ -65,7 +65,7 @@ def main():
     global STEPS, WORDS
     h2q = a.kernel == "h2q"
     if h2q:
-        STEPS, WORDS = 32, 8 + 4 * 32 * 5
+        STEPS, WORDS = 16, 8 + 4 * 16 * 5            # conv_patch_h2q.hip:kQDbgSteps
     H_, W_ = (int(v) for v in a.hw.split("x"))
     ms = run_conv(a.dump, a.kernel, H=H_, W=W_, cin=a.cin, cout=a.cout)
     raw = np.fromfile(a.dump, dtype=np.uint64)
@@ -102,6 +102,15 @@ def main():
             m_ = (t[..., 4] - t[..., 3])[:, wv].reshape(-1)
             r_ = (t[..., 3] - t[..., 2])[:, wv].reshape(-1)
             P(f"  wave {wv}: whole step mean {v.mean():.0f}  MFMA issue {m_.mean():.0f}  reads+requests {r_.mean():.0f}")
+        names = ("wait", "barrier", "reads", "mfma", "tail")
+        parts = (t[..., 1] - t[..., 0], t[..., 2] - t[..., 1], t[..., 3] - t[..., 2], t[..., 4] - t[..., 3], nxt - t[..., 4])
+        P("  per wave and tap (mean ticks): " + " | ".join(names) + " | whole")
+        for tp in range(9):
+            sel = (steps % 9) == tp
+            if sel.any():
+                for wv in range(4):
+                    P(f"    tap {tp} wave {wv}: " + " ".join(f"{pp[:, wv][:, sel].mean():6.0f}" for pp in parts)
+                      + f" | {(nxt - t[..., 0])[:, wv][:, sel].mean():6.0f}")
         for tp in range(9):
             sel = (steps % 9) == tp
             if sel.any():
