@@ -346,7 +346,8 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     import torch
-    from padel_analytics_amd import dist as D, engine as E, synth, video
+    from padel_analytics_amd import dist as D, engine as E, video
+    from tests import synth
     from padel_analytics_amd.trackers import TrackingRunner
     fake = None
     if a.fake_engine:

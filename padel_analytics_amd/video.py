@@ -1,18 +1,37 @@
 """Frame sources: the reference reads video through ``supervision`` (``sv.VideoInfo.from_video_path``
 ``trackers/runner.py:52``, ``sv.get_video_frames_generator`` ``runner.py:215-220``), which needs OpenCV.
 Neither is available here or on the GPU box, and the checkout ships no video, so this module provides the
-same two calls over (a) ``.npy`` frame stacks (N,H,W,3 uint8 BGR, memory-mapped), (b) seeded synthetic
-clips ``synthetic://?n=64&h=720&w=1280&fps=30&seed=0`` and (c) real video files when ``cv2`` happens to be
-importable, (d) ``DeviceClip`` objects: a clip already resident in HBM (the bench's device-resident mode; the
+same two calls over (a) ``.npy`` frame stacks (N,H,W,3 uint8 BGR, memory-mapped), (b) URL-style sources whose
+scheme somebody registered with ``register_source`` (the tests and the bench register ``synthetic://?n=64&h=720&w=1280&
+fps=30&seed=0``: tests/synth.py — generated frames are test infrastructure, not product) and (c) real video files when
+``cv2`` happens to be importable, (d) ``DeviceClip`` objects: a clip already resident in HBM (the bench's device-resident mode; the
 runner's fan-out mode uploads each batch once and hands the same ``DeviceFrame`` handles to every tracker).
 Frames are HWC uint8 **BGR**, exactly what supervision yields."""
 from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import Iterator, Optional
-from urllib.parse import parse_qs, urlparse
 
 import numpy as np
+
+
+# scheme -> (info(url) -> VideoInfo, frames(url, start, end, stride) -> iterator of HWC uint8 BGR frames)
+_SOURCES: dict = {}
+
+
+def register_source(scheme: str, info, frames) -> None:
+    """Make ``scheme://...`` paths readable by ``VideoInfo.from_video_path`` / ``get_video_frames_generator``."""
+    _SOURCES[scheme] = (info, frames)
+
+
+def _scheme(p: str):
+    i = p.find("://")
+    if i <= 0:
+        return None
+    if p[:i] not in _SOURCES:
+        raise FileNotFoundError(f"no frame source registered for '{p[:i]}://' (video.register_source; the synthetic clips of "
+                                f"the tests register themselves on `import tests.synth`)")
+    return _SOURCES[p[:i]]
 
 
 @dataclass
@@ -31,9 +50,9 @@ class VideoInfo:
         if isinstance(video_path, (DeviceClip, ArrayClip)):
             return cls(video_path.w, video_path.h, video_path.fps, video_path.total_frames)
         p = str(video_path)
-        if p.startswith("synthetic://"):
-            q = _query(p)
-            return cls(q["w"], q["h"], q["fps"], q["n"])
+        src = _scheme(p)
+        if src is not None:
+            return src[0](p)
         if p.endswith(".npy"):
             a = np.load(p, mmap_mode="r")
             return cls(int(a.shape[2]), int(a.shape[1]), 30, int(a.shape[0]))
@@ -47,19 +66,13 @@ class VideoInfo:
         return info
 
 
-def _query(p: str) -> dict:
-    q = {k: int(v[0]) for k, v in parse_qs(urlparse(p).query).items()}
-    return {"n": q.get("n", 64), "h": q.get("h", 720), "w": q.get("w", 1280), "fps": q.get("fps", 30),
-            "seed": q.get("seed", 0)}
-
-
 def _cv2():
     try:
         import cv2
         return cv2
     except ImportError as e:
         raise RuntimeError("reading encoded video needs opencv-python, which is not installed; use a .npy frame "
-                           "stack or a synthetic:// source") from e
+                           "stack or a registered frame source") from e
 
 
 class DeviceFrame:
@@ -194,12 +207,9 @@ def get_video_frames_generator(source_path, stride: int = 1, start: int = 0, end
         yield from source_path.frames(start, end, stride)
         return
     p = str(source_path)
-    if p.startswith("synthetic://"):
-        from . import synth
-        q = _query(p)
-        stop = q["n"] if end is None else min(end, q["n"])
-        for i in range(start, stop, stride):
-            yield synth.synthetic_frames(1, q["h"], q["w"], seed=q["seed"] * 100003 + i)[0]
+    src = _scheme(p)
+    if src is not None:
+        yield from src[1](p, start, end, stride)
         return
     if p.endswith(".npy"):
         a = np.load(p, mmap_mode="r")

@@ -20,6 +20,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
+from tests import synth  # noqa: F401  (registers the synthetic:// frame source)
 
 
 def frame_seed(f) -> int:

@@ -1,7 +1,10 @@
 """Seeded synthetic inputs: there is no sample video in the reference checkout
 (`.MISSING_LARGE_BLOBS:1-2`), so frames are generated: uint8 HWC **BGR** like
 `sv.get_video_frames_generator` yields (`trackers/runner.py:215-220`), a low-frequency background plus
-a few rectangles so activations sit in a realistic range (not white noise)."""
+a few rectangles so activations sit in a realistic range (not white noise).
+
+TEST INFRASTRUCTURE (moved out of the product package in round 4).  Importing this module registers the
+``synthetic://?n=64&h=720&w=1280&fps=30&seed=0`` frame source with ``padel_analytics_amd.video``."""
 from __future__ import annotations
 
 import numpy as np
@@ -26,3 +29,30 @@ def synthetic_frames(n: int, h: int, w: int, seed: int = 0) -> np.ndarray:
         img += rng.normal(0, 3.0, img.shape).astype(np.float32)
         out[i] = np.clip(img, 0, 255).astype(np.uint8)
     return out
+
+
+def _query(p: str) -> dict:
+    from urllib.parse import parse_qs, urlparse
+    q = {k: int(v[0]) for k, v in parse_qs(urlparse(p).query).items()}
+    return {"n": q.get("n", 64), "h": q.get("h", 720), "w": q.get("w", 1280), "fps": q.get("fps", 30), "seed": q.get("seed", 0)}
+
+
+def _info(p: str):
+    from padel_analytics_amd import video
+    q = _query(p)
+    return video.VideoInfo(q["w"], q["h"], q["fps"], q["n"])
+
+
+def _frames(p: str, start: int, end, stride: int):
+    q = _query(p)
+    stop = q["n"] if end is None else min(end, q["n"])
+    for i in range(start, stop, stride):
+        yield synthetic_frames(1, q["h"], q["w"], seed=q["seed"] * 100003 + i)[0]
+
+
+def _register():
+    from padel_analytics_amd import video
+    video.register_source("synthetic", _info, _frames)
+
+
+_register()

@@ -15,6 +15,7 @@ from pathlib import Path
 import pytest
 
 from padel_analytics_amd import dist as D
+from tests import synth  # noqa: F401  (registers the synthetic:// frame source)
 
 WORKER = str(Path(__file__).with_name("dist_worker.py"))
 

@@ -5,7 +5,8 @@ import pytest
 import torch
 
 from oracle import ball_ref as br, tracknet_ref as tr
-from padel_analytics_amd import checkpoint, engine as E, graph as G, synth, video
+from padel_analytics_amd import checkpoint, engine as E, graph as G, video
+from tests import synth
 from padel_analytics_amd.trackers import BallTracker
 
 pytestmark = pytest.mark.gpu

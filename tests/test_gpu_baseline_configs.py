@@ -17,7 +17,8 @@ import pytest
 
 import bench
 from oracle import yolov8_ref as ref
-from padel_analytics_amd import checkpoint, detections as D, dist, engine as E, graph as G, synth, video
+from padel_analytics_amd import checkpoint, detections as D, dist, engine as E, graph as G, video
+from tests import synth
 from padel_analytics_amd.trackers import BallDetectTracker, PlayerKeypointsTracker, PlayerTracker, TrackingRunner
 from tests import parity
 

@@ -15,7 +15,8 @@ import torch
 
 import bench
 from oracle import yolov8_ref as ref
-from padel_analytics_amd import checkpoint, engine as E, graph as G, synth
+from padel_analytics_amd import checkpoint, engine as E, graph as G
+from tests import synth
 from padel_analytics_amd.trackers import Ball, BallDetectTracker
 from tests import parity
 from tests.test_gpu_yolo_parity import _check

@@ -17,7 +17,8 @@ import torch
 import torch.nn.functional as F
 
 from oracle import yolov8_ref as ref
-from padel_analytics_amd import engine as E, graph as G, synth
+from padel_analytics_amd import engine as E, graph as G
+from tests import synth
 from tests import graph_interp, parity
 from tests.test_gpu_yolo_parity import _calib
 

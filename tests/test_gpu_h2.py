@@ -239,7 +239,8 @@ def test_stale_arena_bytes_cannot_reach_results(gpu_engine, mode):
     overflowed.  The h2 / fp32 kernels read no such byte: fill the arena with NaN patterns between two identical
     inferences (YOLOv8 detect with its concat buffers and absorbed upsamples; the TrackNet U-Net) — results unchanged."""
     from oracle import tracknet_ref as tr
-    from padel_analytics_amd import synth, yolo_arch
+    from padel_analytics_amd import yolo_arch
+    from tests import synth
     frames = synth.synthetic_frames(2, 360, 640, seed=4)
     sd = yolo_arch.synth_state_dict("n", 80, None, seed=2, cls_bias=-1.0)
     m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None, dtype=E.graph_dtype(mode)))
@@ -272,7 +273,8 @@ def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
     """Tuning "fuse_stem" (csrc/stem_l1_h2.hip, on by default since round 4): model.0 + model.1 as one kernel — the stem map stays in LDS.  Same
     arithmetic in the same order as the two kernels it replaces: head maps and detections are bitwise those of the unfused
     run (c = 16: tail-only K walk; 32: one chunk; 48: chunk + tail with the LDS region reused; partial tiles at 288)."""
-    from padel_analytics_amd import synth, yolo_arch
+    from padel_analytics_amd import yolo_arch
+    from tests import synth
     h, w = hw
     frames = synth.synthetic_frames(3, h, w, seed=9)
     sd = yolo_arch.synth_state_dict(scale, 80, None, seed=3, cls_bias=-1.0)

@@ -12,6 +12,7 @@ from padel_analytics_amd import checkpoint, detections as D, video
 from padel_analytics_amd.trackers import (BallTracker, PlayerKeypointsTracker, PlayerTracker, Players, PlayersKeypoints,
                                           TrackingRunner)
 from tests import parity
+from tests import synth  # noqa: F401  (registers the synthetic:// frame source)
 
 pytestmark = pytest.mark.gpu
 

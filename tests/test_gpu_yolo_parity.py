@@ -23,7 +23,8 @@ import pytest
 import torch
 
 from oracle import synth_weights, yolov8_ref as ref
-from padel_analytics_amd import engine as E, graph as G, synth
+from padel_analytics_amd import engine as E, graph as G
+from tests import synth
 from tests import parity
 
 pytestmark = pytest.mark.gpu

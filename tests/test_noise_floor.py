@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from oracle import synth_weights, yolov8_ref as ref
-from padel_analytics_amd import synth
+from tests import synth
 from tests import parity
 
 

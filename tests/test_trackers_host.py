@@ -10,6 +10,7 @@ from padel_analytics_amd import bytetrack, detections as D, video
 from padel_analytics_amd.trackers import tracker as T
 from padel_analytics_amd.trackers.players_keypoints_tracker import PlayerKeypoint, PlayerKeypoints, PlayersKeypoints
 from padel_analytics_amd.trackers.players_tracker import Player, Players
+from tests import synth  # noqa: F401  (registers the synthetic:// frame source)
 
 
 class _Obj(T.Object):

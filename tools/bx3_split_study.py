@@ -19,6 +19,7 @@ import torch.nn.functional as F
 sys.path.insert(0, ".")
 from oracle import synth_weights, yolov8_ref as ref          # noqa: E402
 from padel_analytics_amd import synth                        # noqa: E402
+from tests import synth
 from tests import parity                                     # noqa: E402
 
 

@@ -5,7 +5,8 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import bench
-from padel_analytics_amd import engine as E, graph as G, synth
+from padel_analytics_amd import engine as E, graph as G
+from tests import synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "ball"
 frames = synth.synthetic_frames(64, 720, 1280, seed=1000)

@@ -8,7 +8,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import bench
-from padel_analytics_amd import engine as E, synth, video
+from padel_analytics_amd import engine as E, video
+from tests import synth
 from padel_analytics_amd.trackers.tracker import _sampler
 
 B, H, W, NB = 64, 720, 1280, 8

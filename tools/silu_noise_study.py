@@ -18,6 +18,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 from oracle import synth_weights, yolov8_ref as ref          # noqa: E402  (tuning tool: the oracle is the subject here)
 from padel_analytics_amd import synth                         # noqa: E402
+from tests import synth
 from tests import parity                                      # noqa: E402
 
 

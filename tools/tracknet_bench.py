@@ -17,7 +17,8 @@ if __name__ == "__main__":
     ap.add_argument("--feed", type=int, default=8)
     a = ap.parse_args()
     from oracle import tracknet_ref as tr          # seeded synthetic TrackNet weights (setup only)
-    from padel_analytics_amd import engine as E, graph as G, synth
+    from padel_analytics_amd import engine as E, graph as G
+    from tests import synth
     eng = E.default_engine(0)
     frames = synth.synthetic_frames(a.frames, 720, 1280, seed=77)
     g = G.build_tracknet(tr.synth_tracknet_state_dict(3), dtype=E.graph_dtype())

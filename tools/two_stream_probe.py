@@ -9,7 +9,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 import bench
-from padel_analytics_amd import checkpoint, engine as E, synth, video, yolo
+from padel_analytics_amd import checkpoint, engine as E, video, yolo
+from tests import synth
 
 B, H, W, NB = 64, 720, 1280, 8
 half = "--half" in sys.argv
