@@ -94,6 +94,7 @@ def parse():
                     help="fp32-equivalent conv arithmetic: h2 (default: activations as fp16 pairs, 3 products on the f16 matrix "
                          "pipe, corrections in their own accumulator), bx3 (exact 3-way bf16 split, 6 products; the full-range "
                          "fallback of h2), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
+    ap.add_argument("--replay", type=int, default=0, help="tuning: frames per pass over the op list (0 = the whole batch)")
     ap.add_argument("--fake-engine", action="store_true",
                     help="TEST ONLY (tests/test_bench_gloo.py): run main() over tests/fake_engine.py with the gloo backend — the "
                          "launcher contract, barriers, max-over-ranks timing and the weight broadcast without a GPU; the line "
@@ -295,7 +296,7 @@ def spawn_ranks(a) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False, frac=0.01, tag=""):
+def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False, frac=0.01, tag="", replay=0, sd_override=None):
     """The three plugin classes exactly as main.py:126-161 constructs them, over synthetic checkpoints.  Only rank 0
     synthesises / "loads" real weights; the other ranks create their models from an architecture-only checkpoint
     with an EMPTY weight blob in HBM and receive rank 0's blob through pa_engine_bcast_weights."""
@@ -304,7 +305,8 @@ def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False, frac=0.01
     trackers, flops = {}, {}
     for name in names:
         cfg = TRACKERS[name]
-        sd = make_state_dict(name, cfg, frames, frac[name] if isinstance(frac, dict) else frac) if rank == 0 else yolo_arch.synth_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], 0)
+        sd = (sd_override[name] if sd_override else make_state_dict(name, cfg, frames, frac[name] if isinstance(frac, dict) else frac)) \
+            if rank == 0 else yolo_arch.synth_state_dict(cfg["scale"], cfg["nc"], cfg["kpt"], 0)
         path = Path(tmp) / f"{name}{tag}_r{rank}.pt"
         checkpoint.save_checkpoint(path, sd, "pose" if cfg["kpt"] else "detect", cfg["nc"], cfg["kpt"], cfg["scale"],
                                    {0: "person" if name != "ball" else "ball"})
@@ -318,7 +320,7 @@ def build_trackers(names, frames, rank, B, H, W, eng, tmp, half=False, frac=0.01
             t = BallDetectTracker(str(path), batch_size=B, conf=cfg["conf"], half=half)
         # frames per graph replay: the whole batch (measured on c3 in round 1: 16 -> 247, 32 -> 256, 64 -> 264
         # frames/s; small replays leave the P5 layers with ~2 rounds of workgroups)
-        t.model.set_max_batch(B)
+        t.model.set_max_batch(replay or B)
         t.model.attach(eng, receive_weights=rank != 0)
         t.model.broadcast_weights(root=0)                 # RCCL, HBM -> HBM (a self-broadcast at N=1)
         trackers[name] = t
@@ -386,7 +388,7 @@ def main():
     tmp = tempfile.mkdtemp(prefix="padel_bench_")
     os.environ.setdefault("PADEL_BENCH_SD_CACHE", tmp)      # calibrated checkpoints on disk: the PMC sub-runs (measure_traffic) reuse them
     with contextlib.redirect_stdout(sys.stderr):
-        trackers, flops_per_frame = build_trackers(names, frames, rank, B, H, W, eng, tmp, half=a.dtype == "f16")
+        trackers, flops_per_frame = build_trackers(names, frames, rank, B, H, W, eng, tmp, half=a.dtype == "f16", replay=a.replay)
 
     def fence():
         eng.synchronize()
@@ -535,9 +537,29 @@ def main():
                 ve = {"timed_checkpoints": {"value": round(world * B * K / dt_g, 2), "ms_per_step": round(1e3 * dt_g / K, 3),
                                             "objects_per_frame": per_frame(trackers)}}
                 if world == 1:
+                    # second calibration of the SAME checkpoints: the class bias of every head is shifted so that, on the clip,
+                    # ~6 candidates per frame pass `conf` (what a padel court shows: 4 players, the odd spectator) — the shift
+                    # comes from the score distribution the engine itself reports at conf 0.01 (setup, untimed)
+                    target = 6
+                    sds = {}
+                    for n_ in names:
+                        cfg_ = TRACKERS[n_]
+                        sd_ = dict(make_state_dict(n_, cfg_, frames))
+                        bx, _, cn = trackers[n_].model._ensure_model().yolo_infer(
+                            clip.buffer, B, H, W, imgsz=cfg_["imgsz"], conf=0.01, iou=0.7, classes=cfg_["classes"],
+                            pre_mode=E.PRE_PIL_STRETCH if cfg_["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg_["rev"])
+                        sc = np.sort(np.concatenate([bx[i, :cn[i], 4] for i in range(B)]))[::-1]
+                        s_star = float(np.clip(sc[min(target * B, len(sc) - 1)], 1e-4, 1 - 1e-4)) if len(sc) else cfg_["conf"]
+                        delta = np.log(cfg_["conf"] / (1 - cfg_["conf"])) - np.log(s_star / (1 - s_star))
+                        for l in range(3):
+                            k_ = f"model.22.cv3.{l}.2.bias"
+                            b_ = np.asarray(sd_[k_], np.float32).copy()
+                            b_[0] += np.float32(delta)
+                            sd_[k_] = b_.astype(np.float16).astype(np.float32)
+                        sds[n_] = sd_
                     with contextlib.redirect_stdout(sys.stderr):
-                        rtrk, _ = build_trackers(names, frames, rank, B, H, W, eng, tmp, half=a.dtype == "f16",
-                                                 frac={"players": 0.0012, "ball": 0.002, "pose": 0.00024}, tag="_real")
+                        rtrk, _ = build_trackers(names, frames, rank, B, H, W, eng, tmp, half=a.dtype == "f16", tag="_real",
+                                                 replay=a.replay, sd_override=sds)
                     T.set_eager_objects(False)
                     run_runner(clip, 1, trk=rtrk)
                     dt_l, _ = run_runner(clip, K, trk=rtrk)
@@ -547,7 +569,7 @@ def main():
                     ve["realistic_detections"] = {"value": round(world * B * K / dt_r, 2), "ms_per_step": round(1e3 * dt_r / K, 3),
                                                   "value_lazy_objects": round(world * B * K / dt_l, 2),
                                                   "objects_per_frame": per_frame(rtrk),
-                                                  "what": "same graphs, class-bias calibrated for a handful of detections per frame"}
+                                                  "what": "same graphs and weights, class bias of the heads shifted for ~6 detections per frame (a court's worth)"}
                     for t_ in rtrk.values():
                         t_.model.close()
             finally:

@@ -15,6 +15,7 @@
 // LDS: 2 x 12 KB patch + 2 x 3 x BN x 64 B: 48 KB for BN = 64 -> 3 workgroups per CU; 60 KB for BN = 96 -> 2.
 #include "kernels.h"
 #include "act_fast.h"
+#include "f16_epilogue.h"
 #include <cmath>
 #include <cstdint>
 
@@ -62,84 +63,7 @@ __device__ __forceinline__ void q16_dma_k(int k, unsigned voff, p16_i32x4 rsrc, 
 }
 __device__ __forceinline__ void p16_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned p16_off(int p, int q) { return (unsigned)(p * 64 + ((q ^ (((p >> 2) & 1) << 1)) << 4)); }
-// activation: act_fast.h (11 VALU for SiLU instead of the 28+ of expf() and an IEEE division; with one MFMA per product the
-// fp16 kernels spend as many cycles in their epilogues as in their matrix work)
-__device__ __forceinline__ float p16_act(float v, int act) {
-    if (act == ACT_SILU) return fast_act<ACT_SILU>(v);
-    if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
-    if (act == ACT_SIGMOID) return fast_act<ACT_SIGMOID>(v);
-    return v;
-}
-
-// lane: pixel mpix[f] (-1: outside the tensor), channels co0 .. co0+3 with co0 = (fw + j)*16 + lq*4
-template <int MF, int NF, int ACT, bool RES, bool FAST>
-__device__ __forceinline__ void p16_epilogue_case(const ConvArgs& a, const p16_f32x4 (&acc)[MF][NF], const int (&mpix)[MF], int fw, int lq) {
-    const _Float16* res = reinterpret_cast<const _Float16*>(a.res);
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int co0 = (fw + j) * 16 + lq * 4;
-        p16_f32x4 b;
-        if (FAST) b = *reinterpret_cast<const p16_f32x4*>(a.bias + co0);
-        else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) b[r] = a.bias[min(co0 + r, a.n16 * 16 - 1)];
-        }
-#pragma unroll
-        for (int f = 0; f < MF; ++f) {
-            const int m = mpix[f];
-            if (!FAST && m < 0) continue;
-            p16_f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = p16_act(acc[f][j][r] + b[r], ACT);
-            if (FAST) {
-                if (RES) {
-                    const p16_h4 rv = *reinterpret_cast<const p16_h4*>(res + (long long)m * a.res_cs + a.res_choff + co0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                if (a.out_f32) {
-                    *reinterpret_cast<p16_f32x4*>(a.out + (long long)m * a.out_cs + a.out_choff + co0) = v;
-                } else {
-                    typedef float p16_f2 __attribute__((ext_vector_type(2)));
-                    typedef _Float16 p16_h2 __attribute__((ext_vector_type(2)));
-                    p16_h4 o;                                  // saturate (no infinities in HBM), packed round-to-nearest conversion
-#pragma unroll
-                    for (int r = 0; r < 2; ++r) {
-                        const p16_f2 x = {__builtin_amdgcn_fmed3f(v[2 * r], -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(v[2 * r + 1], -65504.0f, 65504.0f)};
-                        const p16_h2 hh = __builtin_convertvector(x, p16_h2);
-                        o[2 * r] = hh[0]; o[2 * r + 1] = hh[1];
-                    }
-                    *reinterpret_cast<p16_h4*>(reinterpret_cast<_Float16*>(a.out) + (long long)m * a.out_cs + a.out_choff + co0) = o;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + r;
-                    if (co >= a.cout) continue;
-                    float x = v[r];
-                    if (RES) x += (float)res[(long long)m * a.res_cs + a.res_choff + co];
-                    if (a.out_f32) a.out[(long long)m * a.out_cs + a.out_choff + co] = x;
-                    else reinterpret_cast<_Float16*>(a.out)[(long long)m * a.out_cs + a.out_choff + co] = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
-                }
-            }
-        }
-    }
-}
-template <int MF, int NF>
-__device__ __forceinline__ void p16_epilogue(const ConvArgs& a, const p16_f32x4 (&acc)[MF][NF], const int (&mpix)[MF], int fw, int lq, bool fast) {
-#define PADEL_P16_EPI(ACT_)                                                                                       \
-    do {                                                                                                          \
-        if (a.res) { if (fast) p16_epilogue_case<MF, NF, ACT_, true, true>(a, acc, mpix, fw, lq);                 \
-                     else p16_epilogue_case<MF, NF, ACT_, true, false>(a, acc, mpix, fw, lq); }                   \
-        else       { if (fast) p16_epilogue_case<MF, NF, ACT_, false, true>(a, acc, mpix, fw, lq);                \
-                     else p16_epilogue_case<MF, NF, ACT_, false, false>(a, acc, mpix, fw, lq); }                  \
-    } while (0)
-    if (a.act == ACT_SILU) PADEL_P16_EPI(ACT_SILU);
-    else if (a.act == ACT_RELU) PADEL_P16_EPI(ACT_RELU);
-    else if (a.act == ACT_SIGMOID) PADEL_P16_EPI(ACT_SIGMOID);
-    else PADEL_P16_EPI(ACT_NONE);
-#undef PADEL_P16_EPI
-}
+// epilogue: f16_epilogue.h (shared with conv_tap16.hip)
 
 }  // namespace
 
@@ -293,7 +217,7 @@ __global__ void __launch_bounds__(256, NF <= 4 ? 3 : 2) conv_p16_kernel(const Co
     }
     const bool fast = y0 + 8 <= a.Ho && x0 + 16 <= a.Wo && (f0 + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
                       (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
-    p16_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
+    f16_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
 }
 
 // ---- the quad variant: a workgroup owns 16 x 16 output pixels x BN channels, a wave 4 rows x 16 pixels x ALL NF fragments.
@@ -466,7 +390,7 @@ __global__ void __launch_bounds__(256, 2) conv_p16q_kernel(const ConvArgs a) {
     }
     const bool fast = y0 + 16 <= a.Ho && x0 + 16 <= a.Wo && (f0 + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
                       (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
-    p16_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
+    f16_epilogue<MF, NF>(a, acc, mpix, f0, lq, fast);
 }
 
 template <int NF>

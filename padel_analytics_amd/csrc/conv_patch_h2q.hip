@@ -26,6 +26,19 @@
 // (+1.6 %: the other resident workgroup already covers most of a prologue), weight requests two steps ahead through a
 // second "operands are in registers" barrier per step (+-0: the request latency was not on the critical path), different
 // MFMA priorities for the two waves of a SIMD (-4 %).
+// Round 4 (gpurun r4a-r4c, tools/ab/ A/B libraries, profiles/r4_quad_variants.txt): the epilogue rewrite (h2_common.h: hoisted
+// residual loads, 16-byte stores) gave this kernel +4..8 %.  Five changes to the main loop were then measured on top of it
+// and ALL dropped — every combination ran 2-4 % SLOWER than this round-3 loop (96 -> 96: 366 vs 350-352 TFLOP/s, 192 -> 192:
+// 415 vs 408-410, pose 96 -> 96: 374 vs 354-356): (1) channel fragments outermost with the third weight operand read under
+// the first twelve MFMAs (two weight operand sets, 229 VGPRs): the late read stalls the MFMA stream (36 MFMAs issued in 855
+// instead of 673 ticks) by what it saves in front of it; (2) all six weight reads up front in that order: same; (3) the lane
+// offsets of the 12 patch spans from an LDS table instead of ~25 VALU per span in wave 3; (4) tap 0's four row reads ahead of
+// its barrier (the patch published at the previous chunk's tap-8 barrier); (5) the main chain of a chunk started from the
+// constant 0 instead of zeroing 48 registers, its flush either inside tap 8's MFMA stream (tap 8: 1950 ticks) or behind it;
+// (6) the first patch requested by all four waves instead of wave 3.  With (3)-(6) on the round-3 row-major order the kernel
+// needs 256 VGPRs + 28 bytes of scratch and loses 7 %.  The step is bounded by the weight DMA's round trip (requested one step
+// ahead: ~1000 cycles issue -> landed under load), which only a third ring stage would hide — 89 KB of LDS against the 80 KB
+// that two workgroups per CU allow.
 // Same products in the same order per accumulator as every other h2 kernel (cross: wh am, then wm ah; main: wh ah, flushed
 // into acc once per chunk): bitwise identical results.
 //
@@ -47,8 +60,8 @@ __device__ __forceinline__ unsigned hq_off(int p, int q) { return (unsigned)(p *
 
 // DBG (tuning only, builds with -DPADEL_H2P_PROBES, pa_engine_set_tuning "timeline"): every wave stamps s_memtime at 5
 // points of every tap step (step top / own requests landed / barrier passed / operands in registers / last MFMA issued)
-// into an LDS ring of 16 steps, dumped to a.dbg at the end (tools/timeline_probe.py --kernel h2q)
-constexpr int kQDbgSteps = 16;
+// into an LDS ring of 32 steps, dumped to a.dbg at the end (tools/timeline_probe.py --kernel h2q)
+constexpr int kQDbgSteps = 32;
 constexpr int kQDbgWords = 8 + 4 * kQDbgSteps * 5;
 
 }  // namespace
@@ -61,12 +74,10 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
     constexpr int BSTAGE_B = 2 * BPLANE_B;
     static_assert(NF == 3, "weight requests are laid out for 6 spans of 16 rows per plane: 2 per wave 0..2");
     constexpr int DBG_B = DBG ? (4 * kQDbgSteps * 5 + 4 * 64) * 8 : 0;
-    constexpr int PTAB_B = 12 * 64 * 4;           // lane offsets of the 12 patch spans (wave 3), computed once per workgroup
-    static_assert(2 * kQPatchB + 2 * BSTAGE_B + PTAB_B + DBG_B <= 80 * 1024, "2 workgroups per CU, instrumented too");
-    __shared__ __attribute__((aligned(16))) float lds[(2 * kQPatchB + 2 * BSTAGE_B + PTAB_B + DBG_B) / 4];
+    static_assert(2 * kQPatchB + 2 * BSTAGE_B + DBG_B <= 80 * 1024, "2 workgroups per CU, instrumented too");
+    __shared__ __attribute__((aligned(16))) float lds[(2 * kQPatchB + 2 * BSTAGE_B + DBG_B) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
-    unsigned* const ptab = reinterpret_cast<unsigned*>(ldsb + 2 * kQPatchB + 2 * BSTAGE_B);
-    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(ldsb + 2 * kQPatchB + 2 * BSTAGE_B + PTAB_B);
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(ldsb + 2 * kQPatchB + 2 * BSTAGE_B);
     unsigned long long t_begin = 0;
     int dbg_k = 0;
     if constexpr (DBG) t_begin = __builtin_amdgcn_s_memtime();
@@ -109,35 +120,24 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
     const int p_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
     const unsigned p_piece = (unsigned)((p_q >> 1) * 64 + (p_q & 1) * 16);
     const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
-    // spans S0_, S0_ + 1 of both planes (a sixth of a chunk's patch) of chunk CH_ into buffer BUF_.  The lane offsets of a span
-    // (pixel -> row / column of the 18-wide patch, image bounds, byte offset: ~25 VALU) do not depend on the chunk: wave 3
-    // computes the 12 of them once into an LDS table and re-reads two per tap (round 3 recomputed them under the MFMAs of every
-    // tap 0..5 — the one wave that did so reached each barrier ~90 cycles after its three siblings)
-#define PADEL_HQ_PATCH2(CH_, BUF_, S0_, V0_, V1_)                                                                         \
+    // spans S0_, S0_ + 1 of both planes (a sixth of a chunk's patch) of chunk CH_ into buffer BUF_
+#define PADEL_HQ_PATCH2(CH_, BUF_, S0_)                                                                           \
     do {                                                                                                          \
         const unsigned so_ = (unsigned)(CH_) * 128u;                                                              \
         const unsigned lb_ = lp0 + (unsigned)(BUF_) * (unsigned)kQPatchB;                                         \
-        PADEL_HQ_PSPAN(S0_, V0_); PADEL_HQ_PSPAN((S0_) + 1, V1_);                                                 \
+        int pl_ = p_lane;                                  /* recomputed per use: 12 hoisted lane offsets would spill */ \
+        asm volatile("" : "+v"(pl_));                                                                             \
+        PADEL_HQ_PSPAN(S0_); PADEL_HQ_PSPAN((S0_) + 1);                                                           \
     } while (0)
-#define PADEL_HQ_PSPAN(S_, VO_)                                                                                   \
+#define PADEL_HQ_PSPAN(S_)                                                                                        \
     do {                                                                                                          \
-        dma3<(S_) * 1024>(VO_, rsrcP, so_, lb_);                                                                  \
-        dma3<kQPlaneB + (S_) * 1024>(VO_, rsrcP, so_ + 32u, lb_);                                                 \
+        const int pp_ = (S_) * 16 + pl_;                                                                          \
+        const int py_ = pp_ / kQPW, px_ = pp_ - py_ * kQPW;                                                       \
+        const bool ok_ = pp_ < kQNPix && (unsigned)(y0 - 1 + py_) < (unsigned)a.H && (unsigned)(x0 - 1 + px_) < (unsigned)a.W; \
+        const unsigned vo_ = ok_ ? (unsigned)((py_ * a.W + px_) * a.in_cs * 4) + p_piece : kOOR3;                 \
+        dma3<(S_) * 1024>(vo_, rsrcP, so_, lb_);                                                                  \
+        dma3<kQPlaneB + (S_) * 1024>(vo_, rsrcP, so_ + 32u, lb_);                                                 \
     } while (0)
-    // Prologue: every wave computes the offsets of three spans into the table and requests those spans of chunk 0 itself
-    // (round 3: wave 3 issued all 24 requests of the first patch one after the other while its siblings waited at the barrier)
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int sp = 3 * wave + k;
-        const int pp = sp * 16 + p_lane;
-        const int py = pp / kQPW, px = pp - py * kQPW;
-        const bool ok = pp < kQNPix && (unsigned)(y0 - 1 + py) < (unsigned)a.H && (unsigned)(x0 - 1 + px) < (unsigned)a.W;
-        const unsigned vo = ok ? (unsigned)((py * a.W + px) * a.in_cs * 4) + p_piece : kOOR3;
-        ptab[sp * 64 + lane] = vo;
-        const unsigned lb = lp0 + (unsigned)sp * 1024u;
-        dma3<0>(vo, rsrcP, 0u, lb);
-        dma3<kQPlaneB>(vo, rsrcP, 32u, lb);
-    }
 
     // ---- weights (waves 0..2): rows of (cin / 32) * 9 k-steps x 128 bytes (h | m); wave w requests the spans 2 w, 2 w + 1
     // (16 rows x 64 bytes) of both planes: lane i -> row i / 4 of the span, physical slot i & 3
@@ -173,8 +173,8 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
 #pragma unroll
     for (int f = 0; f < MF; ++f)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; cross[f][j] = acc[f][j]; }
-    h16x8 ah[4], am[4], wah, wam, wbh, wbm;       // ah / am: input rows in 4 sliding slots (row r of the current kx in slot r & 3)
+        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
+    h16x8 ah[4], am[4], wh[NF], wm[NF];       // ah / am: input rows in 4 sliding slots (row r of the current kx in slot r & 3)
     // input row R_ (0..5 of the wave's window) at column shift KX_ into its slot
 #define PADEL_HQ_READROW(R_, KX_)                                                                                 \
     do {                                                                                                          \
@@ -182,82 +182,72 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
         ah[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_);                                                       \
         am[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_ + kQPlaneB);                                            \
     } while (0)
-    // weights of channel fragment J_ of step T_ (both planes) into one of two operand sets
-#define PADEL_HQ_READW(T_, J_, WH_, WM_)                                                                          \
+#define PADEL_HQ_READB(T_)                                                                                        \
     do {                                                                                                          \
         const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
-        WH_ = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + (J_) * 256));                       \
-        WM_ = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + (J_) * 256));        \
-    } while (0)
-    // the 12 products of channel fragment J_ at tap row KY_ (output row f reads its input row f + KY_ from slot (f + KY_) & 3).
-    // Round 4: channel fragments outermost — the first twelve products of a step need two weight reads instead of six (the
-    // other four travel under them), and two weight operand sets (16 registers) suffice instead of three.  Per accumulator
-    // the products come in the same order as before (cross: wh am, wm ah; main: wh ah): bitwise the same sums.
-    // The main chain of a chunk starts from the constant 0 at tap 0 (same values as zeroing part and adding to it: 48 v_mov
-    // less per chunk) and goes into acc behind tap 8's last product.  Measured and dropped: adding each fragment's sums right
-    // behind its last product INSIDE tap 8's MFMA stream — the adds wait for the matrix pipe to drain and hold up the
-    // products behind them (tap 8: 1950 ticks against 1500-1650 for the other taps, gpurun r4a timeline)
-#define PADEL_HQ_MFMA_COL(J_, KY_, T_, WH_, WM_)                                                                  \
-    do {                                                                                                          \
-        _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                            \
-            cross[f][J_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH_, am[(f + (KY_)) & 3], cross[f][J_], 0, 0, 0); \
-        _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                            \
-            cross[f][J_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WM_, ah[(f + (KY_)) & 3], cross[f][J_], 0, 0, 0); \
-        if constexpr ((T_) == 0) {                                                                                \
-            _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
-                part[f][J_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH_, ah[(f + (KY_)) & 3], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
-        } else {                                                                                                  \
-            _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
-                part[f][J_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WH_, ah[(f + (KY_)) & 3], part[f][J_], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
+            wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
+            wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256));     \
         }                                                                                                         \
     } while (0)
+    // the 9 products of output row F_ at tap row KY_ (its input row F_ + KY_ sits in slot (F_ + KY_) & 3)
+#define PADEL_HQ_MFMA_ROW(F_, KY_)                                                                                \
+    do {                                                                                                          \
+        constexpr int s_ = ((F_) + (KY_)) & 3;                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[s_], cross[F_][j], 0, 0, 0);          \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[s_], cross[F_][j], 0, 0, 0);          \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[s_], part[F_][j], 0, 0, 0);            \
+    } while (0)
     // tap step T_ = 3 kx + ky of the current chunk.  Barrier: the weights of this step (requested one step earlier) have
-    // landed for every wave, the other weight stage (read one step earlier) is free for the request of step T_ + 1.  The
-    // barrier of tap 8 also publishes the NEXT chunk's patch buffer (wave 3 waits for its DMA there, two steps after the last
-    // request) and the barrier of tap 0 frees the other one: every row read, tap 0's four included, is issued ahead of the
-    // step's wait + barrier (round 3 read tap 0's rows behind its barrier: 14 operand reads on the critical path of that step).
+    // landed for every wave, the other weight stage (read one step earlier) is free for the request of step T_ + 1; at
+    // T_ == 0 it also publishes the chunk's patch buffer (wave 3 waited for its DMA) and frees the other patch buffer.
     // Rows: ky == 0 reads rows 0..3 of the new column, ky == 1 row 4 (into the slot of row 0), ky == 2 row 5 (slot of row 1).
-    // Requests go out under the first channel fragment's MFMAs: waves 0..2 the next step's weights, wave 3 a sixth of the next chunk's
-    // patch per tap 0..5 (lane offsets from the LDS table, fetched under the first row's nine products).
+    // Requests go out under the first row's MFMAs: waves 0..2 the next step's weights, wave 3 a sixth of the next chunk's
+    // patch per tap 0..5.
 #define PADEL_HQ_STEP(T_)                                                                                         \
     do {                                                                                                          \
         constexpr int kx_ = h2_tap_kx(T_), ky_ = h2_tap_ky(T_);                                                   \
         int rp_ = rd_pix;                                  /* row addresses recomputed per tap (3 VALU each): 18 hoisted ones would spill */ \
         asm volatile("" : "+v"(rp_));                                                                             \
         PADEL_HQ_STAMP(T_, 0);                                                                                    \
-        if constexpr (ky_ == 0) { PADEL_HQ_READROW(0, kx_); PADEL_HQ_READROW(1, kx_); PADEL_HQ_READROW(2, kx_); PADEL_HQ_READROW(3, kx_); } \
-        else PADEL_HQ_READROW(3 + ky_, kx_);                                                                      \
-        if ((T_) == 8 || wave != 3) wait_vm3<0>();                                                                \
+        if constexpr ((T_) > 0) {                          /* the planes are static inside a chunk: read under the wait */ \
+            if constexpr (ky_ == 0) { PADEL_HQ_READROW(0, kx_); PADEL_HQ_READROW(1, kx_); PADEL_HQ_READROW(2, kx_); PADEL_HQ_READROW(3, kx_); } \
+            else PADEL_HQ_READROW(3 + ky_, kx_);                                                                  \
+        }                                                                                                         \
+        if ((T_) == 0 || wave != 3) wait_vm3<0>();                                                                \
         PADEL_HQ_STAMP(T_, 1);                                                                                    \
         __builtin_amdgcn_s_barrier();                                                                             \
         asm volatile("" ::: "memory");                                                                            \
         PADEL_HQ_STAMP(T_, 2);                                                                                    \
-        PADEL_HQ_READW(T_, 0, wah, wam); PADEL_HQ_READW(T_, 1, wbh, wbm);                                         \
+        PADEL_HQ_READB(T_);                                                                                       \
+        if constexpr ((T_) == 0) { PADEL_HQ_READROW(0, 0); PADEL_HQ_READROW(1, 0); PADEL_HQ_READROW(2, 0); PADEL_HQ_READROW(3, 0); } \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         if constexpr (DBG) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PADEL_HQ_STAMP(T_, 3); }          \
         __builtin_amdgcn_s_setprio(1);                                                                            \
-        PADEL_HQ_MFMA_COL(0, ky_, T_, wah, wam);                                                                  \
+        PADEL_HQ_MFMA_ROW(0, ky_);                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_HQ_READW(T_, 2, wah, wam);                                                                          \
         if (wave != 3) {                                                                                          \
             if ((T_) < 8 || c + 1 < nch) PADEL_HQ_DMAB((T_) + 1, s_kb + ((T_) + 1) * 128u);                       \
         } else if ((T_) < 6 && c + 1 < nch) {                                                                     \
-            const unsigned pv0_ = ptab[2 * ((T_) < 6 ? (T_) : 0) * 64 + lane], pv1_ = ptab[(2 * ((T_) < 6 ? (T_) : 0) + 1) * 64 + lane]; \
-            PADEL_HQ_PATCH2(c + 1, (c + 1) & 1, 2 * ((T_) < 6 ? (T_) : 0), pv0_, pv1_);                           \
+            PADEL_HQ_PATCH2(c + 1, (c + 1) & 1, 2 * ((T_) < 6 ? (T_) : 0));                                       \
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_HQ_MFMA_COL(1, ky_, T_, wbh, wbm); PADEL_HQ_MFMA_COL(2, ky_, T_, wah, wam);                         \
+        PADEL_HQ_MFMA_ROW(1, ky_); PADEL_HQ_MFMA_ROW(2, ky_); PADEL_HQ_MFMA_ROW(3, ky_);                          \
         __builtin_amdgcn_s_setprio(0);                                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         PADEL_HQ_STAMP(T_, 4);                                                                                    \
     } while (0)
 
     unsigned s_kb = 0;
-    if (wave != 3) PADEL_HQ_DMAB(0, 0u);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the offset table is complete before anybody passes the barrier
-    wait_vm3<0>();                                         // chunk 0's patch (and tap 0's weights) before the first rows are read
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    if (wave == 3) {
+        PADEL_HQ_PATCH2(0, 0, 0); PADEL_HQ_PATCH2(0, 0, 2); PADEL_HQ_PATCH2(0, 0, 4);
+        PADEL_HQ_PATCH2(0, 0, 6); PADEL_HQ_PATCH2(0, 0, 8); PADEL_HQ_PATCH2(0, 0, 10);
+    } else {
+        PADEL_HQ_DMAB(0, 0u);
+    }
     for (int c = 0; c < nch; ++c) {
         const char* const pbuf = ldsb + (c & 1) * kQPatchB;
         PADEL_HQ_STEP(0); PADEL_HQ_STEP(1); PADEL_HQ_STEP(2); PADEL_HQ_STEP(3); PADEL_HQ_STEP(4);
@@ -265,15 +255,15 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
 #pragma unroll
         for (int f = 0; f < MF; ++f)
 #pragma unroll
-            for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];
+            for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         { const float* t_ = b_rd0; b_rd0 = b_rd1; b_rd1 = t_; const unsigned u_ = lw0; lw0 = lw1; lw1 = u_; }
         s_kb += 9u * 128u;
         dbg_k += 9;
     }
     wait_vm3<0>();
 #undef PADEL_HQ_STEP
-#undef PADEL_HQ_MFMA_COL
-#undef PADEL_HQ_READW
+#undef PADEL_HQ_MFMA_ROW
+#undef PADEL_HQ_READB
 #undef PADEL_HQ_READROW
 #undef PADEL_HQ_DMAB
 #undef PADEL_HQ_PSPAN

@@ -21,6 +21,7 @@
 //     softmax / box decode / NMS are the same kernels and the same arithmetic as on the fp32 path.
 #include "kernels.h"
 #include "act_fast.h"
+#include "f16_epilogue.h"
 #include <cmath>
 #include <cstdint>
 
@@ -61,13 +62,6 @@ __device__ __forceinline__ int fastdiv16(int n, unsigned magic, unsigned shift) 
     return (int)((__umulhi((unsigned)n, magic) + (unsigned)n) >> shift);
 }
 
-__device__ __forceinline__ float act16(float v, int act) {
-    if (act == ACT_SILU) return fast_act<ACT_SILU>(v);        // act_fast.h: 11 VALU instead of expf() + an IEEE division
-    if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
-    if (act == ACT_SIGMOID) return fast_act<ACT_SIGMOID>(v);
-    return v;
-}
-
 constexpr int min_waves16(int nw, int frags) { return nw == 4 ? (frags <= 6 ? 4 : (frags <= 8 ? 3 : 2)) : 2; }
 
 }  // namespace
@@ -95,71 +89,7 @@ constexpr int min_waves16(int nw, int frags) { return nw == 4 ? (frags <= 6 ? 4 
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
 
-// lane: pixel m = mw + f*16 + lr, channels co0 .. co0+3 with co0 = (fw + j)*16 + lq*4
-template <int MF, int NF, int ACT, bool RES, bool FAST>
-__device__ __forceinline__ void t16_epilogue_case(const ConvArgs& a, const f32x4 (&acc)[MF][NF], int mw, int fw, int lr, int lq) {
-    const _Float16* res = reinterpret_cast<const _Float16*>(a.res);
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int co0 = (fw + j) * 16 + lq * 4;
-        f32x4 b;
-        if (FAST) b = *reinterpret_cast<const f32x4*>(a.bias + co0);
-        else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) b[r] = a.bias[min(co0 + r, a.n16 * 16 - 1)];
-        }
-#pragma unroll
-        for (int f = 0; f < MF; ++f) {
-            const int m = mw + f * 16 + lr;
-            if (!FAST && m >= a.M) continue;
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = act16(acc[f][j][r] + b[r], ACT);
-            if (FAST) {
-                if (RES) {
-                    const h4 rv = *reinterpret_cast<const h4*>(res + (long long)m * a.res_cs + a.res_choff + co0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-                }
-                if (a.out_f32) {
-                    *reinterpret_cast<f32x4*>(a.out + (long long)m * a.out_cs + a.out_choff + co0) = v;
-                } else {
-                    h4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = (_Float16)__builtin_amdgcn_fmed3f(v[r], -65504.0f, 65504.0f);     // saturate: no infinities in HBM
-                    *reinterpret_cast<h4*>(reinterpret_cast<_Float16*>(a.out) + (long long)m * a.out_cs + a.out_choff + co0) = o;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + r;
-                    if (co >= a.cout) continue;
-                    float x = v[r];
-                    if (RES) x += (float)res[(long long)m * a.res_cs + a.res_choff + co];
-                    if (a.out_f32) a.out[(long long)m * a.out_cs + a.out_choff + co] = x;
-                    else reinterpret_cast<_Float16*>(a.out)[(long long)m * a.out_cs + a.out_choff + co] = (_Float16)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
-                }
-            }
-        }
-    }
-}
-
-// `fast`: every row and channel of the WORKGROUP's tile exists and the 4-channel groups are 8-/16-byte aligned
-template <int MF, int NF>
-__device__ __forceinline__ void t16_epilogue(const ConvArgs& a, const f32x4 (&acc)[MF][NF], int mw, int fw, int lr, int lq, bool fast) {
-#define PADEL_T16_EPI(ACT_)                                                                                       \
-    do {                                                                                                          \
-        if (a.res) { if (fast) t16_epilogue_case<MF, NF, ACT_, true, true>(a, acc, mw, fw, lr, lq);               \
-                     else t16_epilogue_case<MF, NF, ACT_, true, false>(a, acc, mw, fw, lr, lq); }                 \
-        else       { if (fast) t16_epilogue_case<MF, NF, ACT_, false, true>(a, acc, mw, fw, lr, lq);              \
-                     else t16_epilogue_case<MF, NF, ACT_, false, false>(a, acc, mw, fw, lr, lq); }                \
-    } while (0)
-    if (a.act == ACT_SILU) PADEL_T16_EPI(ACT_SILU);
-    else if (a.act == ACT_RELU) PADEL_T16_EPI(ACT_RELU);
-    else if (a.act == ACT_SIGMOID) PADEL_T16_EPI(ACT_SIGMOID);
-    else PADEL_T16_EPI(ACT_NONE);
-#undef PADEL_T16_EPI
-}
+// epilogue: f16_epilogue.h (shared with conv_patch16.hip)
 
 #define PADEL_T16_GEOMETRY(NST_)                                                                                  \
     constexpr int NW = WM * WN;                                                                                   \
@@ -217,7 +147,9 @@ __device__ __forceinline__ void t16_epilogue(const ConvArgs& a, const f32x4 (&ac
 #define PADEL_T16_FINISH()                                                                                        \
     const bool fast_ = m0 + BM <= a.M && (f0 + WN * NF) * 16 <= a.cout && ((a.out_choff & 3) == 0) &&             \
                        ((a.out_cs & 3) == 0) && (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));                \
-    t16_epilogue<MF, NF>(a, acc, m0 + wm * MF * 16, f0 + wn * NF, lr, lq, fast_);
+    int mpix_[MF];                                                                                                \
+    _Pragma("unroll") for (int f = 0; f < MF; ++f) { const int m_ = m0 + wm * MF * 16 + f * 16 + lr; mpix_[f] = m_ < a.M ? m_ : -1; } \
+    f16_epilogue<MF, NF>(a, acc, mpix_, f0 + wn * NF, lq, fast_);
 
 // =====================================================================================================  3x3
 template <int WM, int WN, int MF, int NF>

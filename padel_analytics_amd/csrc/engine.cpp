@@ -748,7 +748,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             size_t dbg_bytes = 0;
             if (e->t.timeline && h2 && lv == 323 && conv_h2q_supported(a) && !e->timeline_path.empty()) {
                 const size_t patches = (size_t)n * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);          // conv_patch_h2q.hip: one record per workgroup of its 1-D grid
-                dbg_bytes = 8 * ((patches + 7) / 8) * (size_t)((a.n16 + 5) / 6) * (8 + 4 * 16 * 5) * 8;          // kQDbgWords of conv_patch_h2q.hip (16-step ring)
+                dbg_bytes = 8 * ((patches + 7) / 8) * (size_t)((a.n16 + 5) / 6) * (8 + 4 * 32 * 5) * 8;          // kQDbgWords of conv_patch_h2q.hip (32-step ring)
             } else if (e->t.timeline && !h2 && use_tap && lv == 7 && o.ksize == 3 && !e->timeline_path.empty()) {
                 dbg_bytes = (size_t)((a.M + 63) / 64) * ((o.npad + 95) / 96) * kConvDbgWords * 8;
             }

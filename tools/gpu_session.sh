@@ -10,11 +10,13 @@
 #   ubench        tools/mfma_f16_ubench (16x16x32 and 32x32x16 f16 MFMA ceilings)
 #   sweep         tools/conv_bench.py --dtype h2 for every library under tools/ab/ and the product library
 #   timeline      tools/timeline_probe.py --kernel h2q with tools/ab/libpadel_hip_probes.so (192->192 and 96->96)
+#   tests_f16     the fp16 kernel tests + BASELINE configs[0] / [3] / [4] tests
+#   replay        engine-only c3 with 16 / 32 frames per pass over the op list (MALL residency experiment)
 #   bench         python bench.py --dump-ops (default command line: c3)
 #   bench_short   python bench.py --steps 5 --warmup 2 --dump-ops, engine-only extras skipped where the flag exists
 #   bench_c2 / bench_c4   the other single-GPU configs
 #   stats         rocprofv3 --kernel-trace --stats of the bench command (summary copied to gpurun_out/<tag>/)
-#   pmc           tools/pmc_h2.sh (MFMA busy / LDS conflicts of the h2 kernels), tools/pmc_bench_traffic.sh
+#   pmc           tools/pmc_h2.sh (MFMA busy / wait breakdown / LDS conflicts / L2 hit rate of the h2 conv kernels; three --pmc passes)
 set -u
 TAG=$1; shift
 OUT=gpurun_out/$TAG
@@ -58,15 +60,22 @@ for stage in "$@"; do
     bench_c4)
       timeout 900 python bench.py --workload c4 --dump-ops "$OUT/ops_c4.csv" > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; note $stage $?
       python tools/bench_summary.py "$OUT/bench_c4.json" ;;
+    tests_f16)
+      timeout 900 python -m pytest tests/test_gpu_fp16.py tests/test_gpu_baseline_configs.py -m gpu -q -x > "$OUT/pytest_f16.txt" 2>&1; note $stage $?
+      tail -5 "$OUT/pytest_f16.txt"; cp gpurun_out/config4_report.json "$OUT/" 2>/dev/null ;;
+    replay)
+      for n in 16 32; do
+        timeout 600 python bench.py --steps 5 --warmup 2 --quick --engine-only --no-roofline --replay $n > "$OUT/bench_replay$n.json" 2> "$OUT/bench_replay$n.err"; note "replay:$n" $?
+        python -c "import json;d=json.load(open('$OUT/bench_replay$n.json'));print('replay $n', d['value'], d['ms_per_step'])"
+      done ;;
     stats)
       ( cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/rocprof" -o c3 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --quick > "$GRAFT_REPO_ROOT/$OUT/rocprof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/rocprof_bench.err" ); note $stage $?
       find "$OUT/rocprof" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/c3_kernel_stats.csv"
       find "$OUT/rocprof" -type f ! -name '*kernel_stats.csv' -delete 2>/dev/null
       head -12 "$OUT/c3_kernel_stats.csv" ;;
     pmc)
-      timeout 900 bash tools/pmc_h2.sh "$OUT/pmc" > "$OUT/pmc_h2.log" 2>&1; note "pmc:h2" $?
-      timeout 900 bash tools/pmc_bench_traffic.sh "$OUT/pmc_traffic" > "$OUT/pmc_traffic.log" 2>&1; note "pmc:traffic" $?
-      tail -20 "$OUT/pmc_h2.log"; tail -8 "$OUT/pmc_traffic.log" ;;
+      timeout 1200 bash tools/pmc_h2.sh > "$OUT/conv_h2_pmc.txt" 2>&1; note "pmc:h2" $?
+      grep -v '^pass' "$OUT/conv_h2_pmc.txt" | head -40 ;;
     *) echo "unknown stage $stage"; note "$stage" 99 ;;
   esac
 done

@@ -65,7 +65,7 @@ def main():
     global STEPS, WORDS
     h2q = a.kernel == "h2q"
     if h2q:
-        STEPS, WORDS = 16, 8 + 4 * 16 * 5            # conv_patch_h2q.hip:kQDbgSteps
+        STEPS, WORDS = 32, 8 + 4 * 32 * 5            # conv_patch_h2q.hip:kQDbgSteps
     H_, W_ = (int(v) for v in a.hw.split("x"))
     ms = run_conv(a.dump, a.kernel, H=H_, W=W_, cin=a.cin, cout=a.cout)
     raw = np.fromfile(a.dump, dtype=np.uint64)
