@@ -41,7 +41,7 @@ enum pa_op_kind {
     PA_OP_MAXPOOL2 = 5    /* MaxPool2d(2,2) into a buffer one level coarser                      */
 };
 
-enum pa_act { PA_ACT_NONE = 0, PA_ACT_SILU = 1, PA_ACT_RELU = 2, PA_ACT_SIGMOID = 3 };
+enum pa_act { PA_ACT_NONE = 0, PA_ACT_SILU = 1, PA_ACT_RELU = 2, PA_ACT_SIGMOID = 3, PA_ACT_LEAKY = 4 /* nn.LeakyReLU(0.01): InpaintNet, reference trackers/ball_tracker/models.py:83-93 */ };
 
 /* activation buffer: fp32 NHWC, spatial size = network input >> level, `channels` floats per pixel */
 typedef struct pa_buf_desc {

@@ -26,6 +26,7 @@ __device__ __forceinline__ float fast_act(float x) {
     if (ACT == ACT_SILU) return fast_div(x, 1.0f + fast_exp_neg(x));
     if (ACT == ACT_RELU) return x > 0.0f ? x : 0.0f;
     if (ACT == ACT_SIGMOID) return fast_div(1.0f, 1.0f + fast_exp_neg(x));
+    if (ACT == ACT_LEAKY) return x >= 0.0f ? x : 0.01f * x;
     return x;
 }
 

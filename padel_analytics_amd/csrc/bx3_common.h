@@ -85,6 +85,7 @@ __device__ __forceinline__ void bx3_epilogue_case(const ConvArgs& a, const f32x4
                 if (ACT == ACT_SILU) x = x / (1.0f + expf(-x));
                 else if (ACT == ACT_RELU) x = x > 0.0f ? x : 0.0f;
                 else if (ACT == ACT_SIGMOID) x = 1.0f / (1.0f + expf(-x));
+                else if (ACT == ACT_LEAKY) x = x >= 0.0f ? x : 0.01f * x;
                 v[r] = x;
             }
             if (FAST) {
@@ -121,6 +122,7 @@ __device__ __forceinline__ void bx3_epilogue(const ConvArgs& a, const f32x4 (&ac
     if (a.act == ACT_SILU) PADEL_BX3_EPI(ACT_SILU);
     else if (a.act == ACT_RELU) PADEL_BX3_EPI(ACT_RELU);
     else if (a.act == ACT_SIGMOID) PADEL_BX3_EPI(ACT_SIGMOID);
+    else if (a.act == ACT_LEAKY) PADEL_BX3_EPI(ACT_LEAKY);
     else PADEL_BX3_EPI(ACT_NONE);
 #undef PADEL_BX3_EPI
 }

@@ -30,6 +30,7 @@ __device__ __forceinline__ float act_apply2(float v, int act) {
     if (act == ACT_SILU) return v / (1.0f + expf(-v));
     if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
     if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == ACT_LEAKY) return v >= 0.0f ? v : 0.01f * v;
     return v;
 }
 

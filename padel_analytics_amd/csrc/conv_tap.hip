@@ -40,6 +40,7 @@ __device__ __forceinline__ float act_apply5(float v, int act) {
     if (act == ACT_SILU) return v / (1.0f + expf(-v));
     if (act == ACT_RELU) return v > 0.0f ? v : 0.0f;
     if (act == ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == ACT_LEAKY) return v >= 0.0f ? v : 0.01f * v;
     return v;
 }
 
@@ -149,6 +150,7 @@ __device__ __forceinline__ void tap_epilogue_case(const ConvArgs& a, const f32x4
                     if (ACT == ACT_SILU) v = v / (1.0f + expf(-v));
                     else if (ACT == ACT_RELU) v = v > 0.0f ? v : 0.0f;
                     else if (ACT == ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                    else if (ACT == ACT_LEAKY) v = v >= 0.0f ? v : 0.01f * v;
                     if (RES) v += a.res[(long long)m * a.res_cs + a.res_choff + co];
                     a.out[(long long)m * a.out_cs + a.out_choff + co] = v;
                 }
@@ -174,6 +176,7 @@ __device__ __forceinline__ void tap_epilogue(const ConvArgs& a, const f32x4 (&ac
     if (a.act == ACT_SILU) tap_epilogue_act<MF, NF, ACT_SILU>(a, acc, mw, fw, lr, lq, full);
     else if (a.act == ACT_RELU) tap_epilogue_act<MF, NF, ACT_RELU>(a, acc, mw, fw, lr, lq, full);
     else if (a.act == ACT_SIGMOID) tap_epilogue_act<MF, NF, ACT_SIGMOID>(a, acc, mw, fw, lr, lq, full);
+    else if (a.act == ACT_LEAKY) tap_epilogue_act<MF, NF, ACT_LEAKY>(a, acc, mw, fw, lr, lq, full);
     else tap_epilogue_act<MF, NF, ACT_NONE>(a, acc, mw, fw, lr, lq, full);
 }
 

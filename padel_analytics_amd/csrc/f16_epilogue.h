@@ -156,6 +156,7 @@ __device__ __forceinline__ void f16_epilogue(const ConvArgs& a, const f16e_f32x4
     if (a.act == ACT_SILU) PADEL_F16_EPI(ACT_SILU);
     else if (a.act == ACT_RELU) PADEL_F16_EPI(ACT_RELU);
     else if (a.act == ACT_SIGMOID) PADEL_F16_EPI(ACT_SIGMOID);
+    else if (a.act == ACT_LEAKY) PADEL_F16_EPI(ACT_LEAKY);
     else PADEL_F16_EPI(ACT_NONE);
 #undef PADEL_F16_EPI
 }

@@ -234,6 +234,7 @@ __device__ __forceinline__ void h2_epilogue(const ConvArgs& a, const f32x4 (&mai
     if (a.act == ACT_SILU) PADEL_H2_EPI(ACT_SILU);
     else if (a.act == ACT_RELU) PADEL_H2_EPI(ACT_RELU);
     else if (a.act == ACT_SIGMOID) PADEL_H2_EPI(ACT_SIGMOID);
+    else if (a.act == ACT_LEAKY) PADEL_H2_EPI(ACT_LEAKY);
     else PADEL_H2_EPI(ACT_NONE);
 #undef PADEL_H2_EPI
     if (!a.out_f32) h2_raise(a.ovf_flag, bad);

@@ -9,7 +9,7 @@
 
 namespace padel {
 
-enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_LEAKY = 4 };   // LEAKY: nn.LeakyReLU() (slope 0.01): InpaintNet's Conv1DBlock (models.py:83-93)
 
 struct ConvArgs {
     const float* in;      // input buffer base

@@ -115,6 +115,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
     __shared__ uint64_t skeys[NMS_LDS_KEYS];
     __shared__ uint8_t ssupp[NMS_LDS_SUPP];
     __shared__ float4 sbox[NMS_MASK_MAX];      // bit-mask NMS: ranked boxes, class offset applied
+    __shared__ int skeep[300];                 // bit-mask NMS: candidate slots of the kept detections, in rank order (max_det <= 300)
     __shared__ int s_kept, s_done;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -155,19 +156,30 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
         }
     }
     int ne = n < a.max_nms ? n : a.max_nms;
-    for (int i = tid; i < ne; i += NMS_THREADS) { order[i] = (int)(keys[i] & 0xffffu); supp[i] = 0; }
+    // bit-mask path (ne <= NMS_MASK_MAX): the ranked slot ids stay in LDS (in the 16 KB of the flag array, which that path does
+    // not use) and the kept list is collected in LDS too.  Round 3 kept both in HBM: the one-wave scan below then did a global
+    // load -> wait -> global store per KEPT candidate (~2 us each under load): 1.35 ms for the ~280 detections per image of the
+    // bench's pose graph, 64 workgroups on 64 CUs — the scan is the whole kernel
+    const bool lds_path = ne <= NMS_MASK_MAX;
+    int* const sord = reinterpret_cast<int*>(ssupp);
+    static_assert(NMS_LDS_SUPP >= NMS_MASK_MAX * (int)sizeof(int), "ranked slot ids alias the flag array");
+    if (lds_path) {
+        for (int i = tid; i < ne; i += NMS_THREADS) sord[i] = (int)(keys[i] & 0xffffu);
+    } else {
+        for (int i = tid; i < ne; i += NMS_THREADS) { order[i] = (int)(keys[i] & 0xffffu); supp[i] = 0; }
+    }
     __syncthreads();
 
     // greedy suppression in rank order; boxes are offset by cls * 7680 like upstream (agnostic=False)
     int kept = 0;
-    if (ne <= NMS_MASK_MAX) {
+    if (lds_path) {
         // SURVEY K9 — the IoU decisions are computed IN PARALLEL as a bit matrix, only the scan that consumes them is
         // serial (what torchvision's device NMS does).  Rows are produced in blocks that fit the 64 KB the sort keys no
         // longer need: mask[(i - r0) * words + w] bit jj = IoU(rank i, rank w * 64 + jj) > iou, for j > i.  One wave then
         // walks the block: lane l keeps word l of the "removed" set; a kept candidate ORs its row into it.
         const int words = (ne + 63) >> 6;                       // <= 64
         for (int i = tid; i < ne; i += NMS_THREADS) {
-            const float* bi = cand + order[i] * 6;
+            const float* bi = cand + sord[i] * 6;
             const float off = bi[5] * 7680.0f;
             sbox[i] = make_float4(bi[0] + off, bi[1] + off, bi[2] + off, bi[3] + off);
         }
@@ -207,7 +219,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
                     const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), w);
                     const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
                     if ((rw >> (i & 63)) & 1ull) continue;
-                    if (tid == 0) order[k] = order[i];              // compacted list of kept slots (k <= i: consumed already)
+                    if (tid == 0) skeep[k] = sord[i];               // kept slots in rank order (LDS: nothing to wait for)
                     ++k;
                     if (k >= a.max_det) { done = true; break; }
                     if (tid < words) removed |= mask[(i - r0) * words + tid];
@@ -254,7 +266,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
         for (int k = kept * nkv + tid; k < a.max_det * nkv; k += NMS_THREADS) a.out_kpts[(long long)b * a.max_det * nkv + k] = 0.0f;
     // write kept detections in rank order, rescaled to the source frame
     for (int k = tid; k < kept; k += NMS_THREADS) {
-        const int slot = order[k];
+        const int slot = lds_path ? skeep[k] : order[k];
         const float* c = cand + slot * 6;
         float* o = a.out_boxes + ((long long)b * a.max_det + k) * 6;
         float x1 = (c[0] - a.pad_x) / a.gain, y1 = (c[1] - a.pad_y) / a.gain;

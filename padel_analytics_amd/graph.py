@@ -24,7 +24,7 @@ from . import yolo_arch
 
 # mirror of include/padel_hip.h
 OP_STEM, OP_CONV, OP_SPPF_POOL, OP_UPSAMPLE2X, OP_MAXPOOL2 = 1, 2, 3, 4, 5
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_LEAKY = 0, 1, 2, 3, 4
 TASK_DETECT, TASK_POSE, TASK_TRACKNET = 0, 1, 2
 DTYPE_F32, DTYPE_F16, DTYPE_H2 = 0, 1, 2
 
@@ -495,4 +495,46 @@ def build_tracknet(sd, dtype: str = "f32") -> Graph:
            np.asarray(sd["predictor.bias"], np.float32), 1, 1, ACT_SIGMOID)
     g.head_buf = (out, -1, -1)
     g.out_channels = out_dim
+    return g
+
+
+INPAINT_LAYERS = ("down_1", "down_2", "down_3", "buttleneck.conv_1", "buttleneck.conv_2", "up_1", "up_2", "up_3")
+
+
+def build_inpaintnet(sd, dtype: str = "f32") -> Graph:
+    """InpaintNet (reference ``trackers/ball_tracker/models.py:101-130``: Conv1d(k=3, same) + LeakyReLU U-Net over
+    length-L coordinate sequences, sigmoid output) over the engine's op set (round 4).
+
+    A sequence is one image row: NHWC ``(windows, 1, L, C)``.  ``Conv1d(k=3, padding=same)`` along the sequence is a 3x3
+    convolution whose only non-zero kernel row is the middle one (``w2d[:, :, 1, kx] = w1d[:, :, kx]``; the rows above and
+    below the single image row are padding anyway).  ``torch.cat([x, skip], 1)`` (:117-122) are concat buffers written in
+    place by their producers, like everywhere else.  Buffer 0: the fp32 input ``[x, y, mask]`` zero-padded to 16 channels;
+    the head buffer: 2 sigmoid outputs (padded to 4)."""
+    g = Graph(task=TASK_TRACKNET, dtype={"f32": DTYPE_F32, "h2": DTYPE_H2}[dtype])
+    g.in_channels = 16
+
+    def c1d(name, src, dst, act=ACT_LEAKY, out_width=None):
+        w1 = np.asarray(sd[f"{name}.weight"], np.float32)               # (cout, cin, 3)
+        w2 = np.zeros(w1.shape[:2] + (3, 3), np.float32)
+        w2[:, :, 1, :] = w1
+        g.conv(src, dst, w2, np.asarray(sd[f"{name}.bias"], np.float32), 3, 1, act, None, out_width)
+
+    x0 = g.buf(0, 16)
+    cat3 = g.buf(0, 64 + 32)         # [up_2 | x1]
+    cat2 = g.buf(0, 128 + 64)        # [up_1 | x2]
+    cat1 = g.buf(0, 256 + 128)       # [bottleneck | x3]
+    c1d("down_1.conv", (x0, 0, 16), (cat3, 64))
+    c1d("down_2.conv", (cat3, 64, 32), (cat2, 128))
+    c1d("down_3.conv", (cat2, 128, 64), (cat1, 256))
+    t = g.buf(0, 256)
+    c1d("buttleneck.conv_1.conv", (cat1, 256, 128), (t, 0))
+    c1d("buttleneck.conv_2.conv", (t, 0, 256), (cat1, 0))
+    c1d("up_1.conv", (cat1, 0, 384), (cat2, 0))
+    c1d("up_2.conv", (cat2, 0, 192), (cat3, 0))
+    u3 = g.buf(0, 32)
+    c1d("up_3.conv", (cat3, 0, 96), (u3, 0))
+    out = g.buf(0, 4)
+    c1d("predictor", (u3, 0, 32), (out, 0), act=ACT_SIGMOID)
+    g.head_buf = (out, -1, -1)
+    g.out_channels = 2
     return g

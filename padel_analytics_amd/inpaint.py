@@ -1,5 +1,7 @@
-"""InpaintNet trajectory repair on the host (0.52 M parameters over length-16
-coordinate sequences — negligible FLOPs, kept on the CPU in numpy fp32).
+"""InpaintNet trajectory repair (0.52 M parameters over length-16 coordinate sequences).
+The network runs on the device since round 4 (``InpaintNetDevice``: the engine's conv kernels over one-row images); its numpy
+fp32 twin ``InpaintNetHost`` remains for CPU tests; mask generation, windows, blending and the temporal ensemble are host
+bookkeeping in both cases.
 
 Restates, from the reference's ball tracker:
 * ``generate_inpaint_mask`` (``ball_tracker.py:100-136``): runs of invisible frames that are bounded by
@@ -107,6 +109,50 @@ class InpaintNetHost:
         x = self._conv(x, "predictor", act=False)
         x = (1.0 / (1.0 + np.exp(-x.astype(np.float32)))).astype(np.float32)
         return x.transpose(0, 2, 1)
+
+
+class InpaintNetDevice:
+    """The same forward on the HIP engine: ``graph.build_inpaintnet`` — eight Conv1d + LeakyReLU
+    layers and the sigmoid predictor as 3x3 convolutions over one-row images, in the engine's fp32-equivalent arithmetic.
+    Same ``forward(coor, mask)`` contract as ``InpaintNetHost`` (which stays as its CPU twin for the tests); windows are
+    processed ``max_windows`` at a time."""
+
+    def __init__(self, state_dict, engine=None, max_windows: int = 4096):
+        from . import engine as E, graph as G
+        self._E, self._G = E, G
+        self.sd = {k: np.asarray(v, np.float32) for k, v in state_dict.items()}
+        self.engine = engine
+        self.max_windows = int(max_windows)
+        self.mode = E.fp32_mode()
+        self._model = None
+
+    def _ensure(self):
+        if self._model is None:
+            E, G = self._E, self._G
+            self._model = E.Model(self.engine or E.default_engine(), G.build_inpaintnet(self.sd, dtype=E.graph_dtype(self.mode)))
+            self._model.set_max_batch(self.max_windows)
+        return self._model
+
+    def forward(self, coor: np.ndarray, mask: np.ndarray) -> np.ndarray:
+        n, L = coor.shape[:2]
+        x = np.zeros((n, 1, L, 16), np.float32)
+        x[:, 0, :, :2] = coor
+        x[:, 0, :, 2] = mask[..., 0]
+        out = np.empty((n, L, 2), np.float32)
+        for lo in range(0, n, self.max_windows):
+            m = self._ensure()
+            y = m.tracknet_infer(x[lo:lo + self.max_windows])
+            if self.mode == "h2" and m.take_overflow():          # cannot happen on normalised coordinates; kept for symmetry
+                self.close()
+                self.mode = "bx3"
+                y = self._ensure().tracknet_infer(x[lo:lo + self.max_windows])
+            out[lo:lo + self.max_windows] = y[:, 0, :, :2]
+        return out
+
+    def close(self) -> None:
+        if self._model is not None:
+            self._model.close()
+            self._model = None
 
 
 def inpaint_trajectory(xs, ys, vs, img_w: int, img_h: int, net: InpaintNetHost, seq_len: int,

@@ -89,7 +89,9 @@ class BallTracker(Tracker):
             if ick.task != "inpaintnet":
                 raise ValueError(f"{inpainting_model_path}: not an InpaintNet checkpoint")
             self.inpaintnet_seq_len = int(ick.param_dict.get("seq_len", 16))
-            self.inpaintnet = inpaint.InpaintNetHost(ick.state_dict)
+            self.inpaintnet = inpaint.InpaintNetHost(ick.state_dict)     # CPU twin (tests; boxes without a GPU cannot get here)
+            self._inpaint_sd = ick.state_dict
+        self._inpaint_dev = None                                         # the device network (round 4), created on first use
         self.batch_size = batch_size
         self.median_max_sample_num = median_max_sample_num
         self.median = median
@@ -126,9 +128,20 @@ class BallTracker(Tracker):
             if self._model is None:
                 self._model = E.Model(self._engine or E.default_engine(), self.graph)
                 self._model.set_max_batch(max(1, self.batch_size))
-        elif self._model is not None:
-            self._model.close()
-            self._model = None
+        else:
+            if self._model is not None:
+                self._model.close()
+                self._model = None
+            if self._inpaint_dev is not None:
+                self._inpaint_dev.close()
+
+    def _inpaint_net(self):
+        """InpaintNet on the HIP engine when there is one (K12), else its numpy twin (CPU-only test boxes)."""
+        if self.DEVICE != "cuda":
+            return self.inpaintnet
+        if self._inpaint_dev is None:
+            self._inpaint_dev = inpaint.InpaintNetDevice(self._inpaint_sd, self._engine)
+        return self._inpaint_dev
 
     def predict_sample(self, sample: Iterable[np.ndarray], **kwargs):
         raise NoPredictSample()
@@ -239,7 +252,7 @@ class BallTracker(Tracker):
         xs, ys, vs = [p[0] for p in have], [p[1] for p in have], [p[2] for p in have]
         if self.inpaintnet is not None and len(xs) == n_total and n_total:
             h0, w0 = self._frame_hw()
-            fixed = inpaint.inpaint_trajectory(xs, ys, vs, w0, h0, self.inpaintnet, self.inpaintnet_seq_len,
+            fixed = inpaint.inpaint_trajectory(xs, ys, vs, w0, h0, self._inpaint_net(), self.inpaintnet_seq_len,
                                                self.WIDTH, self.HEIGHT)
             if fixed and fixed[0] is not None:
                 xs, ys, vs = [f[0] for f in fixed], [f[1] for f in fixed], [f[2] for f in fixed]

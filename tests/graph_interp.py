@@ -60,6 +60,8 @@ def act(x, a):
         return F.relu(x)
     if a == G.ACT_SIGMOID:
         return torch.sigmoid(x)
+    if a == G.ACT_LEAKY:
+        return F.leaky_relu(x, 0.01)
     return x
 
 

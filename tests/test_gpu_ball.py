@@ -175,3 +175,41 @@ def test_ball_tracker_plugin(gpu_engine, tmp_path):
         assert abs(got[g][0] - want[g][0]) <= 1 and abs(got[g][1] - want[g][1]) <= 1 and got[g][2] == want[g][2], (g, got[g], want[g])
     assert exact >= T - 2
     t2.to("cpu")
+
+
+@pytest.mark.parametrize("mode", ["h2", "bx3"])
+def test_inpaintnet_on_device_matches_the_numpy_twin_and_the_oracle(gpu_engine, mode):
+    """K12 on the device (round 4): graph.build_inpaintnet — Conv1d(k=3) + LeakyReLU layers as 3x3 convolutions over
+    one-row images — against the numpy twin (padel_analytics_amd/inpaint.py:InpaintNetHost) and the torch oracle
+    (oracle/tracknet_ref.py:InpaintNetRef, pinned to golden outputs of the reference's models.py): sigmoid outputs within
+    2e-6; the repaired trajectory of a 200-frame clip (ints, in pixels) identical."""
+    import torch
+    from padel_analytics_amd import inpaint as ip
+    sd = tr.synth_inpaintnet_state_dict(4)
+    rng = np.random.default_rng(3)
+    S, L = 300, 16
+    coor = rng.uniform(0, 1, (S, L, 2)).astype(np.float32)
+    mask = (rng.uniform(size=(S, L, 1)) > 0.7).astype(np.float32)
+    coor[mask[..., 0] > 0] = 0.0
+    host = ip.InpaintNetHost(sd)
+    dev = ip.InpaintNetDevice(sd, gpu_engine, max_windows=128)           # 300 windows in three passes
+    dev.mode = mode
+    got = dev.forward(coor, mask)
+    want = host.forward(coor, mask)
+    ref = tr.InpaintNetRef(sd).forward(torch.from_numpy(coor), torch.from_numpy(mask)).numpy()
+    assert got.shape == want.shape == (S, L, 2)
+    assert np.abs(want - ref).max() < 2e-6
+    assert np.abs(got - ref).max() < 2e-6, np.abs(got - ref).max()
+    # through the whole repair: same integers as the host network
+    T = 200
+    xs = (640 + 300 * np.sin(np.arange(T) / 9.0)).astype(int).tolist()
+    ys = (360 + 200 * np.cos(np.arange(T) / 7.0)).astype(int).tolist()
+    vs = [1] * T
+    for a, b in ((20, 26), (70, 73), (120, 131)):
+        for i in range(a, b):
+            xs[i], ys[i], vs[i] = 0, 0, 0
+    r_dev = ip.inpaint_trajectory(xs, ys, vs, 1280, 720, dev, L)
+    r_host = ip.inpaint_trajectory(xs, ys, vs, 1280, 720, host, L)
+    assert r_dev == r_host
+    assert any(r_host[i][2] == 1 for i in range(20, 26)), "the masked gap is repaired"
+    dev.close()

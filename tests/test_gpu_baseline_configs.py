@@ -102,7 +102,9 @@ def test_config4_1080p_fp16_all_trackers_through_the_runner(gpu_engine, tmp_path
     # not the fp32 path's 1e-3 px, and it is asserted at measured + margin (round 3 asserted "< 8 px")
     report = {"frames": B, "tracked_players": n_players, "pose_detections": n_pose, "low_noise_heads": {}}
     # per tracker: bound on the geometric mean of the RMS error over the seeds, bound on the worst L-inf of any seed
-    BOUNDS = {"players": (0.35, 5.0), "ball": (0.12, 1.2), "pose": (0.08, 1.5)}
+    # measured (gpurun r4d, three seeds): geomean RMS 0.114 / 0.054 / 0.028 px, worst L-inf 1.57 / 0.42 / 1.06 px (round 3 saw up to
+    # 4 px on one draw of the players checkpoint: the maximum of a heavy-tailed sample gets the wider margin)
+    BOUNDS = {"players": (0.25, 4.0), "ball": (0.12, 1.0), "pose": (0.07, 2.5)}
     for name in ("players", "ball", "pose"):
         cfg = bench.TRACKERS[name]
         f = 0.004 if cfg["imgsz"] > 640 else 0.02

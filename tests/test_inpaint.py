@@ -57,3 +57,29 @@ def test_trajectory_repair_matches_streaming_transcription(T, batch):
         if not near:
             assert got[g] == want[g], (g, got[g], want[g], raw[g])
     assert n_masked >= 0
+
+
+def test_inpaintnet_device_graph_host_logic():
+    """graph.build_inpaintnet (the device form of InpaintNet, round 4) interpreted on the CPU (tests/graph_interp.py unpacks
+    the weight blob the way the kernels index it): Conv1d(k=3) as the middle row of a 3x3 over one-row images, concats as
+    channel slices, LeakyReLU / sigmoid op codes — against the torch oracle, for fp32 and h2 storage; stale buffer contents
+    (pad channels, never-written slices) must not reach the output."""
+    import torch
+    from oracle import tracknet_ref as tr
+    from padel_analytics_amd import graph as G
+    from tests import graph_interp
+    sd = tr.synth_inpaintnet_state_dict(4)
+    rng = np.random.default_rng(1)
+    S, L = 9, 16
+    coor = rng.uniform(0, 1, (S, L, 2)).astype(np.float32)
+    mask = (rng.uniform(size=(S, L, 1)) > 0.6).astype(np.float32)
+    want = tr.InpaintNetRef(sd).forward(torch.from_numpy(coor), torch.from_numpy(mask)).numpy()        # (S, L, 2)
+    x = np.zeros((S, 16, 1, L), np.float32)                                                            # NCHW of (S, 1, L, 16)
+    x[:, 0, 0], x[:, 1, 0], x[:, 2, 0] = coor[..., 0], coor[..., 1], mask[..., 0]
+    for dtype, tol in (("f32", 2e-6), ("h2", 5e-6)):
+        g = G.build_inpaintnet(sd, dtype=dtype)
+        assert len(g.ops) == 9 and [o["act"] for o in g.ops] == [G.ACT_LEAKY] * 8 + [G.ACT_SIGMOID]
+        for stale in (0.0, 1000.0):
+            bufs = graph_interp.run(g, buf0=torch.from_numpy(x), stale=stale)
+            got = bufs[g.head_buf[0]][:, :2, 0].numpy().transpose(0, 2, 1)
+            assert np.abs(got - want).max() < tol, (dtype, stale, np.abs(got - want).max())

@@ -10,6 +10,9 @@
 #   ubench        tools/mfma_f16_ubench (16x16x32 and 32x32x16 f16 MFMA ceilings)
 #   sweep         tools/conv_bench.py --dtype h2 for every library under tools/ab/ and the product library
 #   timeline      tools/timeline_probe.py --kernel h2q with tools/ab/libpadel_hip_probes.so (192->192 and 96->96)
+#   tiles         tools/conv_bench.py --dtype h2 --tiles $TILES (default auto,T323,T303) on $SWEEP_ARGS shapes
+#   tests_post    ball / known-answer (decode, NMS) / runner / bench-config suites
+#   bench_driver  the driver's command line: python bench.py --gpus 1 --steps 20 --warmup 5
 #   tests_f16     the fp16 kernel tests + BASELINE configs[0] / [3] / [4] tests
 #   replay        engine-only c3 with 16 / 32 frames per pass over the op list (MALL residency experiment)
 #   bench         python bench.py --dump-ops (default command line: c3)
@@ -60,6 +63,15 @@ for stage in "$@"; do
     bench_c4)
       timeout 900 python bench.py --workload c4 --dump-ops "$OUT/ops_c4.csv" > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; note $stage $?
       python tools/bench_summary.py "$OUT/bench_c4.json" ;;
+    tiles)
+      timeout 600 python tools/conv_bench.py --dtype h2 --tiles ${TILES:-auto,T323,T303} --reps 7 ${SWEEP_ARGS:-} > "$OUT/tiles.txt" 2>&1; note $stage $?
+      grep -v 'amdgpu.ids' "$OUT/tiles.txt" | head -30 ;;
+    tests_post)
+      timeout 900 python -m pytest tests/test_gpu_ball.py tests/test_gpu_known_answers.py tests/test_gpu_runner.py tests/test_gpu_bench_config.py -m gpu -q -x > "$OUT/pytest_post.txt" 2>&1; note $stage $?
+      tail -5 "$OUT/pytest_post.txt" ;;
+    bench_driver)
+      timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_c3_driver_cmdline.json" 2> "$OUT/bench_c3_driver_cmdline.err"; note $stage $?
+      python tools/bench_summary.py "$OUT/bench_c3_driver_cmdline.json" ;;
     tests_f16)
       timeout 900 python -m pytest tests/test_gpu_fp16.py tests/test_gpu_baseline_configs.py -m gpu -q -x > "$OUT/pytest_f16.txt" 2>&1; note $stage $?
       tail -5 "$OUT/pytest_f16.txt"; cp gpurun_out/config4_report.json "$OUT/" 2>/dev/null ;;
@@ -69,7 +81,7 @@ for stage in "$@"; do
         python -c "import json;d=json.load(open('$OUT/bench_replay$n.json'));print('replay $n', d['value'], d['ms_per_step'])"
       done ;;
     stats)
-      ( cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats -d "$GRAFT_REPO_ROOT/$OUT/rocprof" -o c3 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --quick > "$GRAFT_REPO_ROOT/$OUT/rocprof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/rocprof_bench.err" ); note $stage $?
+      ( cd /tmp && export TMPDIR=/tmp && timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/rocprof" -o c3 -- python "$GRAFT_REPO_ROOT/bench.py" --steps 5 --warmup 2 --quick > "$GRAFT_REPO_ROOT/$OUT/rocprof_bench.json" 2> "$GRAFT_REPO_ROOT/$OUT/rocprof_bench.err" ); note $stage $?
       find "$OUT/rocprof" -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} "$OUT/c3_kernel_stats.csv"
       find "$OUT/rocprof" -type f ! -name '*kernel_stats.csv' -delete 2>/dev/null
       head -12 "$OUT/c3_kernel_stats.csv" ;;
