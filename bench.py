@@ -42,7 +42,8 @@ PEAK_FP16_MFMA_TFLOPS = 2500.0     # same guide: BF16/FP16 MFMA, dense (not the 
 PEAK_BX3_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 6.0, 1)
 # h2 path (default since round 3): activations as fp16 pairs, every fp32 multiply costs 3 f16 products on the same pipe
 PEAK_H2_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 3.0, 1)
-SUSTAINED_FP16_MFMA_TFLOPS = 1750.0     # measured, profiles/r3n_mfma_f16_ubench.txt (reported beside the nominal peak, never instead of it)
+SUSTAINED_FP16_MFMA_TFLOPS = 1780.0     # measured on random operands, 16x16x32 AND 32x32x16 f16 (profiles/r4a_mfma_f16_ubench.txt: 1.71-1.85 PFLOP/s;
+                                        # all-zero operands reach 2.2-2.5): reported beside the nominal peak, never instead of it
 PEAK_BY_IMPL = {"h2": PEAK_H2_TFLOPS, "bx3": PEAK_BX3_TFLOPS, "tap": PEAK_FP32_MFMA_TFLOPS, "lds": PEAK_FP32_MFMA_TFLOPS}
 
 # tracker table: name -> (scale, nc, kpt_shape, imgsz, conf, classes, pre_mode, channel_reverse)
@@ -708,11 +709,11 @@ def main():
                           "peak this replaces is 157.3" if (a.dtype == "f32" and a.impl == "bx3") else None),
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
             "frac": round(ach / PEAK, 4), "traffic": traffic if a.dtype == "f32" else None,
-            # what a kernel of nothing but v_mfma_f32_16x16x32_f16 sustains on this chip with random operands (clock under
-            # matrix load; 2.2 PFLOP/s with all-zero operands, 2.5 nominal): tools/mfma_f16_ubench.hip, static like `traffic`
+            # what a kernel of nothing but v_mfma_f32_16x16x32_f16 (or 32x32x16) sustains on this chip with random operands (clock
+            # under matrix load; 2.2-2.5 PFLOP/s with all-zero operands, 2.5 nominal): tools/mfma_f16_ubench.hip, a static figure
             "sustained_mfma_peak": ({"value": round(SUSTAINED_FP16_MFMA_TFLOPS / (3.0 if a.dtype == "f32" else 1.0), 1), "unit": "TFLOP/s",
                                      "frac": round(ach / (SUSTAINED_FP16_MFMA_TFLOPS / (3.0 if a.dtype == "f32" else 1.0)), 4), "static": True,
-                                     "source": "profiles/r3n_mfma_f16_ubench.txt: 1.70-1.80 PFLOP/s at 2-3 waves per SIMD"}
+                                     "source": "profiles/r4a_mfma_f16_ubench.txt: 1.71-1.85 PFLOP/s on random operands at 2-3 waves per SIMD, v_mfma_f32_16x16x32_f16 and 32x32x16 alike"}
                                     if (a.dtype == "f16" or a.impl == "h2") else None),
             "launches": len(c3), "avg_launch_ms": round(ms3 / max(len(c3), 1), 4),
             "flops_per_step": fl3, "kernel_ms_per_step": round(ms3, 3),
@@ -737,7 +738,8 @@ def main():
         # batch-2 graphs (measured: 256 threads -> 90 s/frame)
         ncores = min(os.cpu_count() or 1, 64)
         torch.set_num_threads(ncores)
-        ns = a.cpu_sample or 2
+        ns = 2                                      # parity sample (fp32 and fp64 oracle)
+        nt = max(ns, (a.cpu_sample or 8) // ns * ns)      # timed sample of the CPU baseline
         sample = frames[:ns]
         tcpu = 0.0
         if a.dtype != "f32":
@@ -758,6 +760,13 @@ def main():
             # host-side processor (BGR2RGB / PIL resize) + predict, like predict_sample() times it
             r32 = ref.predict(model, source_for_oracle(cfg, sample), cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
             tcpu += time.perf_counter() - t1
+            # the TIMED sample is larger than the parity sample (2 frames are a tiny baseline): nt frames in passes
+            # of ns, ~10-20 s of CPU work on the box's EPYC for c3; the parity statements stay on the first ns frames (their
+            # fp64 evaluation is 3-4 x slower)
+            for lo in range(ns, nt, ns):
+                t1 = time.perf_counter()
+                ref.predict(model, source_for_oracle(cfg, frames[lo:lo + ns]), cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
+                tcpu += time.perf_counter() - t1
             # engine results on the same frames (B = 64 pass; bitwise equal to any other batch size —
             # tests/test_gpu_bench_config.py::test_batch_invariance)
             boxes, kpts, counts = trackers[name].model._ensure_model().yolo_infer(
@@ -820,8 +829,8 @@ def main():
         if a.dtype == "f32" and not a.no_fp64 and not a.no_tight:
             par["low_noise_heads"] = parity_low_noise_heads(eng, names, frames, sample, H, W, ref, parity)
         out["parity"] = par
-        out["cpu_baseline"] = {"value": round(ns / tcpu, 3), "unit": "frames/s", "cores": ncores, "kind": "port",
-                               "sample": f"{ns} frames of the same workload through the torch-CPU fp32 oracle "
+        out["cpu_baseline"] = {"value": round(nt / tcpu, 3), "unit": "frames/s", "cores": ncores, "kind": "port", "seconds": round(tcpu, 2),
+                               "sample": f"{nt} frames of the same workload ({tcpu:.1f} s of CPU work) through the torch-CPU fp32 oracle "
                                          f"(oracle/yolov8_ref.py), all {len(names)} trackers, torch threads={ncores}"}
 
     if a.dtype == "f32" and a.impl == "h2" and not a.no_compare and world == 1:

@@ -17,7 +17,8 @@ for f in conv_lds.hip conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx
 done
 hipcc $FLAGS -x hip -c engine.cpp -o "$BUILD/engine.o" &
 pids+=($!)
-g++ -O2 -std=c++17 -fPIC -Wall -c bytetrack.cpp -o "$BUILD/bytetrack.o" &
+# host code; -ffp-contract=off: the tracker's doubles are pinned against the Python twin (no fused multiply-adds)
+g++ -O3 -ffp-contract=off -std=c++17 -fPIC -Wall -c bytetrack.cpp -o "$BUILD/bytetrack.o" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$BUILD"/*.o -Wl,-rpath,/opt/rocm/lib

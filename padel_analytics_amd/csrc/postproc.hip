@@ -107,27 +107,50 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------- NMS
 #define NMS_THREADS 1024
-#define NMS_LDS_KEYS 8192          // bitonic sort in LDS up to this many candidates per image (64 KB), in HBM beyond
-#define NMS_LDS_SUPP 16384          // suppression flags of up to this many ranked candidates live in LDS
-#define NMS_MASK_MAX 4096           // ranked candidates the bit-mask NMS handles (one u64 word of flags per lane of a wave)
+#define NMS_WAVES (NMS_THREADS / 64)
+#define NMS_LDS_KEYS 16384         // bitonic sort in LDS up to this many candidates per image (128 KB), in HBM beyond; the same LDS
+                                   // holds the ranked boxes of a chunk afterwards
+#define NMS_CHUNK 4096             // ranked candidates staged in LDS at a time (boxes 64 KB + areas 16 KB + slot ids 16 KB)
+
+// `IoU(bi, bj) > iou` exactly as torchvision decides it — inter / union > iou in fp32 — with the IEEE division (a dozen
+// instructions) only where it can matter: disjoint boxes (inter == 0: 0 / u = 0, or 0 / 0 = NaN, never > iou) skip everything;
+// otherwise inter is compared with iou x union widened / narrowed by 1e-6 relative — four orders above the roundings involved
+// (2^-24 for the product, 2^-24 for the quotient): beyond that band the quotient's comparison is decided, inside it the division
+// decides.  iarea / jarea: (x2 - x1) * (y2 - y1) of the two boxes.
+__device__ __forceinline__ bool nms_over(const float4 bi, const float iarea, const float4 bj, const float jarea, const float iou) {
+    const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
+    const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
+    const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
+    const float inter = ww * hh;
+    if (!(inter > 0.0f)) return false;
+    const float uni = iarea + jarea - inter;
+    const float t = iou * uni;
+    if (inter > t * 1.000001f) return true;
+    if (inter < t * 0.999999f) return false;
+    return inter / uni > iou;
+}
 
 __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
+    // Sort phase: up to 16 384 keys in LDS.  NMS phase: the same 128 KB hold the ranked boxes, areas and slot ids of a chunk.
     __shared__ uint64_t skeys[NMS_LDS_KEYS];
-    __shared__ uint8_t ssupp[NMS_LDS_SUPP];
-    __shared__ float4 sbox[NMS_MASK_MAX];      // bit-mask NMS: ranked boxes, class offset applied
-    __shared__ int skeep[300];                 // bit-mask NMS: candidate slots of the kept detections, in rank order (max_det <= 300)
+    float4* const sbox = reinterpret_cast<float4*>(skeys);                              // [NMS_CHUNK] class offset applied
+    float* const sarea = reinterpret_cast<float*>(skeys + NMS_CHUNK * 2);               // [NMS_CHUNK]
+    int* const sord = reinterpret_cast<int*>(skeys + NMS_CHUNK * 2 + NMS_CHUNK / 2);    // [NMS_CHUNK] candidate slot of each rank
+    static_assert(NMS_CHUNK * (16 + 4 + 4) <= NMS_LDS_KEYS * 8, "chunk staging fits the sort buffer");
+    __shared__ int skeep[300];                 // candidate slots of the kept detections, in rank order (max_det <= 300)
+    __shared__ float4 kbox[300];               // their boxes (class offset applied) and areas: what later candidates are tested against
+    __shared__ float karea[300];
+    __shared__ unsigned long long smask[64];   // word of 64 ranks: bit j of smask[i] = IoU(rank i, rank j) > iou, j > i
+    __shared__ unsigned long long s_sup;       // word of 64 ranks: suppressed by a box kept before the word
     __shared__ int s_kept, s_done;
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     int n = a.cand_cnt[b];
     if (n > a.A) n = a.A;
     const float* cand = a.cand + (long long)b * a.A * 6;
     const int32_t* cidx = a.cand_idx + (long long)b * a.A;
     int32_t* order = a.order + (long long)b * a.A;
-    // the greedy loop below reads one flag per ranked candidate, serially: from LDS that is ~100 cycles per candidate
-    // instead of an L2 round trip per candidate — the global array only backs very long lists
-    const int ne0 = min(n < a.A ? n : a.A, a.max_nms);
-    uint8_t* supp = ne0 <= NMS_LDS_SUPP ? ssupp : a.supp + (long long)b * a.A;
 
     int p2 = 1;
     while (p2 < n) p2 <<= 1;
@@ -156,106 +179,78 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
         }
     }
     int ne = n < a.max_nms ? n : a.max_nms;
-    // bit-mask path (ne <= NMS_MASK_MAX): the ranked slot ids stay in LDS (in the 16 KB of the flag array, which that path does
-    // not use) and the kept list is collected in LDS too.  Round 3 kept both in HBM: the one-wave scan below then did a global
-    // load -> wait -> global store per KEPT candidate (~2 us each under load): 1.35 ms for the ~280 detections per image of the
-    // bench's pose graph, 64 workgroups on 64 CUs — the scan is the whole kernel
-    const bool lds_path = ne <= NMS_MASK_MAX;
-    int* const sord = reinterpret_cast<int*>(ssupp);
-    static_assert(NMS_LDS_SUPP >= NMS_MASK_MAX * (int)sizeof(int), "ranked slot ids alias the flag array");
-    if (lds_path) {
-        for (int i = tid; i < ne; i += NMS_THREADS) sord[i] = (int)(keys[i] & 0xffffu);
-    } else {
-        for (int i = tid; i < ne; i += NMS_THREADS) { order[i] = (int)(keys[i] & 0xffffu); supp[i] = 0; }
-    }
+    // ranked slot ids to HBM once (parallel): the LDS that held the keys is the staging area of the chunks below
+    for (int i = tid; i < ne; i += NMS_THREADS) order[i] = (int)(keys[i] & 0xffffu);
+    if (tid == 0) { s_kept = 0; s_done = 0; s_sup = 0ull; }
     __syncthreads();
 
-    // greedy suppression in rank order; boxes are offset by cls * 7680 like upstream (agnostic=False)
-    int kept = 0;
-    if (lds_path) {
-        // SURVEY K9 — the IoU decisions are computed IN PARALLEL as a bit matrix, only the scan that consumes them is
-        // serial (what torchvision's device NMS does).  Rows are produced in blocks that fit the 64 KB the sort keys no
-        // longer need: mask[(i - r0) * words + w] bit jj = IoU(rank i, rank w * 64 + jj) > iou, for j > i.  One wave then
-        // walks the block: lane l keeps word l of the "removed" set; a kept candidate ORs its row into it.
-        const int words = (ne + 63) >> 6;                       // <= 64
-        for (int i = tid; i < ne; i += NMS_THREADS) {
-            const float* bi = cand + sord[i] * 6;
+    // Greedy suppression in rank order; boxes are offset by cls * 7680 like upstream (agnostic=False).  A candidate survives
+    // iff no box KEPT before it overlaps it by more than iou (torchvision's definition), so only pairs (kept box, candidate)
+    // matter: at most max_det x n of them, against the n^2 / 2 of the full IoU matrix rounds 2-4 built — with the
+    // bench's 1 700 - 5 000 candidates per pose frame the matrix was 1.1 ms on the one CU an image has
+    // (profiles/r4j_pmc_nms.txt).  The ranking is consumed a WORD of 64 candidates at a time (one per lane):
+    //   1. every wave tests the word against a 16th of the boxes kept so far (leaving as soon as all 64 are suppressed) and
+    //      computes four rows of the word's own 64 x 64 triangle by ballot;
+    //   2. wave 0 walks the survivors serially (ctz over the not-removed bits), appending to the kept list.
+    // The loop ends when max_det are kept (upstream slices the kept list to max_det: the same set).
+    for (int c0 = 0; c0 < ne && !s_done; c0 += NMS_CHUNK) {
+        const int nc = min(NMS_CHUNK, ne - c0);
+        __syncthreads();                                      // the previous chunk's boxes are not read any more
+        for (int i = tid; i < nc; i += NMS_THREADS) {
+            const int slot = order[c0 + i];
+            sord[i] = slot;
+            const float* bi = cand + slot * 6;
             const float off = bi[5] * 7680.0f;
-            sbox[i] = make_float4(bi[0] + off, bi[1] + off, bi[2] + off, bi[3] + off);
+            const float4 bx = make_float4(bi[0] + off, bi[1] + off, bi[2] + off, bi[3] + off);
+            sbox[i] = bx;
+            sarea[i] = (bx.z - bx.x) * (bx.w - bx.y);
         }
-        if (tid == 0) { s_kept = 0; s_done = 0; }
         __syncthreads();
-        uint64_t* mask = skeys;
-        const int rows_per_block = words > 0 ? NMS_LDS_KEYS / words : 1;
-        unsigned long long removed = 0ull;                       // wave 0, lane l: flags of ranks 64 l .. 64 l + 63
-        for (int r0 = 0; r0 < ne; r0 += rows_per_block) {
-            const int r1 = min(ne, r0 + rows_per_block);
-            for (int idx = tid; idx < (r1 - r0) * words; idx += NMS_THREADS) {
-                const int i = r0 + idx / words, w = idx - (idx / words) * words;
+        for (int w0 = 0; w0 < nc; w0 += 64) {
+            const int j = w0 + lane;
+            const bool valid = j < nc;
+            const float4 bj = sbox[valid ? j : w0];
+            const float ja = sarea[valid ? j : w0];
+            const unsigned long long vmask = __ballot(valid);
+            // 1a. against the boxes kept before this word
+            const int K = s_kept;
+            bool sup = false;
+            for (int k = wave; k < K; k += NMS_WAVES) {
+                sup = sup || nms_over(kbox[k], karea[k], bj, ja, a.iou);
+                if ((__ballot(sup) & vmask) == vmask) break;
+            }
+            const unsigned long long sw = __ballot(sup);
+            if (lane == 0 && sw) atomicOr(&s_sup, sw);
+            // 1b. the word's own triangle: rows 4 wave .. 4 wave + 3
+#pragma unroll
+            for (int r = 0; r < 64 / NMS_WAVES; ++r) {
+                const int il = wave * (64 / NMS_WAVES) + r, i = w0 + il;
                 unsigned long long bits = 0ull;
-                if (w * 64 + 63 > i) {
-                    const float4 bi = sbox[i];
-                    const float iarea = (bi.z - bi.x) * (bi.w - bi.y);
-                    const int j0 = max(w * 64, i + 1), j1 = min(ne, w * 64 + 64);
-                    for (int j = j0; j < j1; ++j) {
-                        const float4 bj = sbox[j];
-                        const float xx1 = fmaxf(bi.x, bj.x), yy1 = fmaxf(bi.y, bj.y);
-                        const float xx2 = fminf(bi.z, bj.z), yy2 = fminf(bi.w, bj.w);
-                        const float ww = fmaxf(0.0f, xx2 - xx1), hh = fmaxf(0.0f, yy2 - yy1);
-                        const float inter = ww * hh;
-                        const float ovr = inter / (iarea + (bj.z - bj.x) * (bj.w - bj.y) - inter);
-                        if (ovr > a.iou) bits |= 1ull << (j & 63);
-                    }
-                }
-                mask[idx] = bits;
+                if (i < nc) bits = __ballot(valid && lane > il && nms_over(sbox[i], sarea[i], bj, ja, a.iou));
+                if (lane == 0) smask[il] = bits;
             }
             __syncthreads();
-            if (tid < 64) {
-                int k = s_kept;
+            // 2. serial walk over the survivors of the word
+            if (wave == 0) {
+                unsigned long long rem = s_sup | ~vmask;
+                int k = K;
                 bool done = false;
-                for (int i = r0; i < r1; ++i) {
-                    const int w = i >> 6;
-                    const unsigned lo = __builtin_amdgcn_readlane((unsigned)removed, w);
-                    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(removed >> 32), w);
-                    const unsigned long long rw = ((unsigned long long)hi << 32) | lo;
-                    if ((rw >> (i & 63)) & 1ull) continue;
-                    if (tid == 0) skeep[k] = sord[i];               // kept slots in rank order (LDS: nothing to wait for)
+                unsigned long long cur = ~rem;
+                while (cur) {
+                    const int il = __builtin_ctzll(cur);
+                    if (lane == 0) { skeep[k] = sord[w0 + il]; kbox[k] = sbox[w0 + il]; karea[k] = sarea[w0 + il]; }
                     ++k;
                     if (k >= a.max_det) { done = true; break; }
-                    if (tid < words) removed |= mask[(i - r0) * words + tid];
+                    rem |= smask[il];
+                    cur = il == 63 ? 0ull : (~rem & (~0ull << (il + 1)));
                 }
-                if (tid == 0) { s_kept = k; s_done = done ? 1 : 0; }
+                if (lane == 0) { s_kept = k; s_done = done ? 1 : 0; s_sup = 0ull; }
             }
             __syncthreads();
             if (s_done) break;
         }
-        kept = s_kept;
-    } else {
-    for (int i = 0; i < ne; ++i) {
-        if (supp[i]) continue;                       // uniform: every thread reads the same byte
-        const int slot_i = order[i];
-        if (tid == 0) order[kept] = slot_i;          // compacted list of kept slots (kept <= i: consumed already)
-        ++kept;
-        if (kept >= a.max_det) break;
-        const float* bi = cand + slot_i * 6;
-        const float off_i = bi[5] * 7680.0f;
-        const float ix1 = bi[0] + off_i, iy1 = bi[1] + off_i, ix2 = bi[2] + off_i, iy2 = bi[3] + off_i;
-        const float iarea = (ix2 - ix1) * (iy2 - iy1);
-        for (int j = i + 1 + tid; j < ne; j += NMS_THREADS) {
-            if (supp[j]) continue;
-            const float* bj = cand + order[j] * 6;
-            const float off_j = bj[5] * 7680.0f;
-            const float jx1 = bj[0] + off_j, jy1 = bj[1] + off_j, jx2 = bj[2] + off_j, jy2 = bj[3] + off_j;
-            const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
-            const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
-            const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
-            const float inter = w * h;
-            const float ovr = inter / (iarea + (jx2 - jx1) * (jy2 - jy1) - inter);
-            if (ovr > a.iou) supp[j] = 1;
-        }
-        __syncthreads();
     }
-    }
+    const int kept = s_kept;
     __syncthreads();
     if (tid == 0) a.out_cnt[b] = kept;
 
@@ -266,7 +261,7 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
         for (int k = kept * nkv + tid; k < a.max_det * nkv; k += NMS_THREADS) a.out_kpts[(long long)b * a.max_det * nkv + k] = 0.0f;
     // write kept detections in rank order, rescaled to the source frame
     for (int k = tid; k < kept; k += NMS_THREADS) {
-        const int slot = lds_path ? skeep[k] : order[k];
+        const int slot = skeep[k];
         const float* c = cand + slot * 6;
         float* o = a.out_boxes + ((long long)b * a.max_det + k) * 6;
         float x1 = (c[0] - a.pad_x) / a.gain, y1 = (c[1] - a.pad_y) / a.gain;

@@ -128,3 +128,49 @@ def test_native_equals_python_on_a_dense_random_stream():
         want = {tuple(boxes[f, i, :4].tolist()): int(ids_native[f, i]) for i in sel if ids_native[f, i] >= 0}
         have = {tuple(b.tolist()): int(t) for b, t in zip(got.xyxy, got.tracker_id)}
         assert have == want, f"frame {f}"
+
+
+@pytest.mark.parametrize("mode", ["grid", "crowd", "duplicates", "gaps"])
+def test_native_equals_python_on_ties_crowds_and_duplicates(mode):
+    """Round 4 reorganised the native solver (first pass folded into the setup, visited lists, a separate pass for the pick
+    under scipy's tie rule) and the cost builders: streams built to hit TIES — boxes on a grid (identical IoUs), scores
+    rounded to quarters, exact duplicates of boxes, a crowd where most pairs overlap, frames without detections (tracks go
+    lost and come back: more tracks than detections, the transposed problem) — must give the ids of the Python twin."""
+    E = _native()
+    rng = np.random.default_rng({"grid": 3, "crowd": 4, "duplicates": 5, "gaps": 6}[mode])
+    n, nf, stride = 48, 40, 64
+    pos = rng.uniform([50, 50], [1230, 670], (n, 2))
+    vel = rng.uniform(-4, 4, (n, 2))
+    if mode == "grid":
+        pos, vel = np.round(pos / 40) * 40, vel * 0
+    if mode == "crowd":
+        pos = rng.uniform([500, 300], [700, 420], (n, 2))
+    boxes = np.zeros((nf, stride, 6), np.float32)
+    counts = np.zeros(nf, np.int32)
+    for f in range(nf):
+        pos = pos + vel + (0 if mode == "grid" else rng.normal(0, 0.7, pos.shape))
+        alive = rng.random(n) > 0.1
+        if mode == "gaps" and f % 7 in (3, 4):
+            alive[:] = False
+        k = int(alive.sum())
+        wh = np.stack([30 + np.arange(n) % 40, 80 + np.arange(n) % 60], 1)[alive] if mode != "grid" else np.full((k, 2), [40.0, 90.0])
+        boxes[f, :k, :2] = pos[alive] - wh / 2
+        boxes[f, :k, 2:4] = pos[alive] + wh / 2
+        sc = rng.uniform(0.05, 0.99, k)
+        boxes[f, :k, 4] = np.round(sc * 4) / 4 if mode in ("grid", "duplicates") else sc
+        if mode == "duplicates" and k > 3:
+            boxes[f, 1, :4] = boxes[f, 0, :4]
+            boxes[f, 3, :5] = boxes[f, 2, :5]
+        counts[f] = k
+    ids_native = E.NativeByteTrack(frame_rate=30, lost_track_buffer=5).update_batch(boxes, counts)
+    bt = bytetrack.ByteTrack(frame_rate=30, lost_track_buffer=5)
+    n_ids = 0
+    for f in range(nf):
+        k = counts[f]
+        got = bt.update_with_detections(Detections(boxes[f, :k, :4], boxes[f, :k, 4], np.zeros(k, int)))
+        # duplicates: compare as multisets of (box, id) pairs in output order of the kept rows
+        want = sorted((tuple(boxes[f, i, :4].tolist()), int(ids_native[f, i])) for i in range(k) if ids_native[f, i] >= 0)
+        have = sorted((tuple(b.tolist()), int(t)) for b, t in zip(got.xyxy, got.tracker_id))
+        assert have == want, f"{mode}: frame {f}"
+        n_ids += len(want)
+    assert n_ids > nf

@@ -10,6 +10,7 @@
 #   ubench        tools/mfma_f16_ubench (16x16x32 and 32x32x16 f16 MFMA ceilings)
 #   sweep         tools/conv_bench.py --dtype h2 for every library under tools/ab/ and the product library
 #   timeline      tools/timeline_probe.py --kernel h2q with tools/ab/libpadel_hip_probes.so (192->192 and 96->96)
+#   pmc_nms       instruction mix / wait breakdown of nms_kernel and decode_kernel (tools/pmc_nms.sh)
 #   tiles         tools/conv_bench.py --dtype h2 --tiles $TILES (default auto,T323,T303) on $SWEEP_ARGS shapes
 #   tests_post    ball / known-answer (decode, NMS) / runner / bench-config suites
 #   bench_driver  the driver's command line: python bench.py --gpus 1 --steps 20 --warmup 5
@@ -63,11 +64,14 @@ for stage in "$@"; do
     bench_c4)
       timeout 900 python bench.py --workload c4 --dump-ops "$OUT/ops_c4.csv" > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; note $stage $?
       python tools/bench_summary.py "$OUT/bench_c4.json" ;;
+    pmc_nms)
+      timeout 900 bash tools/pmc_nms.sh "$GRAFT_REPO_ROOT/$OUT/pmc_nms" > "$OUT/pmc_nms.txt" 2>&1; note $stage $?
+      cat "$OUT/pmc_nms.txt" | tail -14; rm -rf "$OUT/pmc_nms" ;;
     tiles)
       timeout 600 python tools/conv_bench.py --dtype h2 --tiles ${TILES:-auto,T323,T303} --reps 7 ${SWEEP_ARGS:-} > "$OUT/tiles.txt" 2>&1; note $stage $?
       grep -v 'amdgpu.ids' "$OUT/tiles.txt" | head -30 ;;
     tests_post)
-      timeout 900 python -m pytest tests/test_gpu_ball.py tests/test_gpu_known_answers.py tests/test_gpu_runner.py tests/test_gpu_bench_config.py -m gpu -q -x > "$OUT/pytest_post.txt" 2>&1; note $stage $?
+      timeout 900 python -m pytest tests/test_gpu_ball.py tests/test_gpu_known_answers.py tests/test_gpu_nms_stress.py tests/test_gpu_runner.py tests/test_gpu_bench_config.py -m gpu -q -x > "$OUT/pytest_post.txt" 2>&1; note $stage $?
       tail -5 "$OUT/pytest_post.txt" ;;
     bench_driver)
       timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench_c3_driver_cmdline.json" 2> "$OUT/bench_c3_driver_cmdline.err"; note $stage $?
