@@ -623,7 +623,9 @@ def main():
             checkpoint.save_checkpoint(tpath, tr.synth_tracknet_state_dict(3), "tracknet", param_dict={"seq_len": 8, "bg_mode": "concat"})
             # (background median over the first B frames: the HBM-resident clip is B distinct frames repeated K times, so
             #  the reference's 1800-frame window would see the same B frames over and over)
-            bt = BallTracker(str(tpath), None, batch_size=B, median_max_sample_num=B)
+            ipath = Path(tmp) / f"inpaintnet_r{rank}.pt"
+            checkpoint.save_checkpoint(ipath, tr.synth_inpaintnet_state_dict(4), "inpaintnet", param_dict={"seq_len": 16})
+            bt = BallTracker(str(tpath), str(ipath), batch_size=B, median_max_sample_num=B)
             bt._engine = eng
             ref_trackers = [trackers["players"], trackers["pose"], bt]
 
@@ -642,7 +644,8 @@ def main():
                 "value": round(world * B * K / dt_r, 2), "unit": "frames/s", "ms_per_step": round(1e3 * dt_r / K, 3),
                 "trackers": {"players": "yolov8m-detect-nc80 @640 + PolygonZone + ByteTrack", "pose": "yolov8m-pose13x3 @1280",
                              "ball": "TrackNetV3 27->8 @288x512, one window per frame, median background over the clip, "
-                                     "temporal ensemble, threshold, connected components on the device (BallTracker)"},
+                                     "temporal ensemble, threshold, connected components on the device, InpaintNet trajectory repair over "
+                                     "the whole clip (device network, host windows / blending) (BallTracker)"},
                 "conv_gflop_per_frame": round((flops_per_frame["players"] + flops_per_frame["pose"]) / 1e9 + 227.61, 1),
                 "seconds_per_tracker_rank0": {k_: round(v_["seconds"], 4) for k_, v_ in rr.timings.items()},
                 "what": "TrackingRunner.run() over the same HBM-resident clip with the reference's default trackers"}

@@ -33,6 +33,7 @@ struct Tuning {
     int timeline = 0;    // 1: 3x3 tap launches of the 64x96 tile run the s_memtime-instrumented instantiation
     int alias = 1;       // 1: activation buffers share one arena by liveness, 0: disjoint ranges
     int fuse_stem = 1;   // 1: h2 YOLOv8 graphs run model.0 (stem) + model.1 (3x3 stride 2) as ONE kernel (stem_l1_h2.hip; default since round 4, 0 = two kernels)
+    int fuse_sppf = 1;   // 1: h2 graphs run the three chained 5x5 max-pools of SPPF as ONE kernel (sppf_h2_kernel: keys in LDS, separable passes); 0 = three launches.  Bitwise the same maps
     int fold_up = 1;     // 1: an nn.Upsample(2) whose only reader is a bf16x3 1x1 conv is never materialised (the conv
                          // fetches those channels at [y >> 1][x >> 1] of the coarse map), 0: run the upsample kernel
 };
@@ -140,12 +141,15 @@ int pa_engine_create(int device_id, pa_engine** out) {
     r = hipMalloc((void**)&e->zeros, 256);
     if (r == hipSuccess) r = hipMemset(e->zeros, 0, 256);
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "zero page: %s", hipGetErrorString(r)); }
+    r = padel::init_misc_kernels();
+    if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "kernel attributes: %s", hipGetErrorString(r)); }
     if (const char* v = getenv("PADEL_CONV_IMPL")) e->t.impl = (v[0] == 'l') ? 1 : (v[0] == 'b') ? 2 : 0;   // tap | lds | bx3
     e->t.variant = env_int("PADEL_CONV_VARIANT", -1);
     e->t.tune = env_int("PADEL_CONV_TUNE", 1);
     e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
     e->t.graph = env_int("PADEL_GRAPH", 0);
     e->t.fuse_stem = env_int("PADEL_FUSE_STEM", 1);
+    e->t.fuse_sppf = env_int("PADEL_FUSE_SPPF", 1);
     e->t.alias = env_int("PADEL_ALIAS", 1);
     e->t.fold_up = env_int("PADEL_FOLD_UP", 1);
     *out = e;
@@ -164,6 +168,7 @@ int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     else if (k == "alias") e->t.alias = value ? 1 : 0;
     else if (k == "fold_up") e->t.fold_up = value ? 1 : 0;
     else if (!strcmp(key, "fuse_stem")) e->t.fuse_stem = value;
+    else if (!strcmp(key, "fuse_sppf")) e->t.fuse_sppf = value;
     else PA_FAIL(e, "pa_engine_set_tuning: unknown key '%s'", key);
     e->tuning_epoch++;
     return 0;
@@ -800,7 +805,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             r = launch_stem(a, s);
         } else if (o.kind == PA_OP_SPPF_POOL) {
             pr = prof_begin(m, (*pi)++, o.kind, 5, 0.0);
-            r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s, (int)m->d.dtype);
+            r = launch_sppf_pool(m->bptr[o.in_buf], m->bufs[o.in_buf].channels, o.in_choff, o.cin, n, Ho, Wo, s, (int)m->d.dtype, e->t.fuse_sppf);
         } else if (o.kind == PA_OP_UPSAMPLE2X) {
             if (m->fold_dst[i] >= 0) {                   // absorbed by its consumer conv?  (same decision as at that conv)
                 ConvArgs ca{};

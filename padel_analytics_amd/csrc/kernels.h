@@ -112,7 +112,8 @@ hipError_t launch_stem_l1_h2(const StemArgs& st, const ConvArgs& cv, hipStream_t
 // SPPF: three chained MaxPool2d(5,1,2) of slice [choff, choff+c) written to the next three slices
 // (f16 == 1 in these three: the buffers hold _Float16 elements; cs / choff / c count elements, c % 8 == 0;
 //  f16 == 2: h2 pairs in 16-channel groups, 4 bytes per channel, cs / choff / c count channels)
-hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16 = 0);
+hipError_t init_misc_kernels();
+hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16 = 0, int fused = 1);
 // nearest x2 upsample of a slice into a slice of a buffer with twice the spatial size
 hipError_t launch_upsample2x(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
                              int c, int B, int H, int W, hipStream_t s, int f16 = 0);

@@ -280,23 +280,51 @@ __global__ void __launch_bounds__(256) pool5_kernel(typename VecT<V>::E* buf, in
 
 // ---- h2 buffers: a "unit" is 8 channels = 16 bytes of h + 16 bytes of m (32 bytes further) inside a 16-channel group.
 // Max-pooling compares the VALUES (h + m / 2048) and copies the winning pair: exact, nothing is re-encoded.
-struct H2Unit { h16x8 h, m; };
+//
+// One ORDER for every h2 max-pool: the value h + m / 2048 in fp32 first, the bits of the pair (h << 16 | m) between pairs of
+// equal value.  A total order makes the maximum of a window independent of how the window is walked, which is what lets
+// sppf_h2_kernel (separable passes, three levels in LDS) reproduce three chained pool5_h2_kernel launches bit for bit.  An
+// element travels as (value, packed pair): one select per field, the running maximum's value is never recomputed.
+template <int N> struct H2Vec;
+template <> struct H2Vec<4> { typedef float F __attribute__((ext_vector_type(4))); typedef unsigned U __attribute__((ext_vector_type(4))); };
+template <> struct H2Vec<8> { typedef float F __attribute__((ext_vector_type(8))); typedef unsigned U __attribute__((ext_vector_type(8))); };
+template <int N>
+struct H2Elems { typename H2Vec<N>::F v; typename H2Vec<N>::U p; };
 __device__ __forceinline__ const char* h2_unit_ptr(const float* buf, long long pix, int cs, int choff, int u) {
     const int c = choff + u * 8;
     return reinterpret_cast<const char*>(buf) + pix * cs * 4 + (long long)(c >> 4) * 64 + (c & 15) * 2;
 }
-__device__ __forceinline__ H2Unit h2_load_unit(const char* p) {
-    return H2Unit{*reinterpret_cast<const h16x8*>(p), *reinterpret_cast<const h16x8*>(p + 32)};
+__device__ __forceinline__ void h2_elem(_Float16 h, _Float16 m, float& v, unsigned& pk) {
+    v = fmaf((float)m, kH2InvScale, (float)h);
+    pk = ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | __builtin_bit_cast(unsigned short, m);
 }
-__device__ __forceinline__ H2Unit h2_max_unit(const H2Unit a, const H2Unit b) {
-    H2Unit r;
+__device__ __forceinline__ H2Elems<8> h2_load_unit(const char* q) {
+    const h16x8 h = *reinterpret_cast<const h16x8*>(q), m = *reinterpret_cast<const h16x8*>(q + 32);
+    H2Elems<8> r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const float va = fmaf((float)a.m[i], kH2InvScale, (float)a.h[i]), vb = fmaf((float)b.m[i], kH2InvScale, (float)b.h[i]);
-        const bool ta = va > vb;
-        r.h[i] = ta ? a.h[i] : b.h[i];
-        r.m[i] = ta ? a.m[i] : b.m[i];
+        float v; unsigned pk;
+        h2_elem(h[i], m[i], v, pk);
+        r.v[i] = v; r.p[i] = pk;
     }
+    return r;
+}
+__device__ __forceinline__ void h2_store_unit(char* q, const H2Elems<8>& e) {
+    h16x8 h, m;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = __builtin_bit_cast(_Float16, (unsigned short)(e.p[i] >> 16));
+        m[i] = __builtin_bit_cast(_Float16, (unsigned short)(e.p[i] & 0xffffu));
+    }
+    *reinterpret_cast<h16x8*>(q) = h;
+    *reinterpret_cast<h16x8*>(q + 32) = m;
+}
+template <int N>
+__device__ __forceinline__ H2Elems<N> h2_max(const H2Elems<N>& a, const H2Elems<N>& b) {
+    const auto ta = (a.v > b.v) | ((a.v == b.v) & (a.p > b.p));          // lane-wise, all ones where a wins
+    H2Elems<N> r;
+    r.v = ta ? a.v : b.v;
+    r.p = ta ? a.p : b.p;
     return r;
 }
 __global__ void __launch_bounds__(256) pool5_h2_kernel(float* buf, int cs, int src_off, int dst_off, int un, int B, int H, int W) {
@@ -308,20 +336,87 @@ __global__ void __launch_bounds__(256) pool5_h2_kernel(float* buf, int cs, int s
     const int x = (int)(t % W); t /= W;
     const int y = (int)(t % H);
     const int n = (int)(t / H);
-    H2Unit m = h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + y) * W + x, cs, src_off, u));
-    // clamped window (see pool5_kernel): a re-read pixel compares equal (strict >: the earlier pair stays), the result is the same
+    H2Elems<8> m = h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + y) * W + x, cs, src_off, u));
+    // clamped window (see pool5_kernel): a re-read pixel is the same element, the maximum is the same
 #pragma unroll
     for (int dy = -2; dy <= 2; ++dy) {
         const int yy = min(max(y + dy, 0), H - 1);
 #pragma unroll
         for (int dx = -2; dx <= 2; ++dx) {
             const int xx = min(max(x + dx, 0), W - 1);
-            m = h2_max_unit(h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + yy) * W + xx, cs, src_off, u)), m);
+            m = h2_max(h2_load_unit(h2_unit_ptr(buf, ((long long)n * H + yy) * W + xx, cs, src_off, u)), m);
         }
     }
-    char* o = const_cast<char*>(h2_unit_ptr(buf, ((long long)n * H + y) * W + x, cs, dst_off, u));
-    *reinterpret_cast<h16x8*>(o) = m.h;
-    *reinterpret_cast<h16x8*>(o + 32) = m.m;
+    h2_store_unit(const_cast<char*>(h2_unit_ptr(buf, ((long long)n * H + y) * W + x, cs, dst_off, u)), m);
+}
+
+// SPPF on h2 buffers as ONE kernel (round 4; three pool5_h2_kernel launches otherwise).  A workgroup owns the whole H x W map
+// of four channels of one image: the elements live in LDS, a 5 x 5 maximum is a row pass and a column pass (5 + 5 reads
+// instead of 25), the three chained levels (5, 9, 13 pixels wide) are computed back to back and each is written once.  Window
+// coordinates are clamped like pool5_h2_kernel's.  LDS: 2 planes x H*W x 32 bytes (40 x 40: 100 KB).  Workgroup ids are
+// mapped so that the four 4-channel units of a 16-channel group (one 64-byte line per pixel) run on the same XCD, next to
+// each other in time: their 8-byte pieces of a line meet in that XCD's L2.
+typedef H2Elems<4> Elem4;
+template <int NT>
+__global__ void __launch_bounds__(NT) sppf_h2_kernel(float* buf, int cs, int choff, int c, int B, int H, int W) {
+    extern __shared__ unsigned long long sppf_lds[];
+    const int HW = H * W;
+    const float inv_w = 1.0f / (float)W;
+    Elem4* X = reinterpret_cast<Elem4*>(sppf_lds);
+    Elem4* T = X + HW;
+    // id -> (XCD, slot); slot -> (group q of the XCD, unit); group index g = q * 8 + xcd over B x ceil(c / 16) groups
+    const int ngrp = (c + 15) / 16, G = B * ngrp;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = (slot >> 2) * 8 + xcd, ul = slot & 3;
+    if (g >= G) return;
+    const int n = g / ngrp, u = (g - n * ngrp) * 4 + ul;
+    if (u * 4 >= c) return;
+    const int c0 = choff + u * 4;
+    char* base = reinterpret_cast<char*>(buf) + (long long)n * HW * cs * 4 + (long long)(c0 >> 4) * 64 + (c0 & 15) * 2;
+    for (int p = threadIdx.x; p < HW; p += NT) {
+        const char* q = base + (long long)p * cs * 4;
+        const h16x4 hv = *reinterpret_cast<const h16x4*>(q), mv = *reinterpret_cast<const h16x4*>(q + 32);
+        Elem4 k;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v; unsigned pk;
+            h2_elem(hv[i], mv[i], v, pk);
+            k.v[i] = v; k.p[i] = pk;
+        }
+        X[p] = k;
+    }
+    __syncthreads();
+    for (int level = 1; level <= 3; ++level) {
+        for (int p = threadIdx.x; p < HW; p += NT) {
+            const int y = (int)(((float)p + 0.5f) * inv_w), x = p - y * W;     // exact: p + 0.5 is at least 0.5 / W from a multiple of W
+            Elem4 m = X[p];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d) m = h2_max(m, X[y * W + min(max(x + d, 0), W - 1)]);
+            T[p] = m;
+        }
+        __syncthreads();
+        const int off = level * c;                                   // slice `level` of the concat buffer: c channels further
+        char* ob = reinterpret_cast<char*>(buf) + (long long)n * HW * cs * 4 + (long long)((c0 + off) >> 4) * 64 + ((c0 + off) & 15) * 2;
+        for (int p = threadIdx.x; p < HW; p += NT) {
+            const int y = (int)(((float)p + 0.5f) * inv_w), x = p - y * W;
+            Elem4 m = T[p];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d) m = h2_max(m, T[min(max(y + d, 0), H - 1) * W + x]);
+            X[p] = m;                                                 // (only this thread touches X[p] in this pass: T is the source)
+            h16x4 hv, mv;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                hv[i] = __builtin_bit_cast(_Float16, (unsigned short)(m.p[i] >> 16));
+                mv[i] = __builtin_bit_cast(_Float16, (unsigned short)(m.p[i] & 0xffffu));
+            }
+            char* q = ob + (long long)p * cs * 4;
+            *reinterpret_cast<h16x4*>(q) = hv;
+            *reinterpret_cast<h16x4*>(q + 32) = mv;
+        }
+        __syncthreads();
+    }
 }
 __global__ void __launch_bounds__(256) maxpool2_h2_kernel(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
                                                            int un, int B, int H, int W) {
@@ -335,13 +430,10 @@ __global__ void __launch_bounds__(256) maxpool2_h2_kernel(const float* in, int i
     const int y = (int)(t % Ho);
     const int n = (int)(t / Ho);
     const long long p00 = ((long long)n * H + 2 * y) * W + 2 * x;
-    // same comparison order as vmax(vmax(a0, a1), vmax(b0, b1)) of the fp32 kernel
-    const H2Unit a0 = h2_load_unit(h2_unit_ptr(in, p00, in_cs, in_choff, u)), a1 = h2_load_unit(h2_unit_ptr(in, p00 + 1, in_cs, in_choff, u));
-    const H2Unit b0 = h2_load_unit(h2_unit_ptr(in, p00 + W, in_cs, in_choff, u)), b1 = h2_load_unit(h2_unit_ptr(in, p00 + W + 1, in_cs, in_choff, u));
-    const H2Unit m = h2_max_unit(h2_max_unit(a0, a1), h2_max_unit(b0, b1));
-    char* o = const_cast<char*>(h2_unit_ptr(out, ((long long)n * Ho + y) * Wo + x, out_cs, out_choff, u));
-    *reinterpret_cast<h16x8*>(o) = m.h;
-    *reinterpret_cast<h16x8*>(o + 32) = m.m;
+    const H2Elems<8> a0 = h2_load_unit(h2_unit_ptr(in, p00, in_cs, in_choff, u)), a1 = h2_load_unit(h2_unit_ptr(in, p00 + 1, in_cs, in_choff, u));
+    const H2Elems<8> b0 = h2_load_unit(h2_unit_ptr(in, p00 + W, in_cs, in_choff, u)), b1 = h2_load_unit(h2_unit_ptr(in, p00 + W + 1, in_cs, in_choff, u));
+    const H2Elems<8> m = h2_max(h2_max(a0, a1), h2_max(b0, b1));
+    h2_store_unit(const_cast<char*>(h2_unit_ptr(out, ((long long)n * Ho + y) * Wo + x, out_cs, out_choff, u)), m);
 }
 // fp32 NHWC -> h2 pairs, whole 16-channel groups (the network input of a generic h2 graph, pa_tracknet_infer)
 __global__ void __launch_bounds__(256) h2_encode_kernel(const float* in, float* out, long long n4, unsigned* ovf) {
@@ -364,10 +456,33 @@ hipError_t launch_h2_encode(const float* in, float* out, long long n_floats, uns
     return hipGetLastError();
 }
 
+constexpr size_t kSppfMaxLds = 150 * 1024;
+// once per engine, outside any stream capture: kernels whose dynamic LDS exceeds the 64 KB default
+hipError_t init_misc_kernels() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_h2_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_h2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_h2_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
+    return e;
+}
+
 // f16: storage type of the buffer — 0 fp32, 1 fp16, 2 h2 pairs
-hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16) {
+hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, int W, hipStream_t s, int f16, int fused) {
     if (f16 == 2) {
         if ((c | choff) & 7) return hipErrorInvalidValue;
+        const size_t lds = (size_t)2 * H * W * sizeof(Elem4);
+        const long long wgs = ((long long)B * ((c + 15) / 16) + 7) / 8 * 8 * 4;          // see the id mapping in sppf_h2_kernel
+        // measured on the c3 graphs (profiles/r4n_sppf_ab.txt: three launches 0.69 / 0.135 / 0.072 ms for the 40 x 40 x 288,
+        // 12 x 20 x 288 and 12 x 20 x 128 maps of 64 images; fused 0.35 / 0.043 / 0.023): big maps want the 16 waves of a
+        // 1024-thread workgroup (their two LDS planes leave room for one workgroup per CU), small ones several 256-thread
+        // workgroups per CU.  fused = 2 / 3 / 4: force 256 / 512 / 1024 threads (tuning only)
+        if (fused && lds <= kSppfMaxLds && wgs < (1ll << 31)) {          // (init_misc_kernels raised the kernel's dynamic-LDS limit)
+            const dim3 grid((unsigned)wgs);
+            const int nt = fused == 2 ? 256 : fused == 3 ? 512 : fused == 4 ? 1024 : (H * W > 1024 ? 1024 : 256);
+            if (nt == 256) hipLaunchKernelGGL(sppf_h2_kernel<256>, grid, dim3(256), lds, s, buf, cs, choff, c, B, H, W);
+            else if (nt == 512) hipLaunchKernelGGL(sppf_h2_kernel<512>, grid, dim3(512), lds, s, buf, cs, choff, c, B, H, W);
+            else hipLaunchKernelGGL(sppf_h2_kernel<1024>, grid, dim3(1024), lds, s, buf, cs, choff, c, B, H, W);
+            return hipGetLastError();
+        }
         const long long total = (long long)B * H * W * (c / 8);
         for (int k = 0; k < 3; ++k) {
             hipLaunchKernelGGL(pool5_h2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, buf, cs, choff + k * c,

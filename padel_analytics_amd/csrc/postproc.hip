@@ -187,8 +187,8 @@ __global__ void __launch_bounds__(NMS_THREADS) nms_kernel(const NmsArgs a) {
     // Greedy suppression in rank order; boxes are offset by cls * 7680 like upstream (agnostic=False).  A candidate survives
     // iff no box KEPT before it overlaps it by more than iou (torchvision's definition), so only pairs (kept box, candidate)
     // matter: at most max_det x n of them, against the n^2 / 2 of the full IoU matrix rounds 2-4 built — with the
-    // bench's 1 700 - 5 000 candidates per pose frame the matrix was 1.1 ms on the one CU an image has
-    // (profiles/r4j_pmc_nms.txt).  The ranking is consumed a WORD of 64 candidates at a time (one per lane):
+    // bench's 1 700 - 5 000 candidates per pose frame the matrix was 1.15 ms on the one CU an image has
+    // (profiles/r4j_pmc_nms.txt); this walk is 0.37 ms (profiles/r4k_pmc_nms.txt).  The ranking is consumed a WORD of 64 candidates at a time (one per lane):
     //   1. every wave tests the word against a 16th of the boxes kept so far (leaving as soon as all 64 are suppressed) and
     //      computes four rows of the word's own 64 x 64 triangle by ballot;
     //   2. wave 0 walks the survivors serially (ctz over the not-removed bits), appending to the kept list.

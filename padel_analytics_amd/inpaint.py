@@ -54,33 +54,31 @@ def ensemble_weight(seq_len: int) -> np.ndarray:
 def temporal_ensemble(seq: np.ndarray, weight: np.ndarray) -> np.ndarray:
     """seq: (S, L, ...) per-window predictions (window s covers frames s..s+L-1) -> (S + L - 1, ...):
     frame g < L-1: mean of the available windows; L-1 <= g < S: sum_k weight[k] * seq[g-(L-1)+k][L-1-k];
-    the L-1 tail frames: means of the remaining windows (ball_tracker.py:449-509 / :600-650)."""
+    the L-1 tail frames: means of the remaining windows (ball_tracker.py:449-509 / :600-650).
+    All frames at once; per frame the L terms are added in the order k = 0 .. L-1 (the loop of the reference)."""
     S, L = seq.shape[:2]
+    T = S + L - 1
     zero = np.zeros((L - 1,) + seq.shape[1:], np.float32)
     buf = np.concatenate([zero, seq.astype(np.float32), zero], 0)          # row r <-> window r-(L-1)
     k = np.arange(L)
-    out = []
-    wb = weight.reshape((L,) + (1,) * (seq.ndim - 2))
-    for g in range(S):
-        rows = buf[k + g, L - 1 - k]
-        if g < L - 1:
-            acc = rows[0].copy()
-            for r in rows[1:]:
-                acc = acc + r
-            out.append(acc / np.float32(g + 1))
-        else:
-            prod = rows * wb
-            acc = prod[0].copy()
-            for r in prod[1:]:
-                acc = acc + r
-            out.append(acc)
-    for fi in range(1, L):
-        rows = buf[k + (S - 1) + fi, L - 1 - k]
-        acc = rows[0].copy()
-        for r in rows[1:]:
-            acc = acc + r
-        out.append(acc / np.float32(L - fi))
-    return np.stack(out)
+    rows = buf[np.arange(T)[:, None] + k[None, :], (L - 1 - k)[None, :]]    # (T, L, ...): window k of frame g (zeros where none)
+    wb = weight.reshape((1, L) + (1,) * (seq.ndim - 2)).astype(np.float32)
+    g = np.arange(T)
+    mid = (g >= L - 1) & (g < S)
+    terms = np.where(mid.reshape((T, 1) + (1,) * (seq.ndim - 2)), rows * wb, rows)
+    acc = terms[:, 0].copy()
+    for j in range(1, L):
+        acc = acc + terms[:, j]
+    # head: g + 1 windows, tail frame S - 1 + fi: L - fi windows  (S < L - 1: the head rule wins, like the loops did)
+    div = np.ones(T, np.float32)
+    head = g < min(L - 1, S)
+    div[head] = (g[head] + 1).astype(np.float32)
+    tail = g >= S
+    div[tail] = (L - (g[tail] - S + 1)).astype(np.float32)
+    out = acc.copy()
+    sel = head | tail
+    out[sel] = acc[sel] / div[sel].reshape((-1,) + (1,) * (seq.ndim - 2))
+    return out
 
 
 class InpaintNetHost:

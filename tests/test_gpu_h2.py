@@ -267,6 +267,41 @@ def test_stale_arena_bytes_cannot_reach_results(gpu_engine, mode):
     t.close()
 
 
+@pytest.mark.parametrize("scale,hw,imgsz", [("n", (360, 640), 640), ("s", (180, 320), 288), ("m", (720, 1280), 1280), ("n", (1080, 1920), 1920)],
+                         ids=["n-640", "s-288", "m-1280", "n-1920"])
+def test_fused_sppf_matches_three_pool_launches(gpu_engine, scale, hw, imgsz):
+    """Tuning "fuse_sppf" (sppf_h2_kernel, on by default): the three chained MaxPool2d(5, 1, 2) of SPPF as one kernel — keys in
+    LDS, a row pass and a column pass per level.  Every h2 max-pool orders pairs the same way (value, then the pair's bits), so
+    the separable walk picks the pairs the 25-tap walks pick: head maps and detections are bitwise those of the three
+    launches (P5 maps of 12 x 20, 5 x 9 (partial everything), 23 x 40 and 34 x 60: the largest map that fits the LDS planes)."""
+    from padel_analytics_amd import yolo_arch
+    from tests import synth
+    h, w = hw
+    frames = synth.synthetic_frames(2, h, w, seed=12)
+    sd = yolo_arch.synth_state_dict(scale, 80, None, seed=5, cls_bias=-1.0)
+    m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None, dtype="h2"))
+    m.set_max_batch(2)
+    kw = dict(imgsz=imgsz, conf=0.25, iou=0.7)
+    gpu_engine.set_profiling(True)
+    try:
+        gpu_engine.set_tuning(fuse_sppf=0)
+        b0, _, c0 = m.yolo_infer(frames, 2, h, w, **kw)
+        h0 = [m.read_head(l, 2) for l in range(3)]
+        assert not m.take_overflow()
+        gpu_engine.set_tuning(fuse_sppf=1)
+        b1, _, c1 = m.yolo_infer(frames, 2, h, w, **kw)
+        h1 = [m.read_head(l, 2) for l in range(3)]
+        assert not m.take_overflow()
+    finally:
+        gpu_engine.set_tuning(fuse_sppf=1)           # the default
+        gpu_engine.set_profiling(False)
+        m.close()
+    for l in range(3):
+        assert np.array_equal(h0[l].view(np.uint32), h1[l].view(np.uint32)), f"head {l} differs"
+    assert np.array_equal(c0, c1) and np.array_equal(b0.view(np.uint32), b1.view(np.uint32))
+    assert int(c1.sum()) > 0
+
+
 @pytest.mark.parametrize("scale,hw,imgsz", [("n", (360, 640), 640), ("s", (180, 320), 288), ("m", (180, 320), 288), ("m", (360, 640), 640)],
                          ids=["n-640", "s-288", "m-288", "m-640"])
 def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):

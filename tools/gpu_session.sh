@@ -12,6 +12,8 @@
 #   timeline      tools/timeline_probe.py --kernel h2q with tools/ab/libpadel_hip_probes.so (192->192 and 96->96)
 #   pmc_nms       instruction mix / wait breakdown of nms_kernel and decode_kernel (tools/pmc_nms.sh)
 #   tiles         tools/conv_bench.py --dtype h2 --tiles $TILES (default auto,T323,T303) on $SWEEP_ARGS shapes
+#   tests_sel     python -m pytest $PYTEST_SEL -m gpu (any selection)
+#   bench_c2q / bench_c4q   the other configs with --quick --steps 5 (runner + engine-only + roofline only)
 #   tests_post    ball / known-answer (decode, NMS) / runner / bench-config suites
 #   bench_driver  the driver's command line: python bench.py --gpus 1 --steps 20 --warmup 5
 #   tests_f16     the fp16 kernel tests + BASELINE configs[0] / [3] / [4] tests
@@ -64,6 +66,15 @@ for stage in "$@"; do
     bench_c4)
       timeout 900 python bench.py --workload c4 --dump-ops "$OUT/ops_c4.csv" > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; note $stage $?
       python tools/bench_summary.py "$OUT/bench_c4.json" ;;
+    tests_sel)
+      timeout 1200 python -m pytest ${PYTEST_SEL:-tests} -m gpu -q --maxfail=5 > "$OUT/pytest_sel.txt" 2>&1; note $stage $?
+      grep -E "passed|failed|FAILED|Error" "$OUT/pytest_sel.txt" | tail -12 ;;
+    bench_c2q)
+      timeout 600 python bench.py --workload c2 --steps 5 --warmup 2 --quick > "$OUT/bench_c2_quick.json" 2> "$OUT/bench_c2_quick.err"; note $stage $?
+      python tools/bench_summary.py "$OUT/bench_c2_quick.json" ;;
+    bench_c4q)
+      timeout 600 python bench.py --workload c4 --steps 5 --warmup 2 --quick > "$OUT/bench_c4_quick.json" 2> "$OUT/bench_c4_quick.err"; note $stage $?
+      python tools/bench_summary.py "$OUT/bench_c4_quick.json" ;;
     pmc_nms)
       timeout 900 bash tools/pmc_nms.sh "$GRAFT_REPO_ROOT/$OUT/pmc_nms" > "$OUT/pmc_nms.txt" 2>&1; note $stage $?
       cat "$OUT/pmc_nms.txt" | tail -14; rm -rf "$OUT/pmc_nms" ;;
