@@ -18,6 +18,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Optional
 
+import os
+
 import numpy as np
 
 from . import yolo_arch
@@ -294,6 +296,10 @@ class Graph:
         return total
 
 
+# tests / tuning (PADEL_HEAD_SPLIT=0|1): force the Detect / Pose head's first convs merged (False) or per branch (True)
+HEAD_SPLIT: Optional[bool] = {"0": False, "1": True}.get(os.environ.get("PADEL_HEAD_SPLIT", ""))
+
+
 def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f32") -> Graph:
     """YOLOv8 detect / pose graph (SURVEY.md Appendix A layer table) over the engine's op set.
 
@@ -390,7 +396,18 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f
     c2f(21, (cat20, 0, c4 + c5), c5, False, 5, (b21, 0))
 
     # Detect / Pose head: the first 3x3 convs of the box / cls / kpt branches share their input, so
-    # they run as ONE conv with concatenated (16-padded) output slices
+    # they run as ONE conv with concatenated (16-padded) output slices — except, on h2 graphs, at P3 / P4 when the merged
+    # width is a whole number of neither 48- nor 64-channel tiles (the 13-keypoint pose head of the m scale: 64 + 192 + 48 = 304
+    # channels = 19 fragments on seven 48-channel tiles): there each branch is its own conv into its slice of the same
+    # buffer, the 192-channel class branch on the 96-channel quad tiles (conv_patch_h2q.hip), the others on the 64- / 48-
+    # channel patch tiles.  Measured on the bench's 64 x 1280^2 pose batch (profiles/r4o_head_split.txt): P3 4.55 -> 4.23 ms,
+    # P4 2.24 -> 2.14, P5 (few tiles per conv) 0.96 -> 1.05; a detect head of 64 + 192 = 256 channels, which fills its tiles,
+    # loses 4-7 % at 640^2 when split.  Same numbers either way (a row of the weight matrix does not know its neighbours);
+    # HEAD_SPLIT forces one or the other for the tests.
+    def split_head(lvl, tot):
+        if HEAD_SPLIT is not None:
+            return HEAD_SPLIT
+        return g.dtype == DTYPE_H2 and lvl <= 4 and tot % 64 != 0 and tot % 48 != 0
     head_cs = (64 + nc + nk + 3) // 4 * 4
     heads = []
     branches = [("cv2", c2h, 4 * yolo_arch.REG_MAX, 0), ("cv3", c3h, nc, 64)]
@@ -410,7 +427,11 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f
             offs.append(o)
             o += pw
         h0 = g.buf(lvl, tot)
-        g.conv((feat, 0, chn), (h0, 0), wcat, bcat, 3, 1, ACT_SILU)
+        if split_head(lvl, tot):
+            for (br, wd, _, _), pw, o in zip(branches, widths, offs):
+                g.conv((feat, 0, chn), (h0, o), wcat[o:o + wd], bcat[o:o + wd], 3, 1, ACT_SILU, out_width=pw)
+        else:
+            g.conv((feat, 0, chn), (h0, 0), wcat, bcat, 3, 1, ACT_SILU)
         hd = g.buf(lvl, head_cs)
         for (br, wd, nout, hoff), pw, o in zip(branches, widths, offs):
             h1 = g.buf(lvl, pw)

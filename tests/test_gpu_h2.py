@@ -267,6 +267,36 @@ def test_stale_arena_bytes_cannot_reach_results(gpu_engine, mode):
     t.close()
 
 
+@pytest.mark.parametrize("nc,kpt", [(80, None), (1, (13, 3))], ids=["detect", "pose"])
+def test_head_branches_as_separate_convs_match_the_merged_conv(gpu_engine, nc, kpt, monkeypatch):
+    """graph.HEAD_SPLIT (automatic on h2 m / l / x graphs): the first 3x3 conv of every Detect / Pose branch as its own op into
+    its slice of the shared buffer, so that every branch gets the tile that fits its width.  A row of the weight matrix does
+    not know its neighbours and results do not depend on the tile: head maps and detections bitwise those of the merged conv."""
+    from padel_analytics_amd import yolo_arch
+    from tests import synth
+    h, w = 360, 640
+    frames = synth.synthetic_frames(2, h, w, seed=4)
+    sd = yolo_arch.synth_state_dict("m", nc, kpt, seed=6, cls_bias=-1.0)
+    res = []
+    for split in (False, True):
+        monkeypatch.setattr(G, "HEAD_SPLIT", split)
+        m = E.Model(gpu_engine, G.build_yolov8(sd, nc, kpt, dtype="h2"))
+        m.set_max_batch(2)
+        try:
+            b, k, c = m.yolo_infer(frames, 2, h, w, imgsz=640, conf=0.25, iou=0.7)
+            heads = [m.read_head(l, 2) for l in range(3)]
+            assert not m.take_overflow()
+        finally:
+            m.close()
+        res.append((b, k, c, heads))
+    (b0, k0, c0, h0), (b1, k1, c1, h1) = res
+    for l in range(3):
+        assert np.array_equal(h0[l].view(np.uint32), h1[l].view(np.uint32)), f"head {l} differs"
+    assert np.array_equal(c0, c1) and np.array_equal(b0.view(np.uint32), b1.view(np.uint32)) and int(c0.sum()) > 0
+    if kpt:
+        assert np.array_equal(k0.view(np.uint32), k1.view(np.uint32))
+
+
 @pytest.mark.parametrize("scale,hw,imgsz", [("n", (360, 640), 640), ("s", (180, 320), 288), ("m", (720, 1280), 1280), ("n", (1080, 1920), 1920)],
                          ids=["n-640", "s-288", "m-1280", "n-1920"])
 def test_fused_sppf_matches_three_pool_launches(gpu_engine, scale, hw, imgsz):

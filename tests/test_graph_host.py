@@ -177,3 +177,31 @@ def test_h2_row_scale_survives_denormal_and_huge_rows():
     assert np.all(back[0] == 0.0)                                   # the denormal row contributes nothing (as in fp16 it cannot)
     assert np.all(np.abs(back[2] - 1e-30) <= 1e-30 * 2.0 ** -21)     # 2^100 keeps a 1e-30 row in the normal fp16 range
     assert np.all(np.abs(back[3, 0] - 1.0) <= 2.0 ** -21)
+
+
+@pytest.mark.parametrize("nc,kpt", [(80, None), (1, (13, 3))])
+def test_head_first_convs_per_branch_equal_the_merged_conv(nc, kpt, monkeypatch):
+    """Round 4: h2 graphs of the m / l / x scales run the first 3x3 conv of each Detect / Pose branch as its own op into its
+    slice of the shared buffer (tile fit, graph.py).  Same head maps as the merged conv, and the automatic choice is what the
+    comment in graph.py says."""
+    sd = yolo_arch.synth_state_dict("s", nc, kpt, seed=2, gain=1.0)
+    x = torch.rand(1, 3, 64, 96)
+    outs, n_convs = [], []
+    for split in (False, True):
+        monkeypatch.setattr(G, "HEAD_SPLIT", split)
+        g = G.build_yolov8(sd, nc, kpt)
+        bufs = graph_interp.run(g, net_in=x)
+        outs.append([bufs[g.head_buf[l]].clone() for l in range(3)])
+        n_convs.append(sum(1 for o in g.ops if o["kind"] == G.OP_CONV))
+    nbr = 3 if kpt else 2
+    assert n_convs[1] == n_convs[0] + 3 * (nbr - 1)
+    for a, b in zip(*outs):          # (the CPU interpreter's conv2d blocks differently for different widths: last-bit
+        assert float((a - b).abs().max()) <= 4e-6 * max(1.0, float(a.abs().max()))       # differences; bitwise on the GPU: tests/test_gpu_h2.py)
+    monkeypatch.setattr(G, "HEAD_SPLIT", None)
+    count = lambda g: sum(1 for o in g.ops if o["kind"] == G.OP_CONV)
+    # automatic: only h2, only P3 / P4, only a merged width that is not a whole number of 48- or 64-channel tiles (m pose: 304)
+    sd_m = yolo_arch.synth_state_dict("m", nc, kpt, seed=2)
+    extra = 2 * (nbr - 1) if kpt else 0
+    assert count(G.build_yolov8(sd_m, nc, kpt, dtype="h2")) == count(G.build_yolov8(sd_m, nc, kpt, dtype="f32")) + extra
+    sd_s = yolo_arch.synth_state_dict("s", nc, kpt, seed=2)           # 64 + 128 (+ 48) channels: whole 64- / 48-channel tiles
+    assert count(G.build_yolov8(sd_s, nc, kpt, dtype="h2")) == count(G.build_yolov8(sd_s, nc, kpt, dtype="f32"))
