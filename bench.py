@@ -418,7 +418,8 @@ def main():
             boxes, kpts, counts = trackers[name].model._ensure_model().yolo_infer(
                 clip.buffer, B, H, W, imgsz=cfg["imgsz"], conf=cfg["conf"], iou=0.7, classes=cfg["classes"],
                 max_det=1 if name == "ball" else 300,
-                pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg["rev"])
+                pre_mode=E.PRE_PIL_STRETCH if cfg["pre"] == "pil" else E.PRE_LETTERBOX, channel_reverse=cfg["rev"],
+                reuse_outputs=True)
             tot += int(counts.sum())
         return tot
 

@@ -92,6 +92,8 @@ struct pa_model {
     std::vector<float*> bptr;
     void* arena = nullptr;                 // what bptr points into
     size_t arena_bytes = 0, logical_bytes = 0;   // bytes of the plan with / without liveness aliasing
+    unsigned h_ovf = 0, h_ovf_last = 0;    // overflow flag as read back by the last pa_yolo_infer calls (h2 models)
+    bool ovf_cached = false;               // h_ovf is current: no kernel of this model has run since it was read
     std::map<int, hipGraphExec_t> graphs;  // op-list replay per batch size (tuning "graph")
     int graph_epoch = -1;                  // engine tuning epoch the graphs were captured under
     uint8_t* d_frames = nullptr; size_t frames_cap = 0;
@@ -371,8 +373,14 @@ int pa_model_take_overflow(pa_model* m, int* out) {
     if (m->d.dtype != PA_DTYPE_H2) return 0;
     PA_HIP(e, hipSetDevice(e->dev));
     unsigned v = 0;
-    PA_HIP(e, hipMemcpyAsync(&v, m->d_ovf, sizeof(v), hipMemcpyDeviceToHost, e->stream));
-    PA_HIP(e, hipStreamSynchronize(e->stream));
+    if (m->ovf_cached) {                 // pa_yolo_infer read the flag back with its results (nothing has run on the model since)
+        v = m->h_ovf;
+    } else {
+        PA_HIP(e, hipMemcpyAsync(&v, m->d_ovf, sizeof(v), hipMemcpyDeviceToHost, e->stream));
+        PA_HIP(e, hipStreamSynchronize(e->stream));
+    }
+    m->ovf_cached = false;
+    m->h_ovf = 0;
     if (v) {
         PA_HIP(e, hipMemsetAsync(m->d_ovf, 0, sizeof(v), e->stream));
         PA_HIP(e, hipStreamSynchronize(e->stream));
@@ -904,6 +912,8 @@ static int run_post(pa_model* m, const pa_yolo_params* p, int nb, int oh, int ow
     prof_end(m, pr);
     if (r != hipSuccess) PA_FAIL(e, "nms launch failed: %s", hipGetErrorString(r));
     // ---- results back to the caller's arrays (rows beyond max_det are never written on device)
+    if (m->d.dtype == PA_DTYPE_H2)      // the overflow flag travels with the results: pa_model_take_overflow needs no device round trip
+        PA_HIP(e, hipMemcpyAsync(&m->h_ovf_last, m->d_ovf, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     PA_HIP(e, hipMemcpyAsync(out_counts, m->d_ocnt, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PA_HIP(e, hipMemcpyAsync(out_boxes, m->d_oboxes,
                              (size_t)nb * p->max_det * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -988,6 +998,7 @@ int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const
                      m->d.nk ? out_kpts + (size_t)c0 * p->max_det * m->d.nk : nullptr, out_counts + c0)) return 1;
         PA_HIP(e, hipStreamSynchronize(s));
         m->last_n = nb;
+        if (m->d.dtype == PA_DTYPE_H2) { m->h_ovf |= m->h_ovf_last; m->ovf_cached = true; }
     }
     finish_profile(m, pi);
     return 0;
@@ -1083,6 +1094,7 @@ int pa_tracknet_infer(pa_model* m, const float* x, int n, int h, int w, int x_on
     if (m->d.task != PA_TASK_TRACKNET) PA_FAIL(e, "pa_tracknet_infer on a non-TrackNet model");
     if (!x || !out || n <= 0) PA_FAIL(e, "pa_tracknet_infer: bad arguments");
     PA_HIP(e, hipSetDevice(e->dev));
+    m->ovf_cached = false;               // this call's kernels may raise the flag: the host copy is stale
     if (!m->planned || m->net_h != h || m->net_w != w || m->p_batch != m->max_batch) {
         PA_HIP(e, hipStreamSynchronize(e->stream));
         free_plan(m);
@@ -1303,6 +1315,7 @@ int pa_ball_feed(pa_ball* b, const uint8_t* frames, int n, int on_device, int fl
                 b->B, m->max_batch);
     if (n < 0 || n > b->B || (n > 0 && !frames)) PA_FAIL(e, "pa_ball_feed: n = %d (max %d)", n, b->B);
     PA_HIP(e, hipSetDevice(e->dev));
+    m->ovf_cached = false;               // this call's kernels may raise the flag: the host copy is stale
     hipStream_t s = e->stream;
     const size_t HW = (size_t)BALL_H * BALL_W;
     if (!m->planned || m->net_h != BALL_H || m->net_w != BALL_W || m->p_batch != m->max_batch) {

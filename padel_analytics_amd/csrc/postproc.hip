@@ -97,8 +97,16 @@ __global__ void __launch_bounds__(256) decode_kernel(const DecodeArgs a) {
     a.cand_idx[(long long)b * a.A + slot] = ai;
 }
 
+// (a kernel, not hipMemsetAsync: between two kernels of a stream the runtime's memset left the GPU idle for 0.3 ms —
+//  profiles/r4p_copy_trace_c3.txt)
+__global__ void zero_i32_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(a.cand_cnt, 0, sizeof(int32_t) * a.B, s);
+    hipLaunchKernelGGL(zero_i32_kernel, dim3((a.B + 255) / 256), dim3(256), 0, s, a.cand_cnt, a.B);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     dim3 grid((a.A + 255) / 256, a.B, 1);
     hipLaunchKernelGGL(decode_kernel, grid, dim3(256), 0, s, a);

@@ -322,6 +322,40 @@ class Model:
                                                  graph.n_floats if empty else blob.size, C.byref(h)))
         self.handle = h
         self.max_batch = 64
+        self._out_ring: dict = {}        # (n, max_det) -> [three page-locked (boxes, kpts, counts) sets, next slot]
+
+    #: result sets a ``yolo_infer(..., reuse_outputs=True)`` caller may hold at a time (the batch loop of the trackers holds two:
+    #: the batch in the host stage and the batch being inferred)
+    OUT_RING = 3
+
+    def _ring_outputs(self, n: int, max_det: int):
+        key = (int(n), int(max_det))
+        ring = self._out_ring.get(key)
+        if ring is None:
+            nk = self.graph.nk
+            sets = []
+            for _ in range(self.OUT_RING):
+                arrs = (np.zeros((n, max_det, 6), np.float32), np.zeros((n, max_det, nk), np.float32) if nk else None,
+                        np.zeros((n,), np.int32))
+                for a in arrs:
+                    if a is not None:
+                        self.engine.pin(a)
+                sets.append(arrs)
+            ring = self._out_ring[key] = [sets, 0]
+        sets, i = ring
+        ring[1] = (i + 1) % self.OUT_RING
+        return sets[i]
+
+    def _free_rings(self):
+        for sets, _ in self._out_ring.values():
+            for arrs in sets:
+                for a in arrs:
+                    if a is not None:
+                        try:
+                            self.engine.unpin(a)
+                        except Exception:
+                            pass
+        self._out_ring = {}
 
     def set_max_batch(self, n: int):
         self.engine._check(self.engine.lib.pa_model_set_max_batch(self.handle, int(n)))
@@ -329,9 +363,13 @@ class Model:
 
     def yolo_infer(self, frames, n: int, h: int, w: int, *, imgsz: int, conf: float, iou: float,
                    classes: Optional[Sequence[int]] = None, max_det: int = 300, pre_mode: int = PRE_LETTERBOX,
-                   channel_reverse: bool = False, letterbox_auto: bool = True):
+                   channel_reverse: bool = False, letterbox_auto: bool = True, reuse_outputs: bool = False):
         """frames: (n,h,w,3) uint8 ndarray, or a DeviceBuffer holding the same bytes.
-        Returns (boxes (n,max_det,6), kpts (n,max_det,nk) | None, counts (n,))."""
+        Returns (boxes (n,max_det,6), kpts (n,max_det,nk) | None, counts (n,)).
+
+        ``reuse_outputs=True`` (the trackers' batch loops): the arrays are one of ``OUT_RING`` page-locked sets this model
+        keeps per (n, max_det) — the device copies its results straight into them (no staging copy, no 3.5 MB of fresh
+        zeros per pose batch) — and are overwritten by the ``OUT_RING``-th next such call; copy what must live longer."""
         on_dev = isinstance(frames, DeviceBuffer)
         if on_dev:
             ptr = frames.ptr
@@ -348,10 +386,13 @@ class Model:
             cls_arr = (C.c_int32 * len(classes))(*[int(c) for c in classes])
             p.n_classes = len(classes)
             p.classes = cls_arr
-        boxes = np.zeros((n, max_det, 6), np.float32)
-        counts = np.zeros((n,), np.int32)
-        nk = self.graph.nk
-        kpts = np.zeros((n, max_det, nk), np.float32) if nk else None
+        if reuse_outputs:
+            boxes, kpts, counts = self._ring_outputs(n, max_det)
+        else:
+            boxes = np.zeros((n, max_det, 6), np.float32)
+            counts = np.zeros((n,), np.int32)
+            nk = self.graph.nk
+            kpts = np.zeros((n, max_det, nk), np.float32) if nk else None
         self.engine._check(self.engine.lib.pa_yolo_infer(
             self.handle, ptr, n, h, w, C.byref(p), boxes.ctypes.data,
             kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
@@ -454,6 +495,7 @@ class Model:
 
     def close(self):
         if self.handle:
+            self._free_rings()
             self.engine.lib.pa_model_destroy(self.handle)
             self.handle = None
 

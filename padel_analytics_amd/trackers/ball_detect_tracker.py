@@ -55,7 +55,7 @@ class BallDetectTracker(Tracker):
     def infer_sample(self, sample, **kwargs):
         # players path convention: raw BGR frames reach the network in their own channel order (App. C #1)
         boxes, _, counts, _, _, _ = self.model.infer_frames(sample, self.CONF, self.IOU, self.IMGSZ, classes=None,
-                                                            max_det=1, channel_reverse=False)
+                                                            max_det=1, channel_reverse=False, reuse_outputs=self._reuse_outputs)
         return boxes, counts
 
     @staticmethod

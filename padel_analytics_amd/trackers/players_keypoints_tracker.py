@@ -145,7 +145,7 @@ class PlayerKeypointsTracker(Tracker):
         sample = sample if isinstance(sample, (list, np.ndarray)) else list(sample)
         h_frame, w_frame = sample[0].shape[:2]
         _, kpts, counts, _, _, _ = self.model.infer_frames(sample, self.CONF, self.IOU, self.train_image_size, classes=[0],
-                                                          channel_reverse=True, pil_stretch=True)
+                                                          channel_reverse=True, pil_stretch=True, reuse_outputs=self._reuse_outputs)
         return kpts, counts, (h_frame, w_frame)
 
     def post_sample(self, raw, **kwargs) -> list:

@@ -161,7 +161,7 @@ class PlayerTracker(Tracker):
     # ---- device stage: detector over one batch of raw BGR frames (host arrays or HBM-resident DeviceFrames)
     def infer_sample(self, sample, **kwargs):
         boxes, _, counts, _, _, _ = self.model.infer_frames(sample, self.CONF, self.IOU, self.IMGSZ, classes=[0],
-                                                            channel_reverse=False)
+                                                            channel_reverse=False, reuse_outputs=self._reuse_outputs)
         return boxes, counts
 
     # ---- host stage, split in the stateless part (zone) and the sequential part (ByteTrack)

@@ -102,6 +102,9 @@ def _sampler(generator: Iterable[np.ndarray], sequence_length: int) -> Iterator[
 
 class Tracker(ABC):
     batch_size: int
+    #: True while a loop that bounds the number of live result sets runs (``_predict_batches``): ``infer_sample`` may then ask
+    #: the engine for its recycled output arrays
+    _reuse_outputs: bool = False
     #: frames of temporal context a shard needs before / after its own frames (TrackNet windows: 7 / 7)
     temporal_context: tuple = (0, 0)
     #: True for trackers that consume the whole stream in predict_frames (TrackNet), False for batch trackers
@@ -205,6 +208,9 @@ class Tracker(ABC):
         # a whole device stage of the small models): a short interval for the duration of the loop
         interval = sys.getswitchinterval()
         sys.setswitchinterval(min(interval, 2e-4))
+        # at most two result sets are alive here (the batch in the host stage, the batch being inferred): the device stage may
+        # hand out the model's recycled page-locked arrays (engine.Model.yolo_infer(reuse_outputs=True))
+        self._reuse_outputs = True
         try:
             with ThreadPoolExecutor(max_workers=1) as pool:
                 pending = []
@@ -216,6 +222,7 @@ class Tracker(ABC):
                 for f in pending:
                     update(f.result())
         finally:
+            self._reuse_outputs = False
             sys.setswitchinterval(interval)
 
     def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:

@@ -179,10 +179,11 @@ class YOLO:
                                                 pil_stretch=pil_stretch))
 
     def infer_frames(self, frames, conf, iou, imgsz, classes=None, max_det=300, *, channel_reverse: bool,
-                     pil_stretch: bool = False) -> tuple:
+                     pil_stretch: bool = False, reuse_outputs: bool = False) -> tuple:
         """The device stage alone: -> (boxes (n,max_det,6), kpts (n,max_det,nk) | None, counts (n,), (h, w), imgsz,
         pre_mode).  ``frames``: (n,h,w,3) uint8 array, a list of such frames, or a list of ``video.DeviceFrame``
-        handles of one contiguous range of a clip that is already in HBM (no upload)."""
+        handles of one contiguous range of a clip that is already in HBM (no upload).  ``reuse_outputs``: see
+        ``engine.Model.yolo_infer`` (the arrays are recycled two calls later)."""
         from . import video
         pre_mode = E.PRE_PIL_STRETCH if pil_stretch else E.PRE_LETTERBOX
         dev = None if isinstance(frames, np.ndarray) else video.device_batch(frames)
@@ -192,7 +193,7 @@ class YOLO:
             src = video.host_batch(frames)
             n, h, w, _ = src.shape
         kw = dict(imgsz=int(imgsz), conf=float(conf), iou=float(iou), classes=classes, max_det=int(max_det),
-                  pre_mode=pre_mode, channel_reverse=channel_reverse, letterbox_auto=True)
+                  pre_mode=pre_mode, channel_reverse=channel_reverse, letterbox_auto=True, reuse_outputs=reuse_outputs)
         m = self._ensure_model()
         boxes, kpts, counts = m.yolo_infer(src, n, h, w, **kw)
         if self.graph.dtype == G.DTYPE_H2 and m.take_overflow():

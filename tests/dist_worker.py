@@ -56,7 +56,7 @@ class FakeYOLO:
             self.fp32_mode, self.fell_back = "bx3", True
         return 0.25 if self.fp32_mode == "bx3" else 0.0
 
-    def infer_frames(self, frames, conf, iou, imgsz, classes=None, max_det=300, *, channel_reverse, pil_stretch=False):
+    def infer_frames(self, frames, conf, iou, imgsz, classes=None, max_det=300, *, channel_reverse, pil_stretch=False, reuse_outputs=False):
         frames = list(frames)
         n = len(frames)
         h, w = frames[0].shape[:2]

@@ -99,7 +99,7 @@ class FakeModel:
         return int(np.frombuffer(self.blob.tobytes(), np.uint32)[::97].astype(np.uint64).sum() % 1000003)
 
     def yolo_infer(self, frames, n, h, w, *, imgsz, conf, iou, classes=None, max_det=300, pre_mode=0, channel_reverse=False,
-                   letterbox_auto=True):
+                   letterbox_auto=True, reuse_outputs=False):
         assert self.has_weights, "inference on a model whose weights never arrived"
         if isinstance(frames, FakeBuffer):
             frames = frames.arr[:n * h * w * 3].reshape(n, h, w, 3)

@@ -80,3 +80,27 @@ def test_court_keypoints_tracker_yolo(gpu_engine, tmp_path):
         for i in range(12):
             k = kp[KeypointsTracker.POINTS_MAPPER[i]]
             assert abs(k.xy[0] - want[i, 0] * 640 / 640) < 0.1 and abs(k.xy[1] - want[i, 1] * 360 / 640) < 0.1
+
+
+def test_recycled_output_arrays_hold_the_same_results(gpu_engine):
+    """``Model.yolo_infer(reuse_outputs=True)`` (what the trackers' batch loops ask for): results land in one of OUT_RING
+    page-locked sets the model recycles — same numbers as fresh arrays, a set stays untouched while OUT_RING - 1 further
+    calls run, and is the one handed out again after that."""
+    from padel_analytics_amd import engine as E, graph as G, yolo_arch
+    m = E.Model(gpu_engine, G.build_yolov8(yolo_arch.synth_state_dict("n", 1, (13, 3), seed=2, cls_bias=1.0), 1, (13, 3), dtype=E.graph_dtype()))
+    m.set_max_batch(3)
+    kw = dict(imgsz=320, conf=0.25, iou=0.7)
+    batches = [synth.synthetic_frames(3, 180, 320, seed=20 + i) for i in range(E.Model.OUT_RING + 1)]
+    fresh = [m.yolo_infer(b, 3, 180, 320, **kw) for b in batches]
+    held = []
+    for i, b in enumerate(batches):
+        got = m.yolo_infer(b, 3, 180, 320, reuse_outputs=True, **kw)
+        for a, w in zip(got, fresh[i]):
+            assert np.array_equal(a, w)
+        for j, (g_old, i_old) in enumerate(held[-(E.Model.OUT_RING - 1):]):          # still what they were
+            for a, w in zip(g_old, fresh[i_old]):
+                assert np.array_equal(a, w), (i, i_old)
+        held.append((got, i))
+    assert held[E.Model.OUT_RING][0][0] is held[0][0][0]                          # the first set came round again
+    assert int(sum(f[2].sum() for f in fresh)) > 0
+    m.close()
