@@ -170,6 +170,22 @@ typedef struct pa_yolo_params {
 int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
                   float* out_boxes, float* out_kpts, int32_t* out_counts);
 
+/* The same call in two halves, for pipelined batch loops (round 4): pa_yolo_submit enqueues everything pa_yolo_infer does
+ * — preprocessing, network, decode, NMS, the result copies — behind whatever the engine's stream still holds and returns a
+ * ticket WITHOUT waiting; pa_yolo_wait blocks until that ticket's results are in the caller's arrays.  Submitting batch
+ * k + 1 before waiting for batch k keeps the GPU busy while the host collects results and prepares the next call (the
+ * reference's `predict` is synchronous per batch, players_tracker.py:351-359: its GPU idles there).
+ * Requirements: frames in HBM (frames_on_device = 1), n <= max_batch, no profiling; out_* must be page-locked
+ * (pa_host_register) and must not be touched between submit and wait — the ONE place where the library keeps caller
+ * pointers past return.  At most PA_MAX_INFLIGHT tickets per model; tickets complete in submission order; the plan
+ * (source size, imgsz, batch) must not change while tickets are in flight.  `overflow` (may be NULL): 1 if an activation of
+ * an h2 model has left the fp16 range by the time this ticket finished (sticky until pa_model_take_overflow): the
+ * results of this and of later tickets are then not to be used (see PA_DTYPE_H2).                                   */
+#define PA_MAX_INFLIGHT 4
+int pa_yolo_submit(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
+                   float* out_boxes, float* out_kpts, int32_t* out_counts, int* ticket);
+int pa_yolo_wait(pa_model* m, int ticket, int* overflow);
+
 /* decode + NMS + rescale alone, on CALLER-SUPPLIED head maps (tests: hand-derived known answers for the Detect / Pose
  * inference branch, ops.non_max_suppression, scale_boxes — players_tracker.py:351-359 [upstream]): heads[l] =
  * n x H_l x W_l x c fp32 in the pa_yolo_head_shape layout of the plan for source size h x w (n <= max_batch); outputs as

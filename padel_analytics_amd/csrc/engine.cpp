@@ -66,7 +66,10 @@ static int env_int(const char* k, int dflt) { const char* v = getenv(k); return 
 #define PA_HIP(eng, call)                                                                  \
     do {                                                                                   \
         hipError_t _e = (call);                                                            \
-        if (_e != hipSuccess) PA_FAIL(eng, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+        if (_e != hipSuccess) {                                                            \
+            (void)hipGetLastError();   /* reported here: must not surface again at the next launch's hipGetLastError() */ \
+            PA_FAIL(eng, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                                  \
     } while (0)
 
 struct ProfRec { int kind; int ksize; double flops; hipEvent_t e0, e1; float ms; int M, cout, cin, stride, mf, nf; };
@@ -92,8 +95,15 @@ struct pa_model {
     std::vector<float*> bptr;
     void* arena = nullptr;                 // what bptr points into
     size_t arena_bytes = 0, logical_bytes = 0;   // bytes of the plan with / without liveness aliasing
-    unsigned h_ovf = 0, h_ovf_last = 0;    // overflow flag as read back by the last pa_yolo_infer calls (h2 models)
+    unsigned h_ovf = 0;                    // overflow flag as read back by the last pa_yolo_infer calls (h2 models)
     bool ovf_cached = false;               // h_ovf is current: no kernel of this model has run since it was read
+    // pa_yolo_submit / pa_yolo_wait: tickets in flight.  slot = ticket % PA_MAX_INFLIGHT; h_pin[slot]: the overflow flag as the
+    // stream read it back after that ticket's kernels (page-locked: a pageable destination would make the copy block the host)
+    unsigned* h_pin = nullptr;
+    hipEvent_t tk_ev[PA_MAX_INFLIGHT]{};
+    bool tk_busy[PA_MAX_INFLIGHT]{};
+    int next_ticket = 0, n_inflight = 0;
+    std::vector<int32_t> classes_host;     // what d_classes holds (uploaded again only when the caller's list changes)
     std::map<int, hipGraphExec_t> graphs;  // op-list replay per batch size (tuning "graph")
     int graph_epoch = -1;                  // engine tuning epoch the graphs were captured under
     uint8_t* d_frames = nullptr; size_t frames_cap = 0;
@@ -330,6 +340,9 @@ int pa_model_create(pa_engine* e, const pa_model_desc* desc, const float* weight
     if (r == hipSuccess) r = hipMemsetAsync(m->d_w + n_floats, 0, kConvReadSlack, e->stream);
     if (r == hipSuccess) r = hipMalloc((void**)&m->d_ovf, 256);
     if (r == hipSuccess) r = hipMemsetAsync(m->d_ovf, 0, 256, e->stream);
+    if (r == hipSuccess) r = hipHostMalloc((void**)&m->h_pin, 64 * sizeof(unsigned), hipHostMallocDefault);
+    if (r == hipSuccess) memset(m->h_pin, 0, 64 * sizeof(unsigned));
+    for (int k = 0; k < PA_MAX_INFLIGHT && r == hipSuccess; ++k) r = hipEventCreateWithFlags(&m->tk_ev[k], hipEventDisableTiming);
     if (r == hipSuccess) r = hipStreamSynchronize(e->stream);
     if (r != hipSuccess) { delete m; PA_FAIL(e, "weights upload: %s", hipGetErrorString(r)); }
     *out = m;
@@ -363,6 +376,8 @@ void pa_model_destroy(pa_model* m) {
     if (m->d_w) hipFree(m->d_w);
     if (m->d_ovf) hipFree(m->d_ovf);
     if (m->d_stage) hipFree(m->d_stage);
+    if (m->h_pin) hipHostFree(m->h_pin);
+    for (int k = 0; k < PA_MAX_INFLIGHT; ++k) if (m->tk_ev[k]) hipEventDestroy(m->tk_ev[k]);
     delete m;
 }
 
@@ -878,7 +893,7 @@ enum { PROF_PRE = 100, PROF_DECODE = 101, PROF_NMS = 102 };
 // the caller's arrays (rows beyond max_det are never written on device).  oh x ow: the size upstream treats as the source
 // (the PIL-resized image on the stretch path).
 static int run_post(pa_model* m, const pa_yolo_params* p, int nb, int oh, int ow, size_t* ppi, float* out_boxes, float* out_kpts,
-                int32_t* out_counts) {
+                int32_t* out_counts, int ovf_slot) {
     pa_engine* e = m->e;
     hipStream_t s = e->stream;
     size_t& pi = *ppi;
@@ -913,7 +928,7 @@ static int run_post(pa_model* m, const pa_yolo_params* p, int nb, int oh, int ow
     if (r != hipSuccess) PA_FAIL(e, "nms launch failed: %s", hipGetErrorString(r));
     // ---- results back to the caller's arrays (rows beyond max_det are never written on device)
     if (m->d.dtype == PA_DTYPE_H2)      // the overflow flag travels with the results: pa_model_take_overflow needs no device round trip
-        PA_HIP(e, hipMemcpyAsync(&m->h_ovf_last, m->d_ovf, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        PA_HIP(e, hipMemcpyAsync(m->h_pin + ovf_slot, m->d_ovf, sizeof(unsigned), hipMemcpyDeviceToHost, s));
     PA_HIP(e, hipMemcpyAsync(out_counts, m->d_ocnt, nb * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PA_HIP(e, hipMemcpyAsync(out_boxes, m->d_oboxes,
                              (size_t)nb * p->max_det * 6 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -923,84 +938,147 @@ static int run_post(pa_model* m, const pa_yolo_params* p, int nb, int oh, int ow
     return 0;
 }
 
-int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
-                  float* out_boxes, float* out_kpts, int32_t* out_counts) {
-    if (!m || !p) return 1;
+// argument checks + plan of a pa_yolo_infer / pa_yolo_submit call, class filter upload
+static int yolo_prepare(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p, float* out_boxes,
+                        float* out_kpts, int32_t* out_counts, const char* who) {
     pa_engine* e = m->e;
-    if (m->d.task != PA_TASK_DETECT && m->d.task != PA_TASK_POSE) PA_FAIL(e, "pa_yolo_infer on a non-YOLO model");
-    if (!frames || n <= 0 || h <= 0 || w <= 0 || !out_boxes || !out_counts) PA_FAIL(e, "pa_yolo_infer: bad arguments");
-    if (m->d.nk && !out_kpts) PA_FAIL(e, "pa_yolo_infer: out_kpts is NULL for a pose model");
+    if (m->d.task != PA_TASK_DETECT && m->d.task != PA_TASK_POSE) PA_FAIL(e, "%s on a non-YOLO model", who);
+    if (!frames || n <= 0 || h <= 0 || w <= 0 || !out_boxes || !out_counts) PA_FAIL(e, "%s: bad arguments", who);
+    if (m->d.nk && !out_kpts) PA_FAIL(e, "%s: out_kpts is NULL for a pose model", who);
     if (p->max_det < 1 || p->max_det > 300) PA_FAIL(e, "max_det %d outside [1,300]", p->max_det);
     PA_HIP(e, hipSetDevice(e->dev));
     if (!m->planned || m->p_h0 != h || m->p_w0 != w || m->p_imgsz != p->imgsz || m->p_pre != p->pre_mode ||
-        m->p_auto != p->letterbox_auto || m->p_batch != m->max_batch)
+        m->p_auto != p->letterbox_auto || m->p_batch != m->max_batch) {
+        if (m->n_inflight) PA_FAIL(e, "%s: the plan would change (source size / imgsz / batch) with %d ticket(s) in flight", who, m->n_inflight);
         if (plan_yolo(m, h, w, p)) return 1;
-    hipStream_t s = e->stream;
-    if (p->n_classes > 0) {
-        if (p->n_classes > m->classes_cap) {
-            if (m->d_classes) hipFree(m->d_classes);
-            PA_HIP(e, hipMalloc((void**)&m->d_classes, p->n_classes * sizeof(int32_t)));
-            m->classes_cap = p->n_classes;
-        }
-        PA_HIP(e, hipMemcpyAsync(m->d_classes, p->classes, p->n_classes * sizeof(int32_t), hipMemcpyHostToDevice, s));
     }
+    if (p->n_classes > 0) {
+        const bool same = (int)m->classes_host.size() == p->n_classes && !memcmp(m->classes_host.data(), p->classes, p->n_classes * sizeof(int32_t));
+        if (!same) {
+            // (the device list is read by queued decode kernels: replace it only once they are done)
+            PA_HIP(e, hipStreamSynchronize(e->stream));
+            if (p->n_classes > m->classes_cap) {
+                if (m->d_classes) hipFree(m->d_classes);
+                PA_HIP(e, hipMalloc((void**)&m->d_classes, p->n_classes * sizeof(int32_t)));
+                m->classes_cap = p->n_classes;
+            }
+            m->classes_host.assign(p->classes, p->classes + p->n_classes);
+            PA_HIP(e, hipMemcpy(m->d_classes, m->classes_host.data(), p->n_classes * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+    }
+    return 0;
+}
+
+// everything one batch of nb <= max_batch frames needs, enqueued on the engine's stream: upload (host frames), preprocessing,
+// network, decode, NMS, result copies (the overflow flag of h2 models into h_pin[ovf_slot]).  Does not wait.
+static int yolo_enqueue(pa_model* m, const uint8_t* src, int nb, int h, int w, const pa_yolo_params* p, float* out_boxes,
+                        float* out_kpts, int32_t* out_counts, int ovf_slot, size_t* ppi) {
+    pa_engine* e = m->e;
+    hipStream_t s = e->stream;
+    size_t& pi = *ppi;
     const size_t frame_bytes = (size_t)h * w * 3;
     const int S = p->imgsz;
     // scale_boxes / scale_coords parameters (upstream treats the PIL-resized image as the source)
     const int oh = p->pre_mode == PA_PRE_PIL_STRETCH ? S : h, ow = p->pre_mode == PA_PRE_PIL_STRETCH ? S : w;
+    if (!p->frames_on_device) {
+        if (m->frames_cap < (size_t)nb * frame_bytes) {
+            if (m->d_frames) hipFree(m->d_frames);
+            m->frames_cap = (size_t)m->max_batch * frame_bytes;
+            PA_HIP(e, hipMalloc((void**)&m->d_frames, m->frames_cap));
+        }
+        PA_HIP(e, hipMemcpyAsync(m->d_frames, src, (size_t)nb * frame_bytes, hipMemcpyHostToDevice, s));
+        src = m->d_frames;
+    }
+    // ---- preprocessing -> u8 NHWC4 network input
+    ProfRec* pr = prof_begin(m, pi++, PROF_PRE, 0, 0.0);
+    hipError_t r = hipSuccess;
+    if (p->pre_mode == PA_PRE_LETTERBOX || (h == S && w == S)) {
+        LetterboxArgs a{};
+        a.src = src; a.dst = m->d_netin; a.B = nb; a.h0 = h; a.w0 = w; a.rw = m->rw; a.rh = m->rh;
+        a.top = m->top; a.left = m->left; a.nh = m->net_h; a.nw = m->net_w; a.mode = m->lb_mode;
+        a.reverse = p->channel_reverse; a.xtab = m->d_xtab; a.ytab = m->d_ytab;
+        r = launch_letterbox(a, s);
+    } else {
+        const uint8_t* cur = src; int ch = h, cw = w, cc = 3;
+        if (w != S) {
+            ResamplePassArgs a{};
+            const bool last = (h == S);
+            a.in = cur; a.out = last ? m->d_netin : m->d_tmp; a.B = nb; a.in_h = ch; a.in_w = cw; a.in_c = cc;
+            a.out_h = ch; a.out_w = S; a.out_c = last ? 4 : 3; a.vertical = 0; a.bounds = m->d_hb; a.coefs = m->d_hk;
+            a.ksize = m->hks; a.reverse = last ? p->channel_reverse : 0;
+            r = launch_resample_pass(a, s);
+            cur = m->d_tmp; cw = S;
+        }
+        if (r == hipSuccess && h != S) {
+            ResamplePassArgs a{};
+            a.in = cur; a.out = m->d_netin; a.B = nb; a.in_h = ch; a.in_w = cw; a.in_c = cc;
+            a.out_h = S; a.out_w = cw; a.out_c = 4; a.vertical = 1; a.bounds = m->d_vb; a.coefs = m->d_vk;
+            a.ksize = m->vks; a.reverse = p->channel_reverse;
+            r = launch_resample_pass(a, s);
+        }
+    }
+    prof_end(m, pr);
+    if (r != hipSuccess) PA_FAIL(e, "preprocess launch failed: %s", hipGetErrorString(r));
+    // ---- network
+    if (run_graph(m, nb, &pi)) return 1;
+    // ---- decode + NMS + results back to the caller's arrays
+    return run_post(m, p, nb, oh, ow, &pi, out_boxes, m->d.nk ? out_kpts : nullptr, out_counts, ovf_slot);
+}
+
+int pa_yolo_infer(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
+                  float* out_boxes, float* out_kpts, int32_t* out_counts) {
+    if (!m || !p) return 1;
+    pa_engine* e = m->e;
+    if (yolo_prepare(m, frames, n, h, w, p, out_boxes, out_kpts, out_counts, "pa_yolo_infer")) return 1;
+    hipStream_t s = e->stream;
+    const size_t frame_bytes = (size_t)h * w * 3;
     size_t pi = 0;
     for (int c0 = 0; c0 < n; c0 += m->max_batch) {
         const int nb = std::min(m->max_batch, n - c0);
-        const uint8_t* src = frames + (size_t)c0 * frame_bytes;
-        if (!p->frames_on_device) {
-            if (m->frames_cap < (size_t)nb * frame_bytes) {
-                if (m->d_frames) hipFree(m->d_frames);
-                m->frames_cap = (size_t)m->max_batch * frame_bytes;
-                PA_HIP(e, hipMalloc((void**)&m->d_frames, m->frames_cap));
-            }
-            PA_HIP(e, hipMemcpyAsync(m->d_frames, src, (size_t)nb * frame_bytes, hipMemcpyHostToDevice, s));
-            src = m->d_frames;
-        }
-        // ---- preprocessing -> u8 NHWC4 network input
-        ProfRec* pr = prof_begin(m, pi++, PROF_PRE, 0, 0.0);
-        hipError_t r = hipSuccess;
-        if (p->pre_mode == PA_PRE_LETTERBOX || (h == S && w == S)) {
-            LetterboxArgs a{};
-            a.src = src; a.dst = m->d_netin; a.B = nb; a.h0 = h; a.w0 = w; a.rw = m->rw; a.rh = m->rh;
-            a.top = m->top; a.left = m->left; a.nh = m->net_h; a.nw = m->net_w; a.mode = m->lb_mode;
-            a.reverse = p->channel_reverse; a.xtab = m->d_xtab; a.ytab = m->d_ytab;
-            r = launch_letterbox(a, s);
-        } else {
-            const uint8_t* cur = src; int ch = h, cw = w, cc = 3;
-            if (w != S) {
-                ResamplePassArgs a{};
-                const bool last = (h == S);
-                a.in = cur; a.out = last ? m->d_netin : m->d_tmp; a.B = nb; a.in_h = ch; a.in_w = cw; a.in_c = cc;
-                a.out_h = ch; a.out_w = S; a.out_c = last ? 4 : 3; a.vertical = 0; a.bounds = m->d_hb; a.coefs = m->d_hk;
-                a.ksize = m->hks; a.reverse = last ? p->channel_reverse : 0;
-                r = launch_resample_pass(a, s);
-                cur = m->d_tmp; cw = S;
-            }
-            if (r == hipSuccess && h != S) {
-                ResamplePassArgs a{};
-                a.in = cur; a.out = m->d_netin; a.B = nb; a.in_h = ch; a.in_w = cw; a.in_c = cc;
-                a.out_h = S; a.out_w = cw; a.out_c = 4; a.vertical = 1; a.bounds = m->d_vb; a.coefs = m->d_vk;
-                a.ksize = m->vks; a.reverse = p->channel_reverse;
-                r = launch_resample_pass(a, s);
-            }
-        }
-        prof_end(m, pr);
-        if (r != hipSuccess) PA_FAIL(e, "preprocess launch failed: %s", hipGetErrorString(r));
-        // ---- network
-        if (run_graph(m, nb, &pi)) return 1;
-        // ---- decode + NMS + results back to the caller's arrays
-        if (run_post(m, p, nb, oh, ow, &pi, out_boxes + (size_t)c0 * p->max_det * 6,
-                     m->d.nk ? out_kpts + (size_t)c0 * p->max_det * m->d.nk : nullptr, out_counts + c0)) return 1;
-        PA_HIP(e, hipStreamSynchronize(s));
+        if (yolo_enqueue(m, frames + (size_t)c0 * frame_bytes, nb, h, w, p, out_boxes + (size_t)c0 * p->max_det * 6,
+                         m->d.nk ? out_kpts + (size_t)c0 * p->max_det * m->d.nk : nullptr, out_counts + c0, PA_MAX_INFLIGHT, &pi))
+            return 1;
+        PA_HIP(e, hipStreamSynchronize(s));          // (also completes every ticket still in flight; their waits return at once)
         m->last_n = nb;
-        if (m->d.dtype == PA_DTYPE_H2) { m->h_ovf |= m->h_ovf_last; m->ovf_cached = true; }
+        if (m->d.dtype == PA_DTYPE_H2) { m->h_ovf |= m->h_pin[PA_MAX_INFLIGHT]; m->ovf_cached = true; }
     }
     finish_profile(m, pi);
+    return 0;
+}
+
+int pa_yolo_submit(pa_model* m, const uint8_t* frames, int n, int h, int w, const pa_yolo_params* p,
+                   float* out_boxes, float* out_kpts, int32_t* out_counts, int* ticket) {
+    if (!m || !p || !ticket) return 1;
+    pa_engine* e = m->e;
+    if (!p->frames_on_device) PA_FAIL(e, "pa_yolo_submit: frames must be in HBM (frames_on_device = 1)");
+    if (n > m->max_batch) PA_FAIL(e, "pa_yolo_submit: n = %d > max_batch %d", n, m->max_batch);
+    if (e->profiling || e->t.timeline) PA_FAIL(e, "pa_yolo_submit: not while profiling (use pa_yolo_infer)");
+    const int slot = m->next_ticket % PA_MAX_INFLIGHT;
+    if (m->tk_busy[slot]) PA_FAIL(e, "pa_yolo_submit: %d tickets in flight (PA_MAX_INFLIGHT)", PA_MAX_INFLIGHT);
+    if (yolo_prepare(m, frames, n, h, w, p, out_boxes, out_kpts, out_counts, "pa_yolo_submit")) return 1;
+    size_t pi = 0;
+    if (yolo_enqueue(m, frames, n, h, w, p, out_boxes, out_kpts, out_counts, slot, &pi)) return 1;
+    PA_HIP(e, hipEventRecord(m->tk_ev[slot], e->stream));
+    m->tk_busy[slot] = true;
+    ++m->n_inflight;
+    m->last_n = n;
+    m->n_prof = 0;
+    m->ovf_cached = false;
+    *ticket = m->next_ticket++;
+    return 0;
+}
+
+int pa_yolo_wait(pa_model* m, int ticket, int* overflow) {
+    if (!m) return 1;
+    pa_engine* e = m->e;
+    const int slot = ticket % PA_MAX_INFLIGHT;
+    if (ticket < 0 || ticket >= m->next_ticket || ticket + PA_MAX_INFLIGHT < m->next_ticket || !m->tk_busy[slot])
+        PA_FAIL(e, "pa_yolo_wait: ticket %d is not in flight", ticket);
+    PA_HIP(e, hipSetDevice(e->dev));
+    PA_HIP(e, hipEventSynchronize(m->tk_ev[slot]));
+    m->tk_busy[slot] = false;
+    --m->n_inflight;
+    if (overflow) *overflow = (m->d.dtype == PA_DTYPE_H2 && m->h_pin[slot]) ? 1 : 0;
     return 0;
 }
 
@@ -1033,7 +1111,7 @@ int pa_yolo_postprocess(pa_model* m, const float* const* heads, int n, int h, in
     const int S = p->imgsz;
     const int oh = p->pre_mode == PA_PRE_PIL_STRETCH ? S : h, ow = p->pre_mode == PA_PRE_PIL_STRETCH ? S : w;
     size_t pi = 0;
-    if (run_post(m, p, n, oh, ow, &pi, out_boxes, out_kpts, out_counts)) return 1;
+    if (run_post(m, p, n, oh, ow, &pi, out_boxes, out_kpts, out_counts, PA_MAX_INFLIGHT)) return 1;
     PA_HIP(e, hipStreamSynchronize(s));
     m->last_n = n;
     finish_profile(m, pi);

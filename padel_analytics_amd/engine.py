@@ -84,7 +84,7 @@ ABI_SYMBOLS = [
     "pa_engine_bcast", "pa_engine_allreduce_max",
     "pa_bytetrack_create", "pa_bytetrack_destroy", "pa_bytetrack_reset", "pa_bytetrack_update_batch",
     "pa_model_take_overflow", "pa_yolo_postprocess", "pa_host_register", "pa_host_unregister",
-    "pa_engine_bcast_weights_from", "pa_model_fill_arena",
+    "pa_engine_bcast_weights_from", "pa_model_fill_arena", "pa_yolo_submit", "pa_yolo_wait",
 ]
 
 
@@ -121,6 +121,8 @@ def load_library():
     lib.pa_model_destroy.restype = None
     lib.pa_model_set_max_batch.argtypes = [vp, i32]
     lib.pa_yolo_infer.argtypes = [vp, vp, i32, i32, i32, C.POINTER(pa_yolo_params), vp, vp, vp]
+    lib.pa_yolo_submit.argtypes = [vp, vp, i32, i32, i32, C.POINTER(pa_yolo_params), vp, vp, vp, C.POINTER(C.c_int)]
+    lib.pa_yolo_wait.argtypes = [vp, i32, C.POINTER(C.c_int)]
     lib.pa_yolo_head_shape.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.pa_yolo_read_head.argtypes = [vp, i32, i32, vp]
     lib.pa_tracknet_infer.argtypes = [vp, vp, i32, i32, i32, i32, vp, i32]
@@ -229,6 +231,7 @@ class Engine:
 
     def set_profiling(self, on: bool):
         self._check(self.lib.pa_engine_set_profiling(self.handle, 1 if on else 0))
+        self.profiling = bool(on)
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
@@ -298,6 +301,13 @@ def default_engine(device_id: Optional[int] = None) -> Engine:
     return _default_engines[device_id]
 
 
+_PAGE = 4096
+
+
+def _round_up(x: int, a: int) -> int:
+    return (int(x) + a - 1) // a * a
+
+
 class Model:
     """A graph + weights resident in HBM on one engine."""
 
@@ -324,37 +334,42 @@ class Model:
         self.max_batch = 64
         self._out_ring: dict = {}        # (n, max_det) -> [three page-locked (boxes, kpts, counts) sets, next slot]
 
-    #: result sets a ``yolo_infer(..., reuse_outputs=True)`` caller may hold at a time (the batch loop of the trackers holds two:
-    #: the batch in the host stage and the batch being inferred)
-    OUT_RING = 3
+    #: recycled result sets per (n, max_det).  The trackers' batch loop holds at most three at a time: the batch in the host
+    #: stage, the submitted batch being collected and the batch submitted behind it
+    OUT_RING = 4
 
     def _ring_outputs(self, n: int, max_det: int):
         key = (int(n), int(max_det))
         ring = self._out_ring.get(key)
         if ring is None:
             nk = self.graph.nk
+            sizes = [n * max_det * 6 * 4, n * max_det * nk * 4, n * 4]
+            offs = [0, _round_up(sizes[0], 64), 0]
+            offs[2] = offs[1] + _round_up(sizes[1], 64)
             sets = []
             for _ in range(self.OUT_RING):
-                arrs = (np.zeros((n, max_det, 6), np.float32), np.zeros((n, max_det, nk), np.float32) if nk else None,
-                        np.zeros((n,), np.int32))
-                for a in arrs:
-                    if a is not None:
-                        self.engine.pin(a)
-                sets.append(arrs)
+                # ONE page-aligned block of whole pages per set (hipHostRegister locks pages: small arrays that share a
+                # page cannot be registered / unregistered independently)
+                raw = np.zeros(_round_up(offs[2] + sizes[2], _PAGE) + _PAGE, np.uint8)
+                skip = (-raw.ctypes.data) % _PAGE
+                block = raw[skip:skip + _round_up(offs[2] + sizes[2], _PAGE)]
+                self.engine.pin(block)
+                boxes = block[offs[0]:offs[0] + sizes[0]].view(np.float32).reshape(n, max_det, 6)
+                kpts = block[offs[1]:offs[1] + sizes[1]].view(np.float32).reshape(n, max_det, nk) if nk else None
+                counts = block[offs[2]:offs[2] + sizes[2]].view(np.int32).reshape(n)
+                sets.append((boxes, kpts, counts, block))
             ring = self._out_ring[key] = [sets, 0]
         sets, i = ring
         ring[1] = (i + 1) % self.OUT_RING
-        return sets[i]
+        return sets[i][:3]
 
     def _free_rings(self):
         for sets, _ in self._out_ring.values():
             for arrs in sets:
-                for a in arrs:
-                    if a is not None:
-                        try:
-                            self.engine.unpin(a)
-                        except Exception:
-                            pass
+                try:
+                    self.engine.unpin(arrs[3])
+                except Exception:
+                    pass
         self._out_ring = {}
 
     def set_max_batch(self, n: int):
@@ -397,6 +412,38 @@ class Model:
             self.handle, ptr, n, h, w, C.byref(p), boxes.ctypes.data,
             kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
         return boxes, kpts, counts
+
+    #: tickets a model may have in flight (PA_MAX_INFLIGHT of include/padel_hip.h)
+    MAX_INFLIGHT = 4
+
+    def yolo_submit(self, frames: "DeviceBuffer", n: int, h: int, w: int, *, imgsz: int, conf: float, iou: float,
+                    classes: Optional[Sequence[int]] = None, max_det: int = 300, pre_mode: int = PRE_LETTERBOX,
+                    channel_reverse: bool = False, letterbox_auto: bool = True):
+        """``yolo_infer`` in two halves (pa_yolo_submit / pa_yolo_wait): enqueue the whole call behind what the engine's stream
+        still holds and return a ticket at once; ``yolo_wait(ticket)`` -> (boxes, kpts, counts, overflow).  Frames must be in
+        HBM; the results land in one of the model's recycled page-locked sets (``reuse_outputs`` rules).  Submit batch k + 1
+        before waiting for batch k and the GPU never waits for the host between batches."""
+        assert isinstance(frames, DeviceBuffer) and frames.nbytes >= n * h * w * 3
+        cls_arr = None
+        p = pa_yolo_params(imgsz=imgsz, pre_mode=pre_mode, channel_reverse=int(channel_reverse),
+                           letterbox_auto=int(letterbox_auto), conf=conf, iou=iou, max_det=max_det,
+                           n_classes=0, classes=None, frames_on_device=1)
+        if classes is not None and len(classes):
+            cls_arr = (C.c_int32 * len(classes))(*[int(c) for c in classes])
+            p.n_classes = len(classes)
+            p.classes = cls_arr
+        boxes, kpts, counts = self._ring_outputs(n, max_det)
+        t = C.c_int(-1)
+        self.engine._check(self.engine.lib.pa_yolo_submit(
+            self.handle, frames.ptr, n, h, w, C.byref(p), boxes.ctypes.data,
+            kpts.ctypes.data if kpts is not None else None, counts.ctypes.data, C.byref(t)))
+        return (t.value, boxes, kpts, counts)
+
+    def yolo_wait(self, ticket):
+        t, boxes, kpts, counts = ticket
+        ovf = C.c_int(0)
+        self.engine._check(self.engine.lib.pa_yolo_wait(self.handle, t, C.byref(ovf)))
+        return boxes, kpts, counts, bool(ovf.value)
 
     def head_shapes(self, h: int, w: int, imgsz: int, pre_mode: int = PRE_LETTERBOX) -> list:
         """[(H_l, W_l, c)] of the three head maps for source size h x w (host arithmetic of the planner)."""

@@ -58,6 +58,15 @@ class BallDetectTracker(Tracker):
                                                             max_det=1, channel_reverse=False, reuse_outputs=self._reuse_outputs)
         return boxes, counts
 
+    def submit_sample(self, sample, **kwargs):
+        if not hasattr(self.model, "submit_frames"):
+            return None
+        return self.model.submit_frames(sample, self.CONF, self.IOU, self.IMGSZ, classes=None, max_det=1, channel_reverse=False)
+
+    def collect_sample(self, token):
+        boxes, _, counts, _, _, _ = self.model.collect_frames(token)
+        return boxes, counts
+
     @staticmethod
     def top1_to_xyv(boxes: np.ndarray, counts: np.ndarray) -> list:
         """(n, >=1, 6) boxes + (n,) counts -> [(x, y, visibility)]: centre of the best box, (0, 0, 0) without one."""

@@ -148,6 +148,20 @@ class PlayerKeypointsTracker(Tracker):
                                                           channel_reverse=True, pil_stretch=True, reuse_outputs=self._reuse_outputs)
         return kpts, counts, (h_frame, w_frame)
 
+    def submit_sample(self, sample, **kwargs):
+        sample = sample if isinstance(sample, (list, np.ndarray)) else list(sample)
+        if not hasattr(self.model, "submit_frames"):
+            return None
+        token = self.model.submit_frames(sample, self.CONF, self.IOU, self.train_image_size, classes=[0], channel_reverse=True,
+                                         pil_stretch=True)
+        if token is not None:
+            token["frame_hw"] = sample[0].shape[:2]
+        return token
+
+    def collect_sample(self, token):
+        _, kpts, counts, _, _, _ = self.model.collect_frames(token)
+        return kpts, counts, tuple(token["frame_hw"])
+
     def post_sample(self, raw, **kwargs) -> list:
         kpts, counts, (h_frame, w_frame) = raw
         ratio = (w_frame / self.train_image_size, h_frame / self.train_image_size)     # reference :276-278

@@ -164,6 +164,15 @@ class PlayerTracker(Tracker):
                                                             channel_reverse=False, reuse_outputs=self._reuse_outputs)
         return boxes, counts
 
+    def submit_sample(self, sample, **kwargs):
+        if not hasattr(self.model, "submit_frames"):
+            return None
+        return self.model.submit_frames(sample, self.CONF, self.IOU, self.IMGSZ, classes=[0], channel_reverse=False)
+
+    def collect_sample(self, token):
+        boxes, _, counts, _, _, _ = self.model.collect_frames(token)
+        return boxes, counts
+
     # ---- host stage, split in the stateless part (zone) and the sequential part (ByteTrack)
     def _zone_keep(self, boxes: np.ndarray, counts: np.ndarray) -> np.ndarray:
         """(n, max_det) bool: rows that exist and (with a zone) whose bottom-centre anchor lies inside it

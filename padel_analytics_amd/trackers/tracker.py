@@ -193,6 +193,14 @@ class Tracker(ABC):
     def post_sample(self, raw, **kwargs) -> list:
         raise NotImplementedError
 
+    # ---- optional two-call form of infer_sample: submit_sample enqueues the device stage and returns a token at once (None:
+    # not possible for this sample — use infer_sample), collect_sample(token) returns what infer_sample would have
+    def submit_sample(self, sample: list, **kwargs):
+        return None
+
+    def collect_sample(self, token):
+        raise NotImplementedError
+
     def _has_stages(self) -> bool:
         return type(self).infer_sample is not Tracker.infer_sample and type(self).post_sample is not Tracker.post_sample
 
@@ -208,17 +216,32 @@ class Tracker(ABC):
         # a whole device stage of the small models): a short interval for the duration of the loop
         interval = sys.getswitchinterval()
         sys.setswitchinterval(min(interval, 2e-4))
-        # at most two result sets are alive here (the batch in the host stage, the batch being inferred): the device stage may
-        # hand out the model's recycled page-locked arrays (engine.Model.yolo_infer(reuse_outputs=True))
+        # at most three result sets are alive here (the batch in the host stage, the submitted batch being collected, the batch
+        # submitted behind it): the device stage may hand out the model's recycled page-locked arrays (engine.Model.OUT_RING)
         self._reuse_outputs = True
         try:
             with ThreadPoolExecutor(max_workers=1) as pool:
                 pending = []
-                for sample in _sampler(frame_generator, self.batch_size):
-                    raw = self.infer_sample(sample, **kwargs)
+
+                def host_stage(raw):
                     pending.append(pool.submit(self.post_sample, raw, **kwargs))
                     while len(pending) > 1:                 # keep one host stage in flight behind the device stage
                         update(pending.pop(0).result())
+
+                # Trackers with the two-call device stage (submit_sample / collect_sample: pa_yolo_submit / pa_yolo_wait) have
+                # batch k + 1 queued on the GPU before batch k is collected; the others run one synchronous call per batch.
+                submitted = None
+                for sample in _sampler(frame_generator, self.batch_size):
+                    token = self.submit_sample(sample, **kwargs)
+                    if submitted is not None:
+                        host_stage(self.collect_sample(submitted))
+                        submitted = None
+                    if token is None:
+                        host_stage(self.infer_sample(sample, **kwargs))
+                    else:
+                        submitted = token
+                if submitted is not None:
+                    host_stage(self.collect_sample(submitted))
                 for f in pending:
                     update(f.result())
         finally:

@@ -204,6 +204,40 @@ class YOLO:
             boxes, kpts, counts = self._ensure_model().yolo_infer(src, n, h, w, **kw)
         return boxes, kpts, counts, (h, w), int(imgsz), pre_mode
 
+    # ---- the device stage in two halves (pa_yolo_submit / pa_yolo_wait): the trackers' batch loops submit batch k + 1 before
+    # collecting batch k, so the GPU does not idle while the host unpacks results and prepares the next call
+    def submit_frames(self, frames, conf, iou, imgsz, classes=None, max_det=300, *, channel_reverse: bool,
+                      pil_stretch: bool = False):
+        """-> a token for ``collect_frames``, or None when the two-call form does not apply (frames not in HBM, profiling
+        on, a fake engine): the caller then uses ``infer_frames``."""
+        from . import video
+        dev = None if isinstance(frames, np.ndarray) else video.device_batch(frames)
+        m = self._ensure_model()
+        if dev is None or not hasattr(m, "yolo_submit") or getattr(m.engine, "profiling", False):
+            return None
+        src, n, h, w = dev
+        if n > m.max_batch:
+            return None
+        pre_mode = E.PRE_PIL_STRETCH if pil_stretch else E.PRE_LETTERBOX
+        ticket = m.yolo_submit(src, n, h, w, imgsz=int(imgsz), conf=float(conf), iou=float(iou), classes=classes,
+                               max_det=int(max_det), pre_mode=pre_mode, channel_reverse=channel_reverse, letterbox_auto=True)
+        return dict(ticket=ticket, model=m, frames=frames, args=(conf, iou, imgsz, classes, max_det),
+                    kw=dict(channel_reverse=channel_reverse, pil_stretch=pil_stretch), ret=((h, w), int(imgsz), pre_mode))
+
+    def collect_frames(self, token) -> tuple:
+        """Results of a ``submit_frames`` token, in ``infer_frames``' form.  If an activation left the fp16 range (now or in
+        an earlier ticket, which replaced the model) the batch is computed again on the bf16x3 model, like ``infer_frames``."""
+        m = token["model"]
+        if m is not self._model:                     # the model this was submitted to is gone (overflow fallback in between)
+            return self.infer_frames(token["frames"], *token["args"], reuse_outputs=True, **token["kw"])
+        boxes, kpts, counts, ovf = m.yolo_wait(token["ticket"])
+        if ovf and self.graph.dtype == G.DTYPE_H2:
+            print(f"padel_analytics_amd: activations beyond the fp16 range — switching this model to the bf16x3 path")
+            self.set_fp32_mode("bx3")                # (closing the model drains its stream: later tickets die with it)
+            self.fell_back = True
+            return self.infer_frames(token["frames"], *token["args"], reuse_outputs=True, **token["kw"])
+        return (boxes, kpts, counts) + token["ret"]
+
     def _run(self, frames: np.ndarray, conf, iou, imgsz, classes, max_det, pre_mode, reverse) -> list:
         return self._results(*self.infer_frames(frames, conf, iou, imgsz, classes, max_det, channel_reverse=reverse,
                                                 pil_stretch=pre_mode == E.PRE_PIL_STRETCH))

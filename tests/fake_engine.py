@@ -123,6 +123,22 @@ class FakeModel:
         return boxes, kpts, counts
 
 
+def _fake_submit(self, frames, n, h, w, **kw):
+    """pa_yolo_submit / pa_yolo_wait stand-ins: the "device" work happens at submit, the ticket carries the results."""
+    self._tickets = getattr(self, "_tickets", 0) + 1
+    LOG.append("submit") if not any(x == "submit" for x in LOG) else None
+    return (self._tickets,) + tuple(self.yolo_infer(frames, n, h, w, **kw))
+
+
+def _fake_wait(self, ticket):
+    return ticket[1], ticket[2], ticket[3], False
+
+
+FakeModel.yolo_submit = _fake_submit
+FakeModel.yolo_wait = _fake_wait
+FakeEngine.profiling = False
+
+
 def install():
     """Point the engine module (and everything that resolves names through it) at the fakes."""
     from padel_analytics_amd import engine as E
