@@ -14,6 +14,7 @@
 #   tiles         tools/conv_bench.py --dtype h2 --tiles $TILES (default auto,T323,T303) on $SWEEP_ARGS shapes
 #   tests_sel     python -m pytest $PYTEST_SEL -m gpu (any selection)
 #   bench_c2q / bench_c4q   the other configs with --quick --steps 5 (runner + engine-only + roofline only)
+#   bench_c2d / bench_c4d   the same with the driver's --steps 20 --warmup 5
 #   tests_post    ball / known-answer (decode, NMS) / runner / bench-config suites
 #   bench_driver  the driver's command line: python bench.py --gpus 1 --steps 20 --warmup 5
 #   tests_f16     the fp16 kernel tests + BASELINE configs[0] / [3] / [4] tests
@@ -69,6 +70,12 @@ for stage in "$@"; do
     tests_sel)
       timeout 1200 python -m pytest ${PYTEST_SEL:-tests} -m gpu -q --maxfail=5 > "$OUT/pytest_sel.txt" 2>&1; note $stage $?
       grep -E "passed|failed|FAILED|Error" "$OUT/pytest_sel.txt" | tail -12 ;;
+    bench_c2d)
+      timeout 600 python bench.py --workload c2 --steps 20 --warmup 5 --quick --dump-ops "$OUT/ops_c2.csv" > "$OUT/bench_c2.json" 2> "$OUT/bench_c2.err"; note $stage $?
+      python tools/bench_summary.py "$OUT/bench_c2.json" ;;
+    bench_c4d)
+      timeout 600 python bench.py --workload c4 --steps 20 --warmup 5 --quick --dump-ops "$OUT/ops_c4.csv" > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"; note $stage $?
+      python tools/bench_summary.py "$OUT/bench_c4.json" ;;
     bench_c2q)
       timeout 600 python bench.py --workload c2 --steps 5 --warmup 2 --quick > "$OUT/bench_c2_quick.json" 2> "$OUT/bench_c2_quick.err"; note $stage $?
       python tools/bench_summary.py "$OUT/bench_c2_quick.json" ;;
