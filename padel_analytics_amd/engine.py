@@ -308,6 +308,32 @@ def _round_up(x: int, a: int) -> int:
     return (int(x) + a - 1) // a * a
 
 
+class _PinnedBlock:
+    """Whole pages of host memory, page-locked for one engine (hipHostRegister locks pages: small arrays that share a page
+    cannot be registered / unregistered independently).  Unregistered by ``release()`` or when the object dies — always
+    before the memory itself can be freed, which the views handed out keep alive."""
+
+    def __init__(self, engine, nbytes: int):
+        size = _round_up(max(int(nbytes), 1), _PAGE)
+        self._raw = np.zeros(size + _PAGE, np.uint8)
+        skip = (-self._raw.ctypes.data) % _PAGE
+        self.block = self._raw[skip:skip + size]
+        self.engine = engine
+        engine.pin(self.block)
+        self._pinned = True
+
+    def release(self) -> None:
+        if self._pinned:
+            self._pinned = False
+            try:
+                self.engine.unpin(self.block)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self.release()
+
+
 class Model:
     """A graph + weights resident in HBM on one engine."""
 
@@ -348,16 +374,12 @@ class Model:
             offs[2] = offs[1] + _round_up(sizes[1], 64)
             sets = []
             for _ in range(self.OUT_RING):
-                # ONE page-aligned block of whole pages per set (hipHostRegister locks pages: small arrays that share a
-                # page cannot be registered / unregistered independently)
-                raw = np.zeros(_round_up(offs[2] + sizes[2], _PAGE) + _PAGE, np.uint8)
-                skip = (-raw.ctypes.data) % _PAGE
-                block = raw[skip:skip + _round_up(offs[2] + sizes[2], _PAGE)]
-                self.engine.pin(block)
+                pb = _PinnedBlock(self.engine, offs[2] + sizes[2])
+                block = pb.block
                 boxes = block[offs[0]:offs[0] + sizes[0]].view(np.float32).reshape(n, max_det, 6)
                 kpts = block[offs[1]:offs[1] + sizes[1]].view(np.float32).reshape(n, max_det, nk) if nk else None
                 counts = block[offs[2]:offs[2] + sizes[2]].view(np.int32).reshape(n)
-                sets.append((boxes, kpts, counts, block))
+                sets.append((boxes, kpts, counts, pb))
             ring = self._out_ring[key] = [sets, 0]
         sets, i = ring
         ring[1] = (i + 1) % self.OUT_RING
@@ -366,11 +388,17 @@ class Model:
     def _free_rings(self):
         for sets, _ in self._out_ring.values():
             for arrs in sets:
-                try:
-                    self.engine.unpin(arrs[3])
-                except Exception:
-                    pass
+                arrs[3].release()
         self._out_ring = {}
+
+    def __del__(self):
+        # a model dropped without close(): its page-locked result blocks must be unregistered BEFORE their memory goes back
+        # to the allocator (a stale registration makes later copies to / from whatever reuses those pages fail)
+        # (only that: destroying the HBM side here could outlive its engine)
+        try:
+            self._free_rings()
+        except Exception:
+            pass
 
     def set_max_batch(self, n: int):
         self.engine._check(self.engine.lib.pa_model_set_max_batch(self.handle, int(n)))
