@@ -1,0 +1,79 @@
+"""Tracker._predict_batches (host logic, no GPU): the device stage in two halves — batch k + 1 submitted before batch k is
+collected — keeps batch order, bounds the number of live result sets, mixes with batches that have to take the synchronous
+call, and a tracker without the two-call form runs as before."""
+import numpy as np
+
+from padel_analytics_amd.trackers.tracker import NoPredictFrames, Tracker
+
+
+class _Toy(Tracker):
+    """Frames are integers; a 'detection' is frame * 10.  submit_sample declines every batch whose first frame is in `sync`."""
+    batch_size = 4
+    streams = False
+
+    def __init__(self, two_call=True, sync=()):
+        super().__init__()
+        self.two_call, self.sync = two_call, set(sync)
+        self.log, self.live, self.max_live = [], 0, 0
+
+    def video_info_post_init(self, video_info): return self
+    def object(self): return int
+    def draw_kwargs(self): return {}
+    def __str__(self): return "toy"
+    def restart(self): self.results.restart()
+    def predict_sample(self, sample, **kw): return self.post_sample(self.infer_sample(sample))
+    def predict_frames(self, frame_generator, **kw): raise NoPredictFrames()
+
+    def _take(self):
+        self.live += 1
+        self.max_live = max(self.max_live, self.live)
+
+    def infer_sample(self, sample, **kw):
+        assert self._reuse_outputs
+        self.log.append(("infer", sample[0]))
+        self._take()
+        return list(sample)
+
+    def submit_sample(self, sample, **kw):
+        if not self.two_call or sample[0] in self.sync:
+            return None
+        self.log.append(("submit", sample[0]))
+        self._take()
+        return {"sample": list(sample)}
+
+    def collect_sample(self, token):
+        self.log.append(("collect", token["sample"][0]))
+        return token["sample"]
+
+    def post_sample(self, raw, **kw):
+        out = [f * 10 for f in raw]
+        self.live -= 1
+        return out
+
+
+def test_two_call_loop_keeps_order_and_submits_ahead():
+    t = _Toy()
+    t.predict_and_update(iter(range(18)))                      # 4 + 4 + 4 + 4 + 2
+    assert t.results.predictions == [f * 10 for f in range(18)]
+    ev = t.log
+    assert ev[:3] == [("submit", 0), ("submit", 4), ("collect", 0)]            # batch 1 is queued before batch 0 is collected
+    assert [e for e in ev if e[0] == "collect"] == [("collect", f) for f in (0, 4, 8, 12, 16)]
+    for k in (4, 8, 12, 16):
+        assert ev.index(("submit", k)) < ev.index(("collect", k - 4))
+    assert t.max_live <= 3 and not t._reuse_outputs            # what engine.Model.OUT_RING = 4 has to cover
+
+
+def test_batches_that_decline_the_two_call_form_run_synchronously_in_place():
+    t = _Toy(sync={4, 12})
+    t.predict_and_update(iter(range(20)))
+    assert t.results.predictions == [f * 10 for f in range(20)]
+    assert ("infer", 4) in t.log and ("infer", 12) in t.log and ("submit", 4) not in t.log
+    assert t.log.index(("collect", 0)) < t.log.index(("infer", 4)) < t.log.index(("submit", 8))
+    assert t.max_live <= 3
+
+
+def test_tracker_without_the_two_call_form():
+    t = _Toy(two_call=False)
+    t.predict_and_update(iter(range(9)))
+    assert t.results.predictions == [f * 10 for f in range(9)]
+    assert [e[0] for e in t.log] == ["infer"] * 3
