@@ -470,7 +470,10 @@ def main():
             "parallelism": f"frames sharded by batch over {world} GPU(s), one-time RCCL weight broadcast inside libpadel_hip.so",
             "inputs": "uint8 BGR clip resident in HBM; result objects (Players / Ball / PlayersKeypoints) on the host",
             "timed_path": "TrackingRunner.run(): PlayerTracker (+PolygonZone +ByteTrack) -> BallDetectTracker -> "
-                          "PlayerKeypointsTracker, sequential over trackers like trackers/runner.py:185",
+                          "PlayerKeypointsTracker, sequential over trackers like trackers/runner.py:185; within a tracker the "
+                          "device stage of batch k + 1 is queued (pa_yolo_submit) before batch k is collected (pa_yolo_wait) and the "
+                          "host stage of batch k (PolygonZone, ByteTrack, containers) runs on a worker thread behind it — every batch's "
+                          "work, results included, is inside the timed region",
         },
     }
 
