@@ -95,10 +95,9 @@ class BallDetectTracker(Tracker):
     # sharded: frame numbers are global, assigned on rank 0 after the gather
     def predict_partial(self, frame_generator, *, first_frame: int = 0, head_context: int = 0, tail_context: int = 0,
                         **kwargs) -> list:
-        from .tracker import _sampler
         out = []
-        for sample in _sampler(frame_generator, self.batch_size):
-            out += self.top1_to_xyv(*self.infer_sample(sample))
+        for raw in self._raw_batches(frame_generator):
+            out += self.top1_to_xyv(*raw)
         return out
 
     def merge_partials(self, partials: list, **kwargs) -> list:

@@ -212,10 +212,8 @@ class PlayerTracker(Tracker):
     def predict_partial(self, frame_generator, *, first_frame: int = 0, head_context: int = 0, tail_context: int = 0,
                         **kwargs) -> list:
         assert head_context == 0 and tail_context == 0
-        from .tracker import _sampler
         out = []
-        for sample in _sampler(frame_generator, self.batch_size):
-            boxes, counts = self.infer_sample(sample)
+        for boxes, counts in self._raw_batches(frame_generator):     # (boolean indexing copies: nothing of a batch's arrays is kept)
             keep = self._zone_keep(boxes, counts)
             out += [boxes[i, keep[i]] for i in range(len(counts))]
         return out

@@ -248,6 +248,27 @@ class Tracker(ABC):
             self._reuse_outputs = False
             sys.setswitchinterval(interval)
 
+    def _raw_batches(self, frame_generator, **kwargs):
+        """Yield ``infer_sample``'s result for every batch of the stream, in order — with the next batch already submitted
+        (``submit_sample``) where the tracker has the two-call device stage.  For loops that finish with a batch's arrays
+        before asking for the next one (sharded ``predict_partial``): at most two result sets are alive."""
+        self._reuse_outputs = True
+        try:
+            submitted = None
+            for sample in _sampler(frame_generator, self.batch_size):
+                token = self.submit_sample(sample, **kwargs)
+                if submitted is not None:
+                    yield self.collect_sample(submitted)
+                    submitted = None
+                if token is None:
+                    yield self.infer_sample(sample, **kwargs)
+                else:
+                    submitted = token
+            if submitted is not None:
+                yield self.collect_sample(submitted)
+        finally:
+            self._reuse_outputs = False
+
     def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:
         try:
             predictions = self.predict_frames(frame_generator, **kwargs)

@@ -126,7 +126,8 @@ class FakeModel:
 def _fake_submit(self, frames, n, h, w, **kw):
     """pa_yolo_submit / pa_yolo_wait stand-ins: the "device" work happens at submit, the ticket carries the results."""
     self._tickets = getattr(self, "_tickets", 0) + 1
-    LOG.append("submit") if not any(x == "submit" for x in LOG) else None
+    if "submit" not in LOG:
+        LOG.append("submit")
     return (self._tickets,) + tuple(self.yolo_infer(frames, n, h, w, **kw))
 
 

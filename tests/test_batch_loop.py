@@ -77,3 +77,13 @@ def test_tracker_without_the_two_call_form():
     t.predict_and_update(iter(range(9)))
     assert t.results.predictions == [f * 10 for f in range(9)]
     assert [e[0] for e in t.log] == ["infer"] * 3
+
+
+def test_raw_batches_for_sharded_loops():
+    t = _Toy(sync={8})
+    got = []
+    for raw in t._raw_batches(iter(range(14))):
+        got += raw
+        t.live -= 1                                           # the consumer is done with the batch before asking for the next
+    assert got == list(range(14)) and t.max_live <= 2 and not t._reuse_outputs
+    assert t.log.index(("submit", 4)) < t.log.index(("collect", 0)) < t.log.index(("infer", 8)) < t.log.index(("submit", 12))

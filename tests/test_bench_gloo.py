@@ -52,3 +52,5 @@ def test_bench_main_world2_gloo_fake_engine(tmp_path):
     assert sum("bcast root=0 had_weights=False" in x for x in r1["log"]) == 3 and sum("bcast root=0 had_weights=True" in x for x in r0["log"]) == 3
     assert any("comm_init nranks=2 rank=1" in x for x in r1["log"])
     assert r1["weight_checksums"] == r0["weight_checksums"] and all(v != 0 for v in r0["weight_checksums"].values())
+    # the sharded runner's device stage goes through the two-call form (submit_sample / collect_sample -> yolo_submit / yolo_wait)
+    assert "submit" in r0["log"] and "submit" in r1["log"]
