@@ -12,7 +12,8 @@
  *                                                                              -> pa_tracknet_infer()
  *
  * Conventions: plain pointers and sizes only; the caller owns every buffer and the
- * library never keeps a caller pointer past return; every call is synchronous at this boundary; one
+ * library never keeps a caller pointer past return; every call is synchronous at this boundary (the one
+ * exception to both: the pa_yolo_submit / pa_yolo_wait pair below); one
  * engine per GPU, not thread-safe; return 0 on success, non-zero on failure with the message in
  * pa_last_error().  The Python binding (`padel_analytics_amd/engine.py`, ctypes) is the only caller.
  */
