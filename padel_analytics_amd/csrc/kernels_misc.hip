@@ -418,6 +418,45 @@ __global__ void __launch_bounds__(NT) sppf_h2_kernel(float* buf, int cs, int cho
         __syncthreads();
     }
 }
+// The same for fp16 buffers (8 channels = one 16-byte vector per pixel and workgroup).  OPT-IN (tuning fuse_sppf >= 5), written
+// at the end of round 4 and NOT yet run on a GPU: the fp16 graphs keep their three pool5_kernel launches until it has been
+// measured (c4: 0.35 ms per step in the three launches).
+template <int NT>
+__global__ void __launch_bounds__(NT) sppf_f16_kernel(_Float16* buf, int cs, int choff, int c, int B, int H, int W) {
+    extern __shared__ unsigned long long sppf_lds[];
+    const int HW = H * W;
+    const float inv_w = 1.0f / (float)W;
+    f16x8* X = reinterpret_cast<f16x8*>(sppf_lds);
+    f16x8* T = X + HW;
+    const int nu = c / 8;
+    const int u = blockIdx.x % nu, n = blockIdx.x / nu;
+    if (n >= B) return;
+    _Float16* base = buf + (long long)n * HW * cs + choff + u * 8;
+    for (int p = threadIdx.x; p < HW; p += NT) X[p] = *reinterpret_cast<const f16x8*>(base + (long long)p * cs);
+    __syncthreads();
+    for (int level = 1; level <= 3; ++level) {
+        for (int p = threadIdx.x; p < HW; p += NT) {
+            const int y = (int)(((float)p + 0.5f) * inv_w), x = p - y * W;
+            f16x8 m = X[p];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d) m = vmax(m, X[y * W + min(max(x + d, 0), W - 1)]);
+            T[p] = m;
+        }
+        __syncthreads();
+        _Float16* ob = base + level * c;
+        for (int p = threadIdx.x; p < HW; p += NT) {
+            const int y = (int)(((float)p + 0.5f) * inv_w), x = p - y * W;
+            f16x8 m = T[p];
+#pragma unroll
+            for (int d = -2; d <= 2; ++d)
+                if (d) m = vmax(m, T[min(max(y + d, 0), H - 1) * W + x]);
+            X[p] = m;
+            *reinterpret_cast<f16x8*>(ob + (long long)p * cs) = m;
+        }
+        __syncthreads();
+    }
+}
 __global__ void __launch_bounds__(256) maxpool2_h2_kernel(const float* in, int in_cs, int in_choff, float* out, int out_cs, int out_choff,
                                                            int un, int B, int H, int W) {
     const int Ho = H / 2, Wo = W / 2;
@@ -491,6 +530,21 @@ hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, 
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
+    }
+    if (f16 == 1 && fused >= 5 && !((c | choff | cs) & 7) && (size_t)2 * H * W * 16 <= kSppfMaxLds && (long long)B * (c / 8) < (1ll << 31)) {
+        const size_t lds = (size_t)2 * H * W * 16;
+        const dim3 grid((unsigned)(B * (c / 8)));
+        _Float16* hb = reinterpret_cast<_Float16*>(buf);
+        static bool attr_set = false;                // (opt-in path: its LDS limit is raised at first use, not at engine creation)
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_f16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_f16_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        if (H * W > 1024) hipLaunchKernelGGL(sppf_f16_kernel<1024>, grid, dim3(1024), lds, s, hb, cs, choff, c, B, H, W);
+        else hipLaunchKernelGGL(sppf_f16_kernel<256>, grid, dim3(256), lds, s, hb, cs, choff, c, B, H, W);
+        return hipGetLastError();
     }
     const int vn = f16 ? 8 : 4;
     const long long total = (long long)B * H * W * (c / vn);

@@ -170,3 +170,30 @@ def test_fp16_graph_vs_emulation_and_fp32_oracle(gpu_engine, scale, nc, kpt, hw,
         old[f"{scale}-nc{nc}-{'pose' if kpt else 'detect'}-{S}"] = rep
         json.dump(old, open(p, "w"), indent=1)
     assert rep["rms_px"] < 4.0, rep
+
+
+@pytest.mark.skipif(__import__("os").environ.get("PADEL_TEST_SPPF_F16") != "1",
+                    reason="opt-in: the fp16 form of the fused SPPF kernel (tuning fuse_sppf=5) was written at the end of round 4 and has not run on a GPU yet")
+def test_fused_sppf_fp16_matches_three_pool_launches(gpu_engine):
+    """First contact of sppf_f16_kernel: same head maps (as numbers: a maximum does not depend on the walk, the sign of a zero
+    may) and the same detections as the three pool5_kernel launches."""
+    from padel_analytics_amd import yolo_arch
+    from tests import synth
+    for scale, (h, w), imgsz in (("n", (360, 640), 640), ("m", (720, 1280), 1280)):
+        frames = synth.synthetic_frames(2, h, w, seed=12)
+        sd = yolo_arch.synth_state_dict(scale, 80, None, seed=5, cls_bias=-1.0)
+        m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None, dtype="f16"))
+        m.set_max_batch(2)
+        try:
+            gpu_engine.set_tuning(fuse_sppf=1)
+            b0, _, c0 = m.yolo_infer(frames, 2, h, w, imgsz=imgsz, conf=0.25, iou=0.7)
+            h0 = [m.read_head(l, 2) for l in range(3)]
+            gpu_engine.set_tuning(fuse_sppf=5)
+            b1, _, c1 = m.yolo_infer(frames, 2, h, w, imgsz=imgsz, conf=0.25, iou=0.7)
+            h1 = [m.read_head(l, 2) for l in range(3)]
+        finally:
+            gpu_engine.set_tuning(fuse_sppf=1)
+            m.close()
+        for l in range(3):
+            assert np.array_equal(h0[l], h1[l]), f"{scale}: head {l} differs"
+        assert np.array_equal(c0, c1) and np.array_equal(b0, b1) and int(c0.sum()) > 0
