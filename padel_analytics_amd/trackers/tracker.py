@@ -219,6 +219,7 @@ class Tracker(ABC):
         # at most three result sets are alive here (the batch in the host stage, the submitted batch being collected, the batch
         # submitted behind it): the device stage may hand out the model's recycled page-locked arrays (engine.Model.OUT_RING)
         self._reuse_outputs = True
+        submitted = None                                    # the token of the batch that is queued on the GPU and not collected yet
         try:
             with ThreadPoolExecutor(max_workers=1) as pool:
                 pending = []
@@ -230,44 +231,63 @@ class Tracker(ABC):
 
                 # Trackers with the two-call device stage (submit_sample / collect_sample: pa_yolo_submit / pa_yolo_wait) have
                 # batch k + 1 queued on the GPU before batch k is collected; the others run one synchronous call per batch.
-                submitted = None
                 for sample in _sampler(frame_generator, self.batch_size):
                     token = self.submit_sample(sample, **kwargs)
                     if submitted is not None:
-                        host_stage(self.collect_sample(submitted))
-                        submitted = None
+                        done, submitted = submitted, token       # (what is in flight is always in `submitted`: the finally drains it)
+                        host_stage(self.collect_sample(done))
+                        if token is None:
+                            host_stage(self.infer_sample(sample, **kwargs))
+                        continue
                     if token is None:
                         host_stage(self.infer_sample(sample, **kwargs))
                     else:
                         submitted = token
                 if submitted is not None:
-                    host_stage(self.collect_sample(submitted))
+                    token, submitted = submitted, None
+                    host_stage(self.collect_sample(token))
                 for f in pending:
                     update(f.result())
         finally:
             self._reuse_outputs = False
             sys.setswitchinterval(interval)
+            self._drain(submitted)
 
     def _raw_batches(self, frame_generator, **kwargs):
         """Yield ``infer_sample``'s result for every batch of the stream, in order — with the next batch already submitted
         (``submit_sample``) where the tracker has the two-call device stage.  For loops that finish with a batch's arrays
         before asking for the next one (sharded ``predict_partial``): at most two result sets are alive."""
         self._reuse_outputs = True
+        submitted = None
         try:
-            submitted = None
             for sample in _sampler(frame_generator, self.batch_size):
                 token = self.submit_sample(sample, **kwargs)
                 if submitted is not None:
-                    yield self.collect_sample(submitted)
-                    submitted = None
+                    done, submitted = submitted, token       # (the new token is tracked before control leaves this frame)
+                    token = None
+                    yield self.collect_sample(done)
+                    if submitted is None:
+                        yield self.infer_sample(sample, **kwargs)
+                    continue
                 if token is None:
                     yield self.infer_sample(sample, **kwargs)
                 else:
                     submitted = token
             if submitted is not None:
-                yield self.collect_sample(submitted)
+                token, submitted = submitted, None
+                yield self.collect_sample(token)
         finally:
             self._reuse_outputs = False
+            self._drain(submitted)
+
+    def _drain(self, token) -> None:
+        """A loop that ends early (an exception in a host stage, a consumer that stops iterating) must not leave its submitted
+        batch uncollected: the ticket would stay in flight on the model (PA_MAX_INFLIGHT of them block further submits)."""
+        if token is not None:
+            try:
+                self.collect_sample(token)
+            except Exception:
+                pass
 
     def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:
         try:

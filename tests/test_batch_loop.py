@@ -87,3 +87,32 @@ def test_raw_batches_for_sharded_loops():
         t.live -= 1                                           # the consumer is done with the batch before asking for the next
     assert got == list(range(14)) and t.max_live <= 2 and not t._reuse_outputs
     assert t.log.index(("submit", 4)) < t.log.index(("collect", 0)) < t.log.index(("infer", 8)) < t.log.index(("submit", 12))
+
+
+def test_a_failing_host_stage_does_not_leave_a_batch_in_flight():
+    class Boom(_Toy):
+        def post_sample(self, raw, **kw):
+            if raw[0] == 4:
+                raise RuntimeError("host stage failed")
+            return super().post_sample(raw)
+
+    t = Boom()
+    try:
+        t.predict_and_update(iter(range(20)))
+        raise AssertionError("the host stage's exception must surface")
+    except RuntimeError as ex:
+        assert "host stage failed" in str(ex)
+    submitted = [e[1] for e in t.log if e[0] == "submit"]
+    collected = [e[1] for e in t.log if e[0] == "collect"]
+    assert submitted and sorted(submitted) == sorted(collected), (submitted, collected)       # every ticket was waited for
+    assert not t._reuse_outputs
+
+
+def test_a_consumer_that_stops_early_drains_the_look_ahead():
+    t = _Toy()
+    it = t._raw_batches(iter(range(20)))
+    assert next(it) == [0, 1, 2, 3]
+    it.close()                                                 # e.g. an exception in the sharded loop's body
+    submitted = [e[1] for e in t.log if e[0] == "submit"]
+    collected = [e[1] for e in t.log if e[0] == "collect"]
+    assert submitted == [0, 4] and sorted(collected) == [0, 4] and not t._reuse_outputs
