@@ -355,7 +355,8 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         case 211: return launch_h2t<4, 1, 2, 2>(a, s);    // 128 x  32
         case 213: return launch_h2t<4, 1, 2, 6>(a, s);    // 128 x  96, 4 waves of 2 x 6 fragments
         case 225: return launch_h2t<4, 1, 1, 5>(a, s);    //  64 x  80: the 19-fragment (304-channel) fused pose heads
-        // eight-wave tiles (tuning only, never chosen automatically; instantiated at the end of round 4, NOT yet measured): one
+        // eight-wave tiles (tuning only, never chosen automatically; instantiated at the end of round 4: bitwise the other tiles
+        // on the GPU — tests/test_gpu_h2.py — but NOT yet timed): one
         // ring stage feeds twice the MFMAs — 20 KB of LDS-DMA per 128 x 192 x 32 block against 14 KB per 128 x 96 x 32, and a
         // 192-channel 1x1 reads its input once instead of once per channel tile
         case 230: return launch_h2t<4, 2, 2, 6>(a, s);    // 128 x 192, 8 waves of 2 x 6 fragments

@@ -419,8 +419,8 @@ __global__ void __launch_bounds__(NT) sppf_h2_kernel(float* buf, int cs, int cho
     }
 }
 // The same for fp16 buffers (8 channels = one 16-byte vector per pixel and workgroup).  OPT-IN (tuning fuse_sppf >= 5), written
-// at the end of round 4 and NOT yet run on a GPU: the fp16 graphs keep their three pool5_kernel launches until it has been
-// measured (c4: 0.35 ms per step in the three launches).
+// at the end of round 4: same head maps and detections as the three launches (tests/test_gpu_fp16.py), but not yet TIMED — the
+// fp16 graphs keep their three pool5_kernel launches until it has been (c4: 0.35 ms per step in the three launches).
 template <int NT>
 __global__ void __launch_bounds__(NT) sppf_f16_kernel(_Float16* buf, int cs, int choff, int c, int B, int H, int W) {
     extern __shared__ unsigned long long sppf_lds[];

@@ -18,13 +18,8 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 303, 304, 306, 313, 314, 323, 341, 342, 343)      # 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
+H2_TILES = (207, 209, 211, 213, 220, 225, 230, 231, 303, 304, 306, 313, 314, 323, 341, 342, 343)      # 230 / 231: the eight-wave tap tiles (128 x 192, 256 x 96; tuning only); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
 H2_SINGLE_LEVEL = (306,)        # patch tile with 6 fragments: main product accumulated in one level (registers)
-if __import__("os").environ.get("PADEL_TEST_TILES_8W") == "1":
-    # the eight-wave tap tiles instantiated at the end of round 4 (conv_tap_h2.hip ids 230 / 231): not measured, not run on a
-    # GPU yet — opt in here for their first contact, then move them into the tuple above
-    H2_TILES = H2_TILES + (230, 231)
-
 
 def _graph(case, w, b, wr, dtype):
     B, H, W, cin, cout, k, s, act, use_res = case
