@@ -82,6 +82,7 @@ bool conv_h2p_supported(const ConvArgs& a);
 hipError_t launch_conv_h2p(const ConvArgs& a, int nf, hipStream_t s);
 bool conv_h2q_supported(const ConvArgs& a);            // conv_patch_h2q.hip: stride-1 3x3, cin % 32 == 0, no absorbed upsample
 hipError_t launch_conv_h2q(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_h2_deep(const ConvArgs& a, int variant, hipStream_t s);     // conv_tap_h2p.hip: tap tiles with a 3-stage activation ring (239, 243); hipErrorNotSupported where they do not apply
 bool conv_h2w_supported(const ConvArgs& a);            // conv_patch_h2w.hip: stride-1 3x3 with 16 / 32 / 48 input channels
 hipError_t launch_conv_h2w(const ConvArgs& a, int nf, hipStream_t s);
 // fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and

@@ -28,6 +28,7 @@ CASES = [
     (2, 16, 20, 80, 48, 3, 1, G.ACT_SILU, False),     # two full chunks + tail (cin 80), 48 outputs (128x48 tile)
     (2, 18, 26, 16, 32, 3, 1, G.ACT_SILU, False),     # stride 1 with the tail block only (n-scale's 16 channels), partial patches
     (2, 20, 24, 64, 192, 3, 1, G.ACT_SILU, True),     # two full 96-channel tiles (quad patch kernel: both channel halves), partial patches in y and x
+    (1, 20, 27, 688, 96, 1, 1, G.ACT_SILU, False),    # 1x1 with long K: 21 full chunks + a 16-channel tail = three accumulation blocks (9 + 9 + 4), M tail
 ]
 
 LDS_VARIANTS = tuple(range(13))

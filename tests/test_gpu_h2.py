@@ -18,7 +18,7 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 230, 231, 303, 304, 306, 313, 314, 323, 341, 342, 343)      # 230 / 231: the eight-wave tap tiles (128 x 192, 256 x 96; tuning only); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
+H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 303, 304, 306, 313, 314, 323, 341, 342, 343)      # 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
 H2_SINGLE_LEVEL = (306,)        # patch tile with 6 fragments: main product accumulated in one level (registers)
 
 def _graph(case, w, b, wr, dtype):
@@ -186,7 +186,7 @@ def test_h2_upsample_absorbed(gpu_engine, shape):
         gpu_engine.set_profiling(False)
         return y, n_up
 
-    absorbing = (220, 209, 213, 207) if k == 1 else (303, 304, 306)
+    absorbing = (220, 209, 213, 207, 243, 239) if k == 1 else (303, 304, 306)
     keeping = () if k == 1 else (220,)
     try:
         ref, n_up = run(variant=220 if k == 1 else 303, fold_up=0)
