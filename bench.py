@@ -501,8 +501,28 @@ def main():
             out["value"] = round(world * B * K / dt, 2)
             out["ms_per_step"] = round(1e3 * dt / K, 3)
             out["config"]["runner_seconds_per_tracker_rank0"] = {k: round(v["seconds"], 4) for k, v in runner.timings.items()}
+            if world > 1:
+                # N > 1: the path BASELINE configs[3] names (reference trackers/runner.py:185-236 over ONE clip): a single clip
+                # of world x K x B frames, TrackingRunner(distributed=True) — every rank runs the stateless part of each tracker
+                # on its contiguous shard, the partials are gathered to rank 0 as packed arrays (dist.gather_arrays) and the
+                # frame-sequential part (ByteTrack ids in global frame order, result containers) runs there.  Seconds = max
+                # over ranks with the gathers and rank 0's sequential stages inside.  THIS is `value` at N > 1; the
+                # independent-replica figure above (each rank its own runner over its own clip: an upper bound that omits the
+                # gather and the rank-0 stage) stays beside it.
+                out["replica_runners"] = {"value": out["value"], "ms_per_step": out["ms_per_step"],
+                                          "what": "N independent TrackingRunner.run() over N private clips: no gather, ByteTrack per rank"}
+                gclip = clip.alias(world * max(K, Wm, 1))       # rank r only ever reads frames [r K B, (r + 1) K B): its own
+                if Wm > 0:
+                    run_runner(gclip, world * Wm, distributed=True)
+                dt, runner = run_runner(gclip, world * K, distributed=True)
+                out["value"] = round(world * B * K / dt, 2)
+                out["ms_per_step"] = round(1e3 * dt / K, 3)
+                out["config"]["timed_path"] += (" — at N > 1 as TrackingRunner(distributed=True) over ONE clip of world x K x B frames: "
+                                                "contiguous shards, packed-array gather to rank 0, ByteTrack / containers there")
+                out["config"]["runner_seconds_per_tracker_rank0"] = {k: round(v["seconds"], 4) for k, v in runner.timings.items()}
             kept = sum(len(p) for p in trackers["players"].results.predictions) if "players" in trackers else 0
             out["config"]["tracked_players_rank0"] = kept
+            out["config"]["frames_with_results_rank0"] = {n_: len(t_.results) for n_, t_ in trackers.items()}
         else:
             out["value"], out["ms_per_step"] = out["engine_only"]["value"], out["engine_only"]["ms_per_step"]
         # how many result OBJECTS the timed run created: `Players` / `PlayersKeypoints` keep the detector's arrays and build

@@ -1058,7 +1058,12 @@ int pa_yolo_submit(pa_model* m, const uint8_t* frames, int n, int h, int w, cons
     if (m->tk_busy[slot]) PA_FAIL(e, "pa_yolo_submit: %d tickets in flight (PA_MAX_INFLIGHT)", PA_MAX_INFLIGHT);
     if (yolo_prepare(m, frames, n, h, w, p, out_boxes, out_kpts, out_counts, "pa_yolo_submit")) return 1;
     size_t pi = 0;
-    if (yolo_enqueue(m, frames, n, h, w, p, out_boxes, out_kpts, out_counts, slot, &pi)) return 1;
+    if (yolo_enqueue(m, frames, n, h, w, p, out_boxes, out_kpts, out_counts, slot, &pi)) {
+        // part of the call may be queued already (preprocessing, some layers) and would write into the caller's arrays with
+        // no ticket to wait on: drain before reporting the failure
+        (void)hipStreamSynchronize(e->stream);
+        return 1;
+    }
     PA_HIP(e, hipEventRecord(m->tk_ev[slot], e->stream));
     m->tk_busy[slot] = true;
     ++m->n_inflight;

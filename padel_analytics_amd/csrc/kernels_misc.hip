@@ -501,6 +501,9 @@ hipError_t init_misc_kernels() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_h2_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_h2_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_h2_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
+    // (hipFuncSetAttribute applies to the current device: once per engine, not behind a process-wide flag — ADVICE r4)
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_f16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_f16_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
     return e;
 }
 
@@ -535,13 +538,7 @@ hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, 
         const size_t lds = (size_t)2 * H * W * 16;
         const dim3 grid((unsigned)(B * (c / 8)));
         _Float16* hb = reinterpret_cast<_Float16*>(buf);
-        static bool attr_set = false;                // (opt-in path: its LDS limit is raised at first use, not at engine creation)
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_f16_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_f16_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSppfMaxLds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        // (init_misc_kernels raised the kernel's dynamic-LDS limit on this engine's device)
         if (H * W > 1024) hipLaunchKernelGGL(sppf_f16_kernel<1024>, grid, dim3(1024), lds, s, hb, cs, choff, c, B, H, W);
         else hipLaunchKernelGGL(sppf_f16_kernel<256>, grid, dim3(256), lds, s, hb, cs, choff, c, B, H, W);
         return hipGetLastError();

@@ -97,14 +97,75 @@ def broadcast_blob(blob: Optional[np.ndarray], n_floats: int, src: int = 0, devi
     return t.cpu().numpy()
 
 
+def _pack_arrays(arrays: list) -> np.ndarray:
+    """[ndarray] -> one uint8 buffer: 8-byte header length, pickled [(dtype, shape)], then the raw bytes back to back."""
+    import pickle
+    arrays = [np.ascontiguousarray(a) for a in arrays]
+    meta = pickle.dumps([(a.dtype.str, a.shape) for a in arrays], protocol=4)
+    out = np.empty(8 + len(meta) + sum(a.nbytes for a in arrays), np.uint8)
+    out[:8] = np.frombuffer(np.int64(len(meta)).tobytes(), np.uint8)
+    out[8:8 + len(meta)] = np.frombuffer(meta, np.uint8)
+    pos = 8 + len(meta)
+    for a in arrays:
+        out[pos:pos + a.nbytes] = a.reshape(-1).view(np.uint8)
+        pos += a.nbytes
+    return out
+
+
+def _unpack_arrays(buf: np.ndarray) -> list:
+    import pickle
+    nmeta = int(np.frombuffer(buf[:8].tobytes(), np.int64)[0])
+    meta = pickle.loads(buf[8:8 + nmeta].tobytes())
+    pos, out = 8 + nmeta, []
+    for dt, shape in meta:
+        nb = int(np.dtype(dt).itemsize * int(np.prod(shape, dtype=np.int64)))
+        out.append(np.frombuffer(buf[pos:pos + nb].tobytes(), np.dtype(dt)).reshape(shape))
+        pos += nb
+    return out
+
+
+def gather_bytes(buf: np.ndarray, dst: int = 0) -> Optional[list]:
+    """One uint8 buffer per rank -> on `dst` the list of all ranks' buffers (rank order), None elsewhere.  Two collectives
+    whatever the content: an all-gather of the lengths and ONE gather of the buffers padded to the longest."""
+    import torch
+    import torch.distributed as dist
+    world, me = dist.get_world_size(), dist.get_rank()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = (lambda t: t.cuda()) if on_gpu else (lambda t: t)
+    n = dev(torch.tensor([int(buf.size)], dtype=torch.int64))
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    sizes = [int(x.cpu()[0]) for x in sizes]
+    cap = max(max(sizes), 1)
+    send = torch.zeros(cap, dtype=torch.uint8)
+    send[:buf.size] = torch.from_numpy(np.ascontiguousarray(buf, np.uint8).reshape(-1))
+    send = dev(send)
+    recv = [dev(torch.empty(cap, dtype=torch.uint8)) for _ in range(world)] if me == dst else None
+    dist.gather(send, recv, dst=dst)
+    if me != dst:
+        return None
+    return [recv[r].cpu().numpy()[:sizes[r]] for r in range(world)]
+
+
+def gather_arrays(arrays: list, dst: int = 0) -> Optional[list]:
+    """Every rank contributes a list of ndarrays; `dst` gets [rank 0's list, rank 1's list, ...] — O(bytes): no per-item
+    pickling (the sharded runner's partials: counts + rows per rank, ``Tracker.pack_partials``)."""
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [list(arrays)]
+    got = gather_bytes(_pack_arrays(arrays), dst)
+    return None if got is None else [_unpack_arrays(b) for b in got]
+
+
 def gather_results(local: list, dst: int = 0) -> Optional[list]:
     """Gather per-rank python result lists (already in local frame order) to `dst`, concatenated in rank
-    (= global frame) order."""
+    (= global frame) order.  Fallback for partials a tracker cannot express as arrays (``Tracker.pack_partials`` returns
+    None): the list is pickled once per rank and travels as ONE byte buffer."""
+    import pickle
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
-    out = [None] * dist.get_world_size() if dist.get_rank() == dst else None
-    dist.gather_object(local, out, dst=dst)
-    if out is None:
+    got = gather_bytes(np.frombuffer(pickle.dumps(local, protocol=4), np.uint8), dst)
+    if got is None:
         return None
-    return [x for part in out for x in part]
+    return [x for b in got for x in pickle.loads(b.tobytes())]

@@ -248,6 +248,8 @@ class Engine:
         """Tests / tools only: impl (2 bx3, 0 tap, 1 lds), variant (tile id, -1 auto), tune, tap_pd, graph, alias, fold_up, timeline."""
         for k, v in kv.items():
             self._check(self.lib.pa_engine_set_tuning(self.handle, k.encode(), int(v)))
+            if k == "timeline":
+                self.timeline = bool(v)              # (pa_yolo_submit refuses then: yolo.YOLO.submit_frames falls back to infer_frames)
 
     # ---- multi-GPU: RCCL communicator owned by the library (include/padel_hip.h "multi-GPU")
     def comm_init(self, unique_id: bytes, nranks: int, rank: int):
@@ -360,9 +362,11 @@ class Model:
         self.max_batch = 64
         self._out_ring: dict = {}        # (n, max_det) -> [three page-locked (boxes, kpts, counts) sets, next slot]
 
-    #: recycled result sets per (n, max_det).  The trackers' batch loop holds at most three at a time: the batch in the host
-    #: stage, the submitted batch being collected and the batch submitted behind it
-    OUT_RING = 4
+    #: tickets a model may have in flight (PA_MAX_INFLIGHT of include/padel_hip.h)
+    MAX_INFLIGHT = 4
+    #: recycled result sets per (n, max_det): every ticket in flight owns one, plus the set whose results the host stage is
+    #: still reading and the one collected just before it — a set is handed out again OUT_RING calls later
+    OUT_RING = MAX_INFLIGHT + 2
 
     def _ring_outputs(self, n: int, max_det: int):
         key = (int(n), int(max_det))
@@ -393,8 +397,14 @@ class Model:
 
     def __del__(self):
         # a model dropped without close(): its page-locked result blocks must be unregistered BEFORE their memory goes back
-        # to the allocator (a stale registration makes later copies to / from whatever reuses those pages fail)
+        # to the allocator (a stale registration makes later copies to / from whatever reuses those pages fail) — and AFTER
+        # the stream has drained: a ticket still queued copies its results into exactly those pages
         # (only that: destroying the HBM side here could outlive its engine)
+        try:
+            if self._out_ring and getattr(self, "handle", None) and self.engine.handle:
+                self.engine.synchronize()
+        except Exception:
+            pass
         try:
             self._free_rings()
         except Exception:
@@ -440,9 +450,6 @@ class Model:
             self.handle, ptr, n, h, w, C.byref(p), boxes.ctypes.data,
             kpts.ctypes.data if kpts is not None else None, counts.ctypes.data))
         return boxes, kpts, counts
-
-    #: tickets a model may have in flight (PA_MAX_INFLIGHT of include/padel_hip.h)
-    MAX_INFLIGHT = 4
 
     def yolo_submit(self, frames: "DeviceBuffer", n: int, h: int, w: int, *, imgsz: int, conf: float, iou: float,
                     classes: Optional[Sequence[int]] = None, max_det: int = 300, pre_mode: int = PRE_LETTERBOX,
@@ -569,10 +576,13 @@ class Model:
         return rows
 
     def close(self):
+        """Drain first, unpin second: pa_model_destroy synchronizes the engine's stream, so tickets still queued (the
+        overflow fallback closes a model with batch k + 1 in flight) have finished their copies into the page-locked result
+        sets before those pages are unregistered (tests/test_gpu_pipeline.py closes a model with a ticket out)."""
         if self.handle:
-            self._free_rings()
             self.engine.lib.pa_model_destroy(self.handle)
             self.handle = None
+            self._free_rings()
 
 
 class NativeByteTrack:

@@ -102,3 +102,10 @@ class BallDetectTracker(Tracker):
 
     def merge_partials(self, partials: list, **kwargs) -> list:
         return [Ball(frame=i, xy=(x, y), visibility=v) for i, (x, y, v) in enumerate(partials)]
+
+    # on the wire: one (n, 3) float64 array per rank (x, y exactly; visibility 0 / 1)
+    def pack_partials(self, partials: list):
+        return [np.array(partials, np.float64).reshape(-1, 3)]
+
+    def unpack_partials(self, arrays: list) -> list:
+        return [(float(x), float(y), int(v)) for x, y, v in arrays[0]]

@@ -245,6 +245,8 @@ class BallTracker(Tracker):
             out += [None] * (n_fed - len(out))
         return out[head_context:n_fed - tail_context]
 
+    merge_is_host_only = False          # the InpaintNet runs on the device
+
     def merge_partials(self, partials: list, **kwargs) -> list:
         """InpaintNet trajectory repair over the WHOLE clip (:525-673) + ``Ball`` objects with global frame numbers."""
         n_total = len(partials)
@@ -266,6 +268,24 @@ class BallTracker(Tracker):
                 print(f"{self}: missing detection frame {i}")
                 out.append(Ball(frame=i, xy=(0.0, 0.0), visibility=0))
         return out
+
+    # on the wire: one (n, 4) float64 array per rank — x, y, visibility, 1 (0: the frame has no output, None)
+    def pack_partials(self, partials: list):
+        a = np.zeros((len(partials), 4), np.float64)
+        for i, p in enumerate(partials):
+            if p is not None:
+                a[i] = (p[0], p[1], p[2], 1.0)
+        return [a]
+
+    def unpack_partials(self, arrays: list) -> list:
+        out = []
+        for x, y, v, have in arrays[0]:
+            out.append((self._wire_num(x), self._wire_num(y), int(v)) if have else None)
+        return out
+
+    @staticmethod
+    def _wire_num(v: float):
+        return int(v) if float(v).is_integer() else float(v)
 
     def _frame_hw(self) -> tuple:
         if getattr(self, "_last_hw", None):

@@ -178,5 +178,27 @@ class PlayerKeypointsTracker(Tracker):
     def predict_sample(self, sample: Iterable[np.ndarray], **kwargs) -> list:
         return self.post_sample(self.infer_sample(sample, **kwargs), **kwargs)
 
+    # ---- sharded: a frame's partial is its (n, K, 2) array of network-input coordinates (invisible points zeroed) with the
+    # frame's ratio in a trailing row — arrays on the wire (Tracker.pack_partials), the containers are built on rank 0
+    def predict_partial(self, frame_generator, *, first_frame: int = 0, head_context: int = 0, tail_context: int = 0,
+                        **kwargs) -> list:
+        assert head_context == 0 and tail_context == 0
+        K, ndim = self.model.kpt_shape
+        out = []
+        for kpts, counts, (h_frame, w_frame) in self._raw_batches(frame_generator):
+            ratio = np.array([w_frame / self.train_image_size, h_frame / self.train_image_size], np.float64)
+            for i in range(len(counts)):
+                k = kpts[i, :counts[i]].reshape(counts[i], K, ndim)
+                xy = k[..., :2].astype(np.float64)                 # (float32 values, exactly: the ratio row needs doubles)
+                if ndim == 3:
+                    xy[k[..., 2] < 0.5] = 0
+                out.append(np.concatenate([xy.reshape(counts[i], K * 2), np.tile(ratio, K)[None, :]], axis=0))
+        return out
+
+    def merge_partials(self, partials: list, **kwargs) -> list:
+        K, _ = self.model.kpt_shape
+        return [PlayersKeypoints(xy=p[:-1].reshape(-1, K, 2).astype(np.float32), ratio=(float(p[-1, 0]), float(p[-1, 1])))
+                for p in partials]
+
     def predict_frames(self, frame_generator, **kwargs):
         raise NoPredictFrames()

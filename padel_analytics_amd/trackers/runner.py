@@ -71,6 +71,7 @@ class TrackingRunner:
 
     def run(self) -> None:
         print(f"runner: Running {self.total_frames} frames")
+        self._merges = []                  # sharded mode, rank 0: sequential stages still running behind the next tracker's shard
         if self.fanout:
             self._run_fanout()
         else:
@@ -90,9 +91,13 @@ class TrackingRunner:
                     self._predict(tracker)
                 t1 = timeit.default_timer()
                 tracker.to("cpu")
+                if self._merges and self._merges[-1][0] is tracker:
+                    self._merges[-1] += (t0,)          # reported (with the merge inside the time) when the merge is done
+                    continue
                 self._report(tracker, t0, t1)
                 if not self.distributed or D.rank() == 0:
                     tracker.save_predictions()
+        self._join_merges()
         self.draw_and_collect_data()
 
     def _predict(self, tracker: Tracker) -> None:
@@ -148,10 +153,39 @@ class TrackingRunner:
             partial, over = attempt()
             assert not over
         assert len(partial) == hi - lo, (str(tracker), len(partial), lo, hi)
-        allp = D.gather_results(partial, dst=0)
+        # the partials travel as arrays (counts + rows per rank: two collectives, O(bytes)); trackers whose partials are not
+        # arrays fall back to one pickled buffer per rank.  Every rank must take the same branch: agreed by a collective
+        packed = tracker.pack_partials(partial)
+        if not D.any_flag(packed is None):
+            parts = D.gather_arrays(packed, dst=0)
+            allp = None if parts is None else [x for a in parts for x in tracker.unpack_partials(a)]
+        else:
+            allp = D.gather_results(partial, dst=0)
         if rank == 0:
-            tracker.results.predictions = tracker.merge_partials(allp)
-            print(f"{tracker.__str__()}: {len(tracker.results)} predictions.")
+            def merge():
+                tracker.results.predictions = tracker.merge_partials(allp)
+                print(f"{tracker.__str__()}: {len(tracker.results)} predictions.")
+                return timeit.default_timer()
+            # The sequential stage (ByteTrack ids over ALL frames in global order: ~60 us per frame of host C++) is rank 0's
+            # alone.  Where it touches no GPU it runs on a worker thread while rank 0's GPU starts on the next tracker's shard —
+            # otherwise the other ranks would wait for it at the next gather; run() joins before it returns
+            if tracker.merge_is_host_only and world > 1:
+                if getattr(self, "_merge_pool", None) is None:
+                    from concurrent.futures import ThreadPoolExecutor
+                    self._merge_pool = ThreadPoolExecutor(max_workers=1)
+                self._merges.append((tracker, self._merge_pool.submit(merge)))
+            else:
+                merge()
+
+    def _join_merges(self) -> None:
+        for tracker, fut, t0 in getattr(self, "_merges", []):
+            t1 = fut.result()
+            self._report(tracker, t0, t1)
+            tracker.save_predictions()
+        self._merges = []
+        pool, self._merge_pool = getattr(self, "_merge_pool", None), None
+        if pool is not None:
+            pool.shutdown()
 
     def _share_background(self, tracker) -> None:
         """TrackNet's background median (iterable.py:59-81) is a property of the clip's first frames: rank 0

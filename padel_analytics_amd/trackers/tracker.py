@@ -100,6 +100,26 @@ def _sampler(generator: Iterable[np.ndarray], sequence_length: int) -> Iterator[
         yield w
 
 
+def pack_ragged(items: list) -> Optional[list]:
+    """[ndarray (k_i, ...)] with one dtype / trailing shape -> [counts (n,) int32, rows (sum k_i, ...)]; None if the items
+    are anything else."""
+    if not all(isinstance(x, np.ndarray) and x.ndim >= 1 for x in items):
+        return None
+    if not items:
+        return [np.zeros(0, np.int32), np.zeros((0,), np.float32)]
+    tail, dt = items[0].shape[1:], items[0].dtype
+    if any(x.shape[1:] != tail or x.dtype != dt for x in items):
+        return None
+    return [np.array([len(x) for x in items], np.int32), np.concatenate(items, axis=0) if items else np.zeros((0,) + tail, dt)]
+
+
+def unpack_ragged(arrays: list) -> list:
+    counts, rows = arrays
+    if len(counts) == 0:
+        return []
+    return np.split(rows, np.cumsum(counts)[:-1])
+
+
 class Tracker(ABC):
     batch_size: int
     #: True while a loop that bounds the number of live result sets runs (``_predict_batches``): ``infer_sample`` may then ask
@@ -201,6 +221,14 @@ class Tracker(ABC):
     def collect_sample(self, token):
         raise NotImplementedError
 
+    def discard_sample(self, token) -> None:
+        """Give up a submitted batch (its results are not wanted): only releases the ticket (``YOLO.discard_frames``)."""
+        model = getattr(self, "model", None)
+        if hasattr(model, "discard_frames"):
+            model.discard_frames(token)
+        else:
+            self.collect_sample(token)
+
     def _has_stages(self) -> bool:
         return type(self).infer_sample is not Tracker.infer_sample and type(self).post_sample is not Tracker.post_sample
 
@@ -285,9 +313,9 @@ class Tracker(ABC):
         batch uncollected: the ticket would stay in flight on the model (PA_MAX_INFLIGHT of them block further submits)."""
         if token is not None:
             try:
-                self.collect_sample(token)
-            except Exception:
-                pass
+                self.discard_sample(token)
+            except Exception as exc:                         # the loop is already unwinding: report, do not mask what ended it
+                print(f"{self.__str__()}: could not release the batch still in flight ({exc!r})")
 
     def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:
         try:
@@ -312,6 +340,20 @@ class Tracker(ABC):
             self._predict_batches(frame_generator, out.extend, **kwargs)
         return out
 
+    #: ``merge_partials`` touches neither the GPU nor shared state of other trackers: the sharded runner may run it on a
+    #: worker thread of rank 0 while that rank's GPU already works on the next tracker's shard (False: run it in line)
+    merge_is_host_only = True
+
     def merge_partials(self, partials: list, **kwargs) -> list:
         """Sequential part, on rank 0, over the partials of ALL frames in global frame order -> final objects."""
         return partials
+
+    # ---- the partials on the wire: arrays, not pickled objects (the gather is then O(bytes): dist.gather_arrays)
+    def pack_partials(self, partials: list) -> Optional[list]:
+        """-> a list of ndarrays that ``unpack_partials`` turns back into the same partials, or None (the runner then falls
+        back to one pickled buffer per rank).  Default: per-frame items that are all ndarrays of one dtype and trailing shape
+        travel as (counts, rows)."""
+        return pack_ragged(partials)
+
+    def unpack_partials(self, arrays: list) -> list:
+        return unpack_ragged(arrays)

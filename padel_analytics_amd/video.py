@@ -107,6 +107,14 @@ class DeviceClip:
     def total_frames(self) -> int:
         return self.n * self.repeat
 
+    def alias(self, repeat: int) -> "DeviceClip":
+        """The same frames in HBM (no copy, not an owner: never ``free()`` it) presented with another ``repeat`` — the
+        bench's sharded leg shows every rank a clip of world x K x n frames of which it only ever reads its own shard."""
+        c = object.__new__(DeviceClip)
+        c.__dict__.update(self.__dict__)
+        c.repeat = int(repeat)
+        return c
+
     def upload(self, frames: np.ndarray, first: int = 0, copy_stream: bool = True) -> None:
         """Overwrite stored frames [first, first + len(frames)) (prefetch thread of the runner's fan-out mode)."""
         frames = np.ascontiguousarray(frames, np.uint8)

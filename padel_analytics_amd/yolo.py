@@ -183,7 +183,7 @@ class YOLO:
         """The device stage alone: -> (boxes (n,max_det,6), kpts (n,max_det,nk) | None, counts (n,), (h, w), imgsz,
         pre_mode).  ``frames``: (n,h,w,3) uint8 array, a list of such frames, or a list of ``video.DeviceFrame``
         handles of one contiguous range of a clip that is already in HBM (no upload).  ``reuse_outputs``: see
-        ``engine.Model.yolo_infer`` (the arrays are recycled two calls later)."""
+        ``engine.Model.yolo_infer`` (a set is handed out again ``engine.Model.OUT_RING`` calls later)."""
         from . import video
         pre_mode = E.PRE_PIL_STRETCH if pil_stretch else E.PRE_LETTERBOX
         dev = None if isinstance(frames, np.ndarray) else video.device_batch(frames)
@@ -213,8 +213,8 @@ class YOLO:
         from . import video
         dev = None if isinstance(frames, np.ndarray) else video.device_batch(frames)
         m = self._ensure_model()
-        if dev is None or not hasattr(m, "yolo_submit") or getattr(m.engine, "profiling", False):
-            return None
+        if dev is None or not hasattr(m, "yolo_submit") or getattr(m.engine, "profiling", False) or getattr(m.engine, "timeline", False):
+            return None                              # (pa_yolo_submit refuses while profiling / collecting a timeline)
         src, n, h, w = dev
         if n > m.max_batch:
             return None
@@ -237,6 +237,14 @@ class YOLO:
             self.fell_back = True
             return self.infer_frames(token["frames"], *token["args"], reuse_outputs=True, **token["kw"])
         return (boxes, kpts, counts) + token["ret"]
+
+    def discard_frames(self, token) -> None:
+        """Give up a ``submit_frames`` token whose results nobody wants (a batch loop that ends early): wait for the ticket
+        if the model it was submitted to is still the live one, nothing otherwise — never a fresh inference, never a model
+        re-upload (closing a model drained its stream and its tickets died with it)."""
+        m = token["model"]
+        if m is self._model and getattr(m, "handle", None):
+            m.yolo_wait(token["ticket"])
 
     def _run(self, frames: np.ndarray, conf, iou, imgsz, classes, max_det, pre_mode, reverse) -> list:
         return self._results(*self.infer_frames(frames, conf, iou, imgsz, classes, max_det, channel_reverse=reverse,

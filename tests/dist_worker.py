@@ -190,8 +190,20 @@ def run_blob(rank, world, out):
     med = D.broadcast_array(np.arange(24, dtype=np.uint8).reshape(2, 4, 3) if rank == 0 else None, (2, 4, 3), np.uint8)
     uid = D.share_unique_id(lambda: b"\x07" * 128)
     assert med.tolist() == np.arange(24).reshape(2, 4, 3).tolist() and uid == b"\x07" * 128
+    # the packed gather of the sharded runner: ragged per-frame arrays as (counts, rows), uneven and EMPTY shards, mixed dtypes
+    from padel_analytics_amd.trackers.tracker import pack_ragged, unpack_ragged
+    items = [np.full((i % 4, 6), i, np.float32) for i in range(lo, hi)] if rank != 1 else []     # rank 1 contributes nothing
+    parts = D.gather_arrays(pack_ragged(items) + [np.arange(rank + 2, dtype=np.int64)], dst=0)
+    packed_ok = None
     if rank == 0:
-        Path(out).write_text(json.dumps({"head": got[:5].tolist(), "order": [a[0] for a in allr]}))
+        back = [x for a in parts for x in unpack_ragged(a[:2])]
+        want = [np.full((i % 4, 6), i, np.float32) for r in range(world) if r != 1 for i in range(*D.shard_range(n, r, world))]
+        packed_ok = (len(back) == len(want) and all(a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b) for a, b in zip(back, want))
+                     and [a[2].tolist() for a in parts] == [list(range(r + 2)) for r in range(world)])
+    else:
+        assert parts is None
+    if rank == 0:
+        Path(out).write_text(json.dumps({"head": got[:5].tolist(), "order": [a[0] for a in allr], "packed_ok": packed_ok}))
 
 
 def main():

@@ -116,3 +116,49 @@ def test_a_consumer_that_stops_early_drains_the_look_ahead():
     submitted = [e[1] for e in t.log if e[0] == "submit"]
     collected = [e[1] for e in t.log if e[0] == "collect"]
     assert submitted == [0, 4] and sorted(collected) == [0, 4] and not t._reuse_outputs
+
+
+def test_drain_releases_the_ticket_without_a_fresh_inference():
+    """the early-exit path gives the submitted batch up through ``discard_sample`` -> ``YOLO.discard_frames`` — a
+    wait on the ticket when its model is still the live one, nothing at all when that model was replaced or closed; never
+    ``collect_frames`` (which would run a whole inference, re-creating the HBM model, to throw the result away)."""
+    from padel_analytics_amd import yolo as Y
+
+    class _M:
+        handle = 1
+        def __init__(self): self.waited = []
+        def yolo_wait(self, ticket): self.waited.append(ticket); return None, None, None, False
+
+    class _Y:
+        discard_frames = Y.YOLO.discard_frames
+        def __init__(self): self._model = _M()
+        def collect_frames(self, token): raise AssertionError("the drain must not collect")
+        def infer_frames(self, *a, **k): raise AssertionError("the drain must not infer")
+
+    class WithModel(_Toy):
+        def __init__(self):
+            super().__init__()
+            self.model = _Y()
+        def submit_sample(self, sample, **kw):
+            tok = super().submit_sample(sample, **kw)
+            tok.update(ticket=("t", sample[0]), model=self.model._model)
+            return tok
+
+    t = WithModel()
+    live = t.model._model
+    it = t._raw_batches(iter(range(20)))
+    assert next(it) == [0, 1, 2, 3]
+    it.close()
+    assert live.waited == [("t", 4)]                           # the look-ahead ticket was waited for, nothing else ran
+    t2 = WithModel()
+    it = t2._raw_batches(iter(range(20)))
+    next(it)
+    old, t2.model._model = t2.model._model, _M()               # the overflow fallback replaced the model in between
+    it.close()
+    assert old.waited == [] and t2.model._model.waited == []
+    t3 = WithModel()
+    it = t3._raw_batches(iter(range(20)))
+    next(it)
+    t3.model._model.handle = None                              # ... or closed it
+    it.close()
+    assert t3.model._model.waited == []

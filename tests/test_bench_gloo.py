@@ -41,6 +41,14 @@ def test_bench_main_world2_gloo_fake_engine(tmp_path):
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["config"]["frames_per_gpu_per_step"] == B
     # value = whole-job frames / (max over ranks of the timed region)
     assert abs(d["value"] - world * B * K / (d["ms_per_step"] * K / 1e3)) <= 0.02 * d["value"]
+    # N > 1: `value` is the SHARDED runner (one clip of world x K x B frames, TrackingRunner(distributed=True): packed gather to
+    # rank 0, ByteTrack there); the independent-replica number stays beside it
+    rep = d["replica_runners"]
+    assert abs(rep["value"] - world * B * K / (rep["ms_per_step"] * K / 1e3)) <= 0.02 * rep["value"]
+    assert "distributed=True" in d["config"]["timed_path"]
+    assert d["config"]["tracked_players_rank0"] > 0                     # rank 0 holds the merged results of ALL shards
+    assert d["config"]["frames_with_results_rank0"] == {"players": world * K * B, "ball": world * K * B, "pose": world * K * B}
+    assert set(d["config"]["runner_seconds_per_tracker_rank0"]) == {"players_tracker", "ball_tracker", "players_keypoints_tracker"}
     e = d["engine_only"]
     assert abs(e["value"] - world * B * K / (e["ms_per_step"] * K / 1e3)) <= 0.02 * e["value"]
     # three trackers x (1 warm-up + K) fake steps of 10 ms each, at least: the timed region is real

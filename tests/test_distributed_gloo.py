@@ -50,6 +50,7 @@ def test_broadcast_and_gather_world2(tmp_path):
     want = np.random.default_rng(0).normal(size=1000).astype(np.float32)[:5].tolist()
     assert got["head"] == want
     assert got["order"] == list(range(37))
+    assert got["packed_ok"] is True            # dist.gather_arrays: (counts, rows) per rank, an empty shard, a second dtype
 
 
 @pytest.fixture(scope="module")

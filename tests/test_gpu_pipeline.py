@@ -49,6 +49,43 @@ def test_submit_wait_equals_infer_with_two_tickets_in_flight(gpu_engine):
     m.close()
 
 
+def test_close_with_a_ticket_in_flight_then_reuse_the_pages(gpu_engine):
+    """``Model.close()`` drains the stream BEFORE it unregisters the page-locked result sets — a ticket still
+    queued copies into exactly those pages.  Close with tickets out (what the overflow fallback does), drop the model, then
+    run a second model whose fresh page-locked sets may reuse the freed memory: its results must be the synchronous ones, and
+    ``YOLO.discard_frames`` of a token whose model is gone must do nothing."""
+    kpt = (13, 3)
+    sd = yolo_arch.synth_state_dict("n", 1, kpt, seed=2, cls_bias=1.0)
+    h, w = 180, 320
+    frames = synth.synthetic_frames(8, h, w, seed=41)
+    clip = video.DeviceClip(gpu_engine, frames)
+    kw = dict(imgsz=320, conf=0.25, iou=0.7, classes=[0])
+    views = [clip.buffer.view(i * 4 * clip.frame_bytes, 4 * clip.frame_bytes) for i in range(2)]
+    ref = E.Model(gpu_engine, G.build_yolov8(sd, 1, kpt, dtype=E.graph_dtype()))
+    ref.set_max_batch(4)
+    want = [tuple(np.array(a) for a in ref.yolo_infer(v, 4, h, w, **kw)) for v in views]
+    ref.close()
+    for rep in range(3):
+        m = E.Model(gpu_engine, G.build_yolov8(sd, 1, kpt, dtype=E.graph_dtype()))
+        m.set_max_batch(4)
+        t0 = m.yolo_submit(views[0], 4, h, w, **kw)
+        t1 = m.yolo_submit(views[1], 4, h, w, **kw)
+        if rep == 2:
+            del t0, t1
+            del m                                        # dropped without close(): __del__ drains before it unpins
+        else:
+            m.close()                                    # tickets t0 / t1 still in flight
+            assert m.handle is None and not m._out_ring
+        m2 = E.Model(gpu_engine, G.build_yolov8(sd, 1, kpt, dtype=E.graph_dtype()))
+        m2.set_max_batch(4)
+        for v, wnt in zip(views, want):
+            got = m2.yolo_infer(v, 4, h, w, reuse_outputs=True, **kw)
+            for a, b in zip(got, wnt):
+                assert np.array_equal(a, b)
+        m2.close()
+    clip.free()
+
+
 def _trackers(tmp_path, sd_p, sd_k, batch):
     checkpoint.save_checkpoint(tmp_path / "players.pt", sd_p, "detect", 80, None, "n", {0: "person"})
     checkpoint.save_checkpoint(tmp_path / "pose.pt", sd_k, "pose", 1, (13, 3), "n", {0: "person"})
