@@ -472,8 +472,8 @@ def main():
             "timed_path": "TrackingRunner.run(): PlayerTracker (+PolygonZone +ByteTrack) -> BallDetectTracker -> "
                           "PlayerKeypointsTracker, sequential over trackers like trackers/runner.py:185; within a tracker the "
                           "device stage of batch k + 1 is queued (pa_yolo_submit) before batch k is collected (pa_yolo_wait) and the "
-                          "host stage of batch k (PolygonZone, ByteTrack, containers) runs on a worker thread behind it — every batch's "
-                          "work, results included, is inside the timed region",
+                          "host stage of batch k (PolygonZone, ByteTrack, containers AND their Player / PlayerKeypoints objects, built where "
+                          "the reference builds them) runs on a worker thread behind it — every batch's work, results included, is inside the timed region",
         },
     }
 
@@ -493,8 +493,13 @@ def main():
         if a.dtype == "f32" and a.impl == "bx3" and not a.no_compare:
             out["engine_only"]["fp32_mfma_kernels"] = fp32_mfma_leg()
         out["config"]["detections_per_step_rank0"] = ndet
-        # ---- through the runner (the metric's path)
+        # ---- through the runner (the metric's path).  Round 5: `value` is the run with the result objects built where the
+        # reference builds them — every Player / PlayerKeypoints object inside predict_sample (players_tracker.py:371-378,
+        # players_keypoints_tracker.py:303-320; trackers.set_eager_objects(True): array-backed objects, ~0.5 us each); the run
+        # that leaves them to first access is the side number `value_lazy_objects`
+        from padel_analytics_amd import trackers as T
         if not a.engine_only:
+            T.set_eager_objects(True)
             if Wm > 0:
                 run_runner(clip, Wm)
             dt, runner = run_runner(clip, K)
@@ -525,9 +530,9 @@ def main():
             out["config"]["frames_with_results_rank0"] = {n_: len(t_.results) for n_, t_ in trackers.items()}
         else:
             out["value"], out["ms_per_step"] = out["engine_only"]["value"], out["engine_only"]["ms_per_step"]
-        # how many result OBJECTS the timed run created: `Players` / `PlayersKeypoints` keep the detector's arrays and build
-        # their `Player` / `PlayerKeypoints` objects on first access (the reference builds them eagerly,
-        # players_tracker.py:371-378) — count what the timed region materialised, then what doing it all costs
+        # how many result OBJECTS the timed run created (`Players` / `PlayersKeypoints` can keep the detector's arrays and build
+        # their `Player` / `PlayerKeypoints` objects on first access; the reference — and `value` — build them eagerly,
+        # players_tracker.py:371-378): count what the timed region materialised
         if not a.engine_only:
             om = {}
             for nm_, t_ in trackers.items():
@@ -535,14 +540,20 @@ def main():
                 cached = lambda p_: getattr(p_, "_players", None) if hasattr(p_, "_players") else getattr(p_, "_items", None)
                 lazy = [p_ for p_ in preds if hasattr(p_, "_players") or hasattr(p_, "_items")]
                 if not lazy:
-                    om[nm_] = {"containers": len(preds), "lazy": False}
+                    om[nm_] = {"containers": len(preds), "array_backed": False}
                     continue
                 inside = sum(len(cached(p_)) for p_ in lazy if cached(p_) is not None)
                 t1_ = time.perf_counter()
                 total = sum(len(p_.players) if hasattr(p_, "_players") else len(p_.players_keypoints) for p_ in lazy)
-                om[nm_] = {"containers": len(preds), "lazy": True, "objects_built_inside_timed_region": inside,
+                om[nm_] = {"containers": len(preds), "array_backed": True, "objects_built_inside_timed_region": inside,
                            "objects_total": total, "build_all_ms": round(1e3 * (time.perf_counter() - t1_), 2)}
             out["objects_materialised"] = om
+            T.set_eager_objects(False)
+            if world == 1:
+                run_runner(clip, 1)
+                dt_lz, _ = run_runner(clip, K)
+                out["value_lazy_objects"] = {"value": round(world * B * K / dt_lz, 2), "ms_per_step": round(1e3 * dt_lz / K, 3),
+                                             "what": "the same run with Player / PlayerKeypoints objects left to first access (rounds 2-4's `value`)"}
         if not a.engine_only and not a.no_eager:
             # The reference builds every Player / PlayerKeypoints object inside predict_sample (players_tracker.py:371-378,
             # players_keypoints_tracker.py:303-320); `value` builds them on first access (none inside the timed region).  Same
@@ -550,17 +561,18 @@ def main():
             # of the anchors pass (hundreds of detections per frame: decode / NMS do real work, object construction is
             # unrepresentatively heavy); (ii) on a second calibration of the same graphs with a court-like handful of
             # detections per frame.
-            from padel_analytics_amd import trackers as T
-
             def per_frame(trk):
                 return {n_: round(sum(len(p_) for p_ in t_.results.predictions) / max(len(t_.results.predictions), 1), 2)
                         for n_, t_ in trk.items() if n_ != "ball"}
-            T.set_eager_objects(True)
+            T.set_eager_objects(2)                 # every object the reference allocates: the 13 PlayerKeypoint records per person too
             try:
                 run_runner(clip, 1)
                 dt_g, _ = run_runner(clip, K)
-                ve = {"timed_checkpoints": {"value": round(world * B * K / dt_g, 2), "ms_per_step": round(1e3 * dt_g / K, 3),
-                                            "objects_per_frame": per_frame(trackers)}}
+                ve = {"timed_checkpoints_all_records": {
+                    "value": round(world * B * K / dt_g, 2), "ms_per_step": round(1e3 * dt_g / K, 3), "objects_per_frame": per_frame(trackers),
+                    "what": "set_eager_objects(2): also the 13 PlayerKeypoint records of every person and their name index inside "
+                            "predict_sample (Python dataclass construction: ~35 us per person, hundreds of persons per frame on these checkpoints)"}}
+                T.set_eager_objects(True)
                 if world == 1:
                     # second calibration of the SAME checkpoints: the class bias of every head is shifted so that, on the clip,
                     # ~6 candidates per frame pass `conf` (what a padel court shows: 4 players, the odd spectator) — the shift
@@ -623,8 +635,8 @@ def main():
                         t_.model.close()
             finally:
                 T.set_eager_objects(False)
-            ve["what"] = ("TrackingRunner.run() with Player / PlayerKeypoints objects built inside predict_sample like the reference; "
-                          "`value` is the same run with those objects built on first access (objects_materialised)")
+            ve["what"] = ("`value` builds Player / PlayerKeypoints inside predict_sample like the reference (array-backed); here: the same "
+                          "with every per-keypoint record too, and — realistic_detections — on a court-like number of detections")
             out["value_eager_objects"] = ve
         if not a.no_host_frames and not a.engine_only:
             with video.ArrayClip(frames, repeat=max(K, 1)).pin(eng) as hclip:     # a decoder writing into page-locked memory

@@ -36,6 +36,13 @@ class PlayerKeypoint:
 
 
 class PlayerKeypoints:
+    """The 13 keypoints of one person (reference :59-162): ``player_keypoints`` (list of ``PlayerKeypoint``),
+    ``keypoints_by_name``, ``[name]``.  Built from that list (reference signature) or — ``from_xy``, what the tracker
+    uses — from the person's (K, 2) row of the detector's keypoint array plus the frame's ratio: the object then costs
+    ~0.5 us, and its 13 ``PlayerKeypoint`` records (same values: ``float32 -> float`` times the ratio, :303-316) come into
+    being when ``player_keypoints`` / ``keypoints_by_name`` / ``[name]`` / iteration first asks for them."""
+    __slots__ = ("_kps", "_by_name", "_xy", "_ratio")
+
     KEYPOINTS_NAMES = ["left_foot", "right_foot", "torso", "right_shoulder", "left_shoulder", "head", "neck",
                        "left_hand", "right_hand", "right_knee", "left_knee", "right_elbow", "left_elbow"]
     CONNECTIONS = [("left_foot", "left_knee"), ("left_knee", "torso"), ("right_foot", "right_knee"),
@@ -45,8 +52,33 @@ class PlayerKeypoints:
                    ("right_shoulder", "neck")]
 
     def __init__(self, player_keypoints: list):
-        self.player_keypoints = player_keypoints
-        self.keypoints_by_name = {k.name: k for k in player_keypoints}
+        self._kps = player_keypoints
+        self._by_name = {k.name: k for k in player_keypoints}
+        self._xy, self._ratio = None, (1.0, 1.0)
+
+    @classmethod
+    def from_xy(cls, xy: np.ndarray, ratio: tuple = (1.0, 1.0)) -> "PlayerKeypoints":
+        """``xy``: (K, 2) float32 network-input coordinates (a view of the tracker's array), ``ratio`` = (w / S, h / S)."""
+        p = object.__new__(cls)
+        p._xy, p._ratio = xy, ratio
+        p._kps = p._by_name = None
+        return p
+
+    @property
+    def player_keypoints(self) -> list:
+        if self._kps is None:
+            names = self.KEYPOINTS_NAMES
+            rx, ry = self._ratio
+            # reference :303-316: keypoint[0].item() * ratio_x — the float32 value widened to a Python float first
+            self._kps = [PlayerKeypoint(id=i, name=names[i] if i < len(names) else str(i), xy=(x * rx, y * ry))
+                         for i, (x, y) in enumerate(self._xy.tolist())]
+        return self._kps
+
+    @property
+    def keypoints_by_name(self) -> dict:
+        if self._by_name is None:
+            self._by_name = {k.name: k for k in self.player_keypoints}
+        return self._by_name
 
     @classmethod
     def from_json(cls, x: dict):
@@ -55,7 +87,7 @@ class PlayerKeypoints:
     def serialize(self) -> dict:
         return {"player_keypoints": [k.serialize() for k in self.player_keypoints]}
 
-    def __len__(self) -> int: return len(self.player_keypoints)
+    def __len__(self) -> int: return len(self._xy) if self._kps is None else len(self._kps)
 
     def __iter__(self): return iter(self.player_keypoints)
 
@@ -68,10 +100,13 @@ class PlayerKeypoints:
 
 class PlayersKeypoints(Object):
     """All players' keypoints of one frame (reference :165-197).  Built from ``PlayerKeypoints`` objects (reference
-    signature) or from the tracker's (n, K, 2) array of frame-pixel coordinates, in which case the per-keypoint
-    objects are created on first access."""
+    signature) or from the tracker's (n, K, 2) array of network-input coordinates and the frame's ratio; the per-person
+    ``PlayerKeypoints`` objects are then created in the constructor (``EAGER``: where the reference creates them, :303-320)
+    or on first access."""
 
-    #: True: build the per-keypoint objects in the constructor, inside ``predict_sample`` like the reference (:303-320)
+    #: 0 / False (default): the ``PlayerKeypoints`` objects on first access; 1 / True: in the constructor, inside
+    #: ``predict_sample`` like the reference (:303-320) — their 13 ``PlayerKeypoint`` records each on first access;
+    #: 2: those too (everything the reference allocates, allocated where it allocates it)
     EAGER = False
 
     def __init__(self, players_keypoints: Optional[list] = None, *, xy: Optional[np.ndarray] = None,
@@ -82,17 +117,16 @@ class PlayersKeypoints(Object):
         if players_keypoints is None and xy is None:
             self._items = []
         if self.EAGER:
-            self.players_keypoints
+            items = self.players_keypoints
+            if self.EAGER == 2:
+                for p in items:
+                    p.player_keypoints, p.keypoints_by_name
 
     @property
     def players_keypoints(self) -> list:
         if self._items is None:
-            names = PlayerKeypoints.KEYPOINTS_NAMES
-            rx, ry = self._ratio
-            # reference :303-316: keypoint[0].item() * ratio_x — the float32 value widened to a Python float first
-            self._items = [PlayerKeypoints([
-                PlayerKeypoint(id=i, name=names[i] if i < len(names) else str(i), xy=(float(kp[0]) * rx, float(kp[1]) * ry))
-                for i, kp in enumerate(person)]) for person in self._xy]
+            new, ratio = PlayerKeypoints.from_xy, (self._ratio[0], self._ratio[1])
+            self._items = [new(person, ratio) for person in self._xy]
         return self._items
 
     @classmethod

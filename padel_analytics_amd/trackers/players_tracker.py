@@ -25,15 +25,43 @@ from .tracker import NoPredictFrames, Object, Tracker
 
 
 class Player:
+    """One tracked person of one frame (reference :14-98): ``xyxy``, ``id``, ``class_id``, ``confidence``, ``projection``,
+    ``detection`` and the geometry properties.  ``__slots__`` + ``Player.from_row``: the tracker builds these straight from
+    the detector's arrays (a view of the box row, Python scalars for the rest: ~1 us each) — the one-row ``Detections`` the
+    reference's constructor takes is created only when ``.detection`` is read."""
+    __slots__ = ("xyxy", "id", "class_id", "confidence", "projection", "_detection", "_tid")
+
     def __init__(self, detection: Detections, projection: Optional[tuple] = None):
-        self.detection = detection
+        self._detection = detection
         self.projection = projection
         self.xyxy = detection.xyxy[0]
         tid = detection.tracker_id
         # reference :32-36 uses array truthiness: a single id 0 reads as None (SURVEY.md App. C #6)
         self.id = int(tid[0]) if (tid is not None and len(tid) and bool(np.asarray(tid).any())) else None
+        self._tid = None                                   # (only from_row objects rebuild their Detections from it)
         self.class_id = int(detection.class_id[0])
         self.confidence = float(detection.confidence[0])
+
+    @classmethod
+    def from_row(cls, xyxy: np.ndarray, confidence: float, class_id: int, tracker_id: Optional[int]) -> "Player":
+        """The same object as ``Player(Detections(one row))`` from the row's pieces (``xyxy``: a (4,) float32 array)."""
+        p = object.__new__(cls)
+        p.xyxy = xyxy
+        p.confidence = confidence
+        p.class_id = class_id
+        p._tid = tracker_id
+        p.id = tracker_id if tracker_id else None          # the reference's truthiness rule: id 0 reads as None
+        p.projection = None
+        p._detection = None
+        return p
+
+    @property
+    def detection(self) -> Detections:
+        if self._detection is None:
+            self._detection = Detections(xyxy=self.xyxy[None, :], confidence=np.array([self.confidence], np.float32),
+                                         class_id=np.array([self.class_id]),
+                                         tracker_id=None if self._tid is None else np.array([self._tid]))
+        return self._detection
 
     @property
     def top_left(self) -> tuple: return tuple(int(p) for p in self.xyxy[:2])
@@ -68,8 +96,8 @@ class Player:
 
 class Players(Object):
     """List of ``Player`` (reference :199-231).  Built either from ``Player`` objects (reference signature) or from
-    the tracker's arrays (``rows`` (k, 6) x1,y1,x2,y2,conf,cls + ``ids`` (k,)), in which case the ``Player``
-    objects are created on first access."""
+    the tracker's arrays (``rows`` (k, 6) x1,y1,x2,y2,conf,cls + ``ids`` (k,)); the ``Player`` objects are then created
+    in the constructor (``EAGER``: where the reference creates them) or on first access."""
 
     #: True: build the ``Player`` objects in the constructor, i.e. inside ``predict_sample`` like the reference does
     #: (:371-378); False (default): on first access.  ``trackers.set_eager_objects`` flips it for every container class.
@@ -89,10 +117,13 @@ class Players(Object):
     def players(self) -> list:
         if self._players is None:
             r, t = self._rows, self._ids
-            self._players = [
-                Player(Detections(xyxy=r[i:i + 1, :4], confidence=r[i:i + 1, 4], class_id=r[i:i + 1, 5].astype(int),
-                                  tracker_id=None if t is None else t[i:i + 1]))
-                for i in range(len(r))]
+            n = len(r)
+            # one C call per column instead of one numpy scalar conversion per field and object
+            conf = r[:, 4].tolist()
+            cls_ = r[:, 5].astype(int).tolist()
+            tids = [None] * n if t is None else np.asarray(t).astype(int).tolist()
+            new = Player.from_row
+            self._players = [new(r[i, :4], conf[i], cls_[i], tids[i]) for i in range(n)]
         return self._players
 
     @classmethod
