@@ -44,7 +44,7 @@ PEAK_BX3_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 6.0, 1)
 PEAK_H2_TFLOPS = round(PEAK_FP16_MFMA_TFLOPS / 3.0, 1)
 SUSTAINED_FP16_MFMA_TFLOPS = 1780.0     # measured on random operands, 16x16x32 AND 32x32x16 f16 (profiles/r4a_mfma_f16_ubench.txt: 1.71-1.85 PFLOP/s;
                                         # all-zero operands reach 2.2-2.5): reported beside the nominal peak, never instead of it
-PEAK_BY_IMPL = {"h2": PEAK_H2_TFLOPS, "bx3": PEAK_BX3_TFLOPS, "tap": PEAK_FP32_MFMA_TFLOPS, "lds": PEAK_FP32_MFMA_TFLOPS}
+PEAK_BY_IMPL = {"h2": PEAK_H2_TFLOPS, "bx3": PEAK_BX3_TFLOPS, "tap": PEAK_FP32_MFMA_TFLOPS}
 
 # tracker table: name -> (scale, nc, kpt_shape, imgsz, conf, classes, pre_mode, channel_reverse)
 TRACKERS = {
@@ -91,10 +91,10 @@ def parse():
                     help="skip the leg with the reference's own default configuration (players yolov8m + pose + the "
                          "TrackNetV3 BallTracker, config.py:22,29-30,36-39)")
     ap.add_argument("--graph", type=int, default=-1, help="hipGraph replay of the op lists (tuning; -1 = engine default)")
-    ap.add_argument("--impl", default="h2", choices=["h2", "bx3", "tap", "lds"],
+    ap.add_argument("--impl", default="h2", choices=["h2", "bx3", "tap"],
                     help="fp32-equivalent conv arithmetic: h2 (default: activations as fp16 pairs, 3 products on the f16 matrix "
                          "pipe, corrections in their own accumulator), bx3 (exact 3-way bf16 split, 6 products; the full-range "
-                         "fallback of h2), tap (fp32-input MFMA, round 1's kernels), lds (their cross-check kernel)")
+                         "fallback of h2), tap (fp32-input MFMA: the strict-fp32 kernels)")
     ap.add_argument("--replay", type=int, default=0, help="tuning: frames per pass over the op list (0 = the whole batch)")
     ap.add_argument("--fake-engine", action="store_true",
                     help="TEST ONLY (tests/test_bench_gloo.py): run main() over tests/fake_engine.py with the gloo backend — the "
@@ -164,7 +164,7 @@ def make_state_dict(name, cfg, frames, frac=0.01, seed_offset=0):
 
 
 H2_CONV3_KERNELS = {"h2": ("conv_h2p_kernel", "conv_h2q_kernel", "conv_h2w_kernel", "conv_h2_kernel"),
-                    "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel"), "tap": ("conv_tap_kernel",), "lds": ("conv_lds_kernel",)}
+                    "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel"), "tap": ("conv_tap_kernel",)}
 
 
 def measure_traffic(a, ops_rows, tmp):
@@ -380,7 +380,7 @@ def main():
     eng = E.Engine(local)
     if a.graph >= 0:
         eng.set_tuning(graph=a.graph)
-    IMPL = {"tap": 0, "lds": 1, "bx3": 2, "h2": 2}
+    IMPL = {"tap": 0, "bx3": 2, "h2": 2}
     eng.set_tuning(impl=IMPL[a.impl])
     # RCCL communicator owned by the library (also with one rank: the broadcast path is exercised at N=1)
     eng.comm_init(D.share_unique_id(E.comm_unique_id), world, rank)

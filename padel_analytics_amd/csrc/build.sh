@@ -10,7 +10,7 @@ BUILD="${PADEL_BUILD_DIR:-build}"
 OUT="${PADEL_OUT:-../libpadel_hip.so}"
 mkdir -p "$BUILD"
 pids=()
-for f in conv_lds.hip conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_tap_h2.hip conv_tap_h2p.hip conv_patch_h2.hip conv_patch_h2q.hip conv_patch_h2w.hip conv_patch16.hip kernels_misc.hip stem_l1_h2.hip postproc.hip tracknet_post.hip; do
+for f in conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_tap_h2.hip conv_tap_h2p.hip conv_patch_h2.hip conv_patch_h2q.hip conv_patch_h2w.hip conv_patch16.hip kernels_misc.hip stem_l1_h2.hip postproc.hip tracknet_post.hip; do
   [ -f "$f" ] || continue
   hipcc $FLAGS -c "$f" -o "$BUILD/${f%.hip}.o" &
   pids+=($!)

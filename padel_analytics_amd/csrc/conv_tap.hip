@@ -231,7 +231,7 @@ __device__ __forceinline__ void tap_epilogue(const ConvArgs& a, const f32x4 (&ac
 // =====================================================================================================  3x3
 // DBG (tuning only, PADEL_CONV_DIAG=16 on the 64x96 tile): every wave stamps s_memtime at 5 points of every k-step
 // (step top / own requests landed / barrier passed / fragments in registers / last MFMA issued) into an LDS ring that is
-// dumped to a.dbg at the end — same dump format as conv_lds.hip's DIAG 16, read by tools/timeline_probe.py --kernel tap.
+// dumped to a.dbg at the end — read by tools/timeline_probe.py --kernel tap.
 template <int WM, int WN, int MF, int NF, bool DBG = false>
 __global__ void __launch_bounds__(64 * WM * WN, tap_min_waves(WM * WN, MF * NF)) conv_tap_kernel(const ConvArgs a) {
     PADEL_TAP_GEOMETRY(3)
@@ -457,7 +457,37 @@ static hipError_t launch_t(const ConvArgs& a_in, hipStream_t s) {
     return hipGetLastError();
 }
 
-// same variant ids as conv_lds.hip / conv_ring.hip; hipErrorNotSupported when the layer or the tile is not covered
+// tile ids of the fp32 id space (shared by the tap, bf16x3 (+0), h2 (+200) and fp16 families): waves WM x WN, fragments MF x NF per wave
+struct TileShape { int id, wm, wn, mf, nf; };
+static const TileShape tile_shapes[] = {
+    {0, 2, 2, 4, 4},   // 128 x 128
+    {1, 2, 2, 4, 3},   // 128 x  96
+    {2, 4, 1, 4, 4},   // 256 x  64
+    {3, 4, 1, 4, 3},   // 256 x  48
+    {4, 4, 1, 4, 2},   // 256 x  32
+    {5, 4, 1, 4, 1},   // 256 x  16
+    {6, 2, 2, 2, 4},   //  64 x 128
+    {7, 2, 2, 2, 3},   //  64 x  96
+    {8, 4, 1, 2, 5},   // 128 x  80
+    {9, 4, 1, 2, 4},   // 128 x  64
+    {10, 2, 2, 4, 2},  // 128 x  64 (2x2 waves)
+    {11, 4, 1, 2, 2},  // 128 x  32
+    {12, 4, 1, 2, 1},  // 128 x  16
+    // tap kernel only (conv_tap.hip): 8 waves per workgroup / 128 x 48
+    {13, 4, 2, 2, 3},  // 128 x  96
+    {14, 4, 2, 2, 4},  // 128 x 128
+    {15, 4, 2, 2, 2},  // 128 x  64
+    {20, 4, 1, 2, 3},  // 128 x  48
+    {25, 4, 1, 1, 5},  //  64 x  80 (bf16x3 kernels only)
+};
+
+bool conv_variant_shape(int variant, int* bm, int* bn) {
+    for (const auto& v : tile_shapes)
+        if (v.id == variant) { *bm = v.wm * v.mf * 16; *bn = v.wn * v.nf * 16; return true; }
+    return false;
+}
+
+// hipErrorNotSupported when the layer or the tile is not covered
 hipError_t launch_conv_tap(const ConvArgs& a, int variant, hipStream_t s) {
     if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16) return hipErrorNotSupported;
     switch (variant) {

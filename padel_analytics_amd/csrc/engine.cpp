@@ -19,7 +19,7 @@ using namespace padel;
 
 static thread_local std::string g_err;
 
-// Tuning knobs: read from the environment ONCE at pa_engine_create (PADEL_CONV_IMPL=tap|lds, PADEL_CONV_VARIANT,
+// Tuning knobs: read from the environment ONCE at pa_engine_create (PADEL_CONV_IMPL=tap|bx3, PADEL_CONV_VARIANT,
 // PADEL_CONV_TUNE, PADEL_CONV_TAP_PD, PADEL_GRAPH, PADEL_ALIAS), changed afterwards only through
 // pa_engine_set_tuning — the replay loop never touches getenv.
 struct Tuning {
@@ -155,7 +155,7 @@ int pa_engine_create(int device_id, pa_engine** out) {
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "zero page: %s", hipGetErrorString(r)); }
     r = padel::init_misc_kernels();
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "kernel attributes: %s", hipGetErrorString(r)); }
-    if (const char* v = getenv("PADEL_CONV_IMPL")) e->t.impl = (v[0] == 'l') ? 1 : (v[0] == 'b') ? 2 : 0;   // tap | lds | bx3
+    if (const char* v = getenv("PADEL_CONV_IMPL")) e->t.impl = (v[0] == 'b') ? 2 : 0;   // tap | bx3
     e->t.variant = env_int("PADEL_CONV_VARIANT", -1);
     e->t.tune = env_int("PADEL_CONV_TUNE", 1);
     e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
@@ -171,7 +171,7 @@ int pa_engine_create(int device_id, pa_engine** out) {
 int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     if (!e || !key) return 1;
     const std::string k = key;
-    if (k == "impl") e->t.impl = (value >= 0 && value <= 2) ? value : 2;
+    if (k == "impl") e->t.impl = (value == 0) ? 0 : 2;      // 0: fp32-input MFMA tap kernels, 2: bf16x3 (1 was the LDS kernel: tools/legacy_conv)
     else if (k == "variant") e->t.variant = value;
     else if (k == "tune") e->t.tune = value;
     else if (k == "tap_pd") e->t.tap_pd = (value == 3) ? 3 : 2;
@@ -720,7 +720,7 @@ static int conv_launch_args(const pa_model* m, size_t i, int n, ConvArgs& a) {
     const int lv = e->t.variant >= 0 ? e->t.variant
                    : f16 ? choose_conv_tap16_variant(a)
                    : use_bx3 ? choose_conv_bx3_variant(a)
-                         : (use_tap ? choose_conv_tap_variant(a.M, a.n16) : choose_conv_lds_variant(a.M, a.n16));
+                         : choose_conv_tap_variant(a.M, a.n16);
     if (use_bx3 && fold_active(m, (int)i) && (o.ksize == 1 || (lv >= 300 && lv < 400 && conv_bx3p_supported(a)))) {
         const pa_op_desc& u = m->ops[m->fold_src[i]];       // the first up_c channels come from the coarse map
         a.in2 = m->bptr[u.in_buf]; a.in2_cs = m->bufs[u.in_buf].channels; a.in2_choff = u.in_choff; a.up_c = u.cin;
@@ -792,11 +792,8 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
                 r = launch_conv_tap16(a, lv, s);
             } else if (use_bx3) {
                 r = launch_conv_bx3(a, lv, s);
-            } else if (use_tap) {
-                r = launch_conv_tap(a, lv, s);
-                if (r == hipErrorNotSupported && e->t.variant < 0) r = launch_conv_lds(a, choose_conv_lds_variant(a.M, a.n16), s);
             } else {
-                r = launch_conv_lds(a, lv, s);
+                r = launch_conv_tap(a, lv, s);
             }
             if (dbg_dev) {
                 (void)hipStreamSynchronize(s);

@@ -39,7 +39,7 @@ struct ConvArgs {
     int out_f32;          // fp16 / h2 kernels only: 1 = `out` is an fp32 buffer (convs that feed the Detect/Pose decode)
     const float* oscale;  // h2 kernels: [Npad] 1 / (power-of-two scale of the weight row), applied before the bias
     unsigned* ovf_flag;   // h2 kernels: set to 1 when an output value does not fit the fp16 range (h2_common.h)
-    unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_lds.hip DIAG 16
+    unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_tap.hip
     // m / (Ho*Wo) and rem / Wo without an integer-division sequence (conv_tap.hip prologue): q = (umulhi(n, magic) + n) >> shift,
     // exact for 0 <= n < 2^31 (fill_fastdiv below; the conv kernels' rows satisfy n < 2^31)
     unsigned howo_magic, howo_shift, wo_magic, wo_shift;
@@ -53,13 +53,10 @@ inline void fill_fastdiv(unsigned d, unsigned* magic, unsigned* shift) {
 constexpr int kConvDbgSteps = 64;                       // k-steps kept per wave (ring)
 constexpr int kConvDbgWords = 8 + 4 * kConvDbgSteps * 5;   // u64 words per workgroup: header + 4 waves x steps x 5 stamps
 
-// Two generations of the implicit-GEMM conv on v_mfma_f32_16x16x4_f32 ship in the library: the default tap-unrolled
-// LDS-DMA ring (conv_tap.hip) and the register-staged LDS kernel (conv_lds.hip), kept as its bitwise cross-check
-// (same K order and accumulation blocks => identical results; tests/test_gpu_conv.py).  Three retired generations
-// live in tools/legacy_conv/ and are not built.  Tile variants share one id space (conv_variant_shape).
-hipError_t launch_conv_lds(const ConvArgs& a, int variant, hipStream_t s);     // ids 0..12
-int conv_lds_num_variants();
-int choose_conv_lds_variant(int M, int n16);
+// The implicit-GEMM conv on v_mfma_f32_16x16x4_f32 (strict fp32: the cross-check / no-argument leg) is the tap-unrolled LDS-DMA
+// ring of conv_tap.hip.  The register-staged LDS kernel of round 1 — its bitwise cross-check until round 5, 75-104 vs 109-124
+// TFLOP/s (profiles/r5e_f32_tap_vs_lds.txt) — and three more retired generations live in tools/legacy_conv/ and are not
+// built.  Tile variants of every family share one id space (conv_variant_shape).
 bool conv_variant_shape(int variant, int* bm, int* bn);                         // false: unknown id
 // conv_tap.hip reads up to 128 B past the last chunk of a pixel / weight row, so every buffer a conv reads is
 // allocated with kConvReadSlack extra bytes; hipErrorNotSupported when the layer or the tile is not covered

@@ -105,7 +105,57 @@ __global__ void __launch_bounds__(256) resample_pass_kernel(const ResamplePassAr
     }
 }
 
+// The vertical pass from 3-byte to 4-byte pixels (the pose tracker's 720p -> 1280 x 1280 stretch is exactly this pass: the width
+// stays 1280) with FOUR output pixels per thread: an input row contributes 12 bytes = 3 aligned dwords per thread instead of
+// 12 byte loads, the 4 output pixels leave as one 16-byte store instead of 16 byte stores.  Same integer arithmetic per
+// channel (22-bit fixed point, accumulator from 1 << 21, >> 22, clip): byte-exact the generic kernel / Pillow.  Round 5: the
+// generic kernel moved this pass at 0.9 TB/s (0.68 ms per 64-frame pose batch).  Needs in_w % 4 == 0 and 4-byte aligned rows.
+__global__ void __launch_bounds__(256) resample_vpass4_kernel(const ResamplePassArgs a) {
+    const int qw = a.out_w >> 2;                                // groups of 4 pixels per row
+    const long long total = (long long)a.B * a.out_h * qw;
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int xq = (int)(i % qw);
+        const long long t = i / qw;
+        const int y = (int)(t % a.out_h);
+        const int b = (int)(t / a.out_h);
+        const int lo = a.bounds[y * 2], n = a.bounds[y * 2 + 1];
+        const int32_t* k = a.coefs + (long long)y * a.ksize;
+        int acc[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) acc[c] = 1 << 21;
+        const uint32_t* col = reinterpret_cast<const uint32_t*>(a.in + ((long long)b * a.in_h * a.in_w + xq * 4) * 3);
+        const long long rowd = (long long)a.in_w * 3 / 4;      // dwords per input row
+        for (int j = 0; j < n; ++j) {
+            const uint32_t* p = col + (long long)(lo + j) * rowd;
+            const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+            const int kk = k[j];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                acc[c] += (int)((d0 >> (8 * c)) & 255u) * kk;
+                acc[4 + c] += (int)((d1 >> (8 * c)) & 255u) * kk;
+                acc[8 + c] += (int)((d2 >> (8 * c)) & 255u) * kk;
+            }
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const unsigned v0 = (unsigned)min(max(acc[3 * px] >> 22, 0), 255), v1 = (unsigned)min(max(acc[3 * px + 1] >> 22, 0), 255),
+                           v2 = (unsigned)min(max(acc[3 * px + 2] >> 22, 0), 255);
+            o[px] = a.reverse ? (v2 | (v1 << 8) | (v0 << 16)) : (v0 | (v1 << 8) | (v2 << 16));
+        }
+        uint4 o4 = {o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<uint4*>(a.out + (((long long)b * a.out_h + y) * a.out_w + xq * 4) * 4) = o4;
+    }
+}
+
 hipError_t launch_resample_pass(const ResamplePassArgs& a, hipStream_t s) {
+    if (a.vertical && a.in_c == 3 && a.out_c == 4 && (a.in_w & 3) == 0 && a.out_w == a.in_w &&
+        (reinterpret_cast<uintptr_t>(a.in) & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && (((long long)a.in_h * a.in_w * 3) & 3) == 0) {
+        const long long total4 = (long long)a.B * a.out_h * (a.out_w >> 2);
+        const int grid4 = (int)((total4 + 255) / 256 > 65536 ? 65536 : (total4 + 255) / 256);
+        hipLaunchKernelGGL(resample_vpass4_kernel, dim3(grid4), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const long long total = (long long)a.B * a.out_h * a.out_w;
     const int grid = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
     hipLaunchKernelGGL(resample_pass_kernel, dim3(grid), dim3(256), 0, s, a);
@@ -418,9 +468,10 @@ __global__ void __launch_bounds__(NT) sppf_h2_kernel(float* buf, int cs, int cho
         __syncthreads();
     }
 }
-// The same for fp16 buffers (8 channels = one 16-byte vector per pixel and workgroup).  OPT-IN (tuning fuse_sppf >= 5), written
-// at the end of round 4: same head maps and detections as the three launches (tests/test_gpu_fp16.py), but not yet TIMED — the
-// fp16 graphs keep their three pool5_kernel launches until it has been (c4: 0.35 ms per step in the three launches).
+// The same for fp16 buffers (8 channels = one 16-byte vector per pixel and workgroup).  Written at the end of round 4, timed at
+// the start of round 5 (profiles/r5e_sppf_f16.txt, c4 = 64 x 1080p fp16: players 0.053 -> 0.033, ball 0.029 -> 0.016, pose 0.258 ->
+// 0.188 ms) and the default of fp16 graphs since (fuse_sppf = 0: the three pool5_kernel launches); same head maps and
+// detections as the three launches (tests/test_gpu_fp16.py).
 template <int NT>
 __global__ void __launch_bounds__(NT) sppf_f16_kernel(_Float16* buf, int cs, int choff, int c, int B, int H, int W) {
     extern __shared__ unsigned long long sppf_lds[];
@@ -534,7 +585,7 @@ hipError_t launch_sppf_pool(float* buf, int cs, int choff, int c, int B, int H, 
         }
         return hipSuccess;
     }
-    if (f16 == 1 && fused >= 5 && !((c | choff | cs) & 7) && (size_t)2 * H * W * 16 <= kSppfMaxLds && (long long)B * (c / 8) < (1ll << 31)) {
+    if (f16 == 1 && fused && !((c | choff | cs) & 7) && (size_t)2 * H * W * 16 <= kSppfMaxLds && (long long)B * (c / 8) < (1ll << 31)) {
         const size_t lds = (size_t)2 * H * W * 16;
         const dim3 grid((unsigned)(B * (c / 8)));
         _Float16* hb = reinterpret_cast<_Float16*>(buf);

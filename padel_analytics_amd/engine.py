@@ -316,10 +316,15 @@ class _PinnedBlock:
     before the memory itself can be freed, which the views handed out keep alive."""
 
     def __init__(self, engine, nbytes: int):
+        import mmap
         size = _round_up(max(int(nbytes), 1), _PAGE)
-        self._raw = np.zeros(size + _PAGE, np.uint8)
-        skip = (-self._raw.ctypes.data) % _PAGE
-        self.block = self._raw[skip:skip + size]
+        # an anonymous mapping of its own, not malloc memory: glibc serves numpy arrays of this size from the brk heap once its
+        # dynamic mmap threshold has grown (after the first multi-megabyte array was freed), and pages of the heap that were
+        # registered, unregistered and then handed to an unrelated array made a later pageable hipMemcpy from that array fault
+        # on the GPU (round 5, tests/test_gpu_pipeline.py::test_close_with_a_ticket_in_flight_then_reuse_the_pages).  A private
+        # mapping is page-aligned, zero-filled, and its addresses go back to the kernel — not to malloc — when the views die
+        self._mm = mmap.mmap(-1, size)
+        self.block = np.frombuffer(self._mm, np.uint8)
         self.engine = engine
         engine.pin(self.block)
         self._pinned = True
@@ -329,8 +334,11 @@ class _PinnedBlock:
             self._pinned = False
             try:
                 self.engine.unpin(self.block)
-            except Exception:
-                pass
+            except Exception as exc:
+                # the pages stay registered and their memory is about to be freed: say so (a later copy from memory that
+                # lands on these addresses fails inside the runtime)
+                import sys
+                print(f"padel_analytics_amd: hipHostUnregister of a result block failed ({exc}); pages left registered", file=sys.stderr)
 
     def __del__(self):
         self.release()

@@ -163,7 +163,9 @@ class TrackingRunner:
             allp = D.gather_results(partial, dst=0)
         if rank == 0:
             def merge():
-                tracker.results.predictions = tracker.merge_partials(allp)
+                from .tracker import relaxed_gc
+                with relaxed_gc():
+                    tracker.results.predictions = tracker.merge_partials(allp)
                 print(f"{tracker.__str__()}: {len(tracker.results)} predictions.")
                 return timeit.default_timer()
             # The sequential stage (ByteTrack ids over ALL frames in global order: ~60 us per frame of host C++) is rank 0's

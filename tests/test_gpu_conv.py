@@ -1,6 +1,6 @@
 """GPU unit test of the fp32-storage conv kernels through the C-ABI (the h2 kernels — the default arithmetic since round 3
 — have their own file, tests/test_gpu_h2.py): every tile variant of the fp32-input MFMA generations (tap-unrolled LDS-DMA
-kernels conv_tap.hip, and the register-staged LDS kernel conv_lds.hip kept as their cross-check) and of the bf16x3 kernels
+kernels conv_tap.hip; the register-staged LDS kernel of round 1 that used to cross-check them is retired: tools/legacy_conv/conv_lds.hip) and of the bf16x3 kernels
 (conv_tap_bx3.hip / conv_patch_bx3.hip: the full-range fallback of h2) against torch.nn.functional.conv2d (fp64 CPU), on
 shapes that exercise stride 2, 1x1, the 16-channel K tail (cin % 32 == 16) including the full-chunk -> tail wrap of the tap
 kernel's request ring, partial channel tiles (cout = 80 -> 5 fragments), the M tail, the fused residual and every
@@ -31,7 +31,6 @@ CASES = [
     (1, 20, 27, 688, 96, 1, 1, G.ACT_SILU, False),    # 1x1 with long K: 21 full chunks + a 16-channel tail = three accumulation blocks (9 + 9 + 4), M tail
 ]
 
-LDS_VARIANTS = tuple(range(13))
 TAP_VARIANTS = (6, 7, 9, 10, 11, 12, 13, 14, 15, 20)
 BX3_VARIANTS = (6, 7, 9, 11, 12, 13, 14, 20, 25, 206, 207, 209, 211, 220, 225, 213, 303, 304, 306)      # bf16x3 kernels (conv_tap_bx3.hip): fp32 accuracy, own rounding
 
@@ -74,9 +73,6 @@ def test_conv_variants(gpu_engine, case):
     scale = max(1.0, float(np.abs(want).max()))
     outs = {}
     try:
-        for v in LDS_VARIANTS:
-            gpu_engine.set_tuning(impl=1, variant=v)
-            outs[f"L{v}"] = _run(gpu_engine, case, x, w, b, wr)
         for v in TAP_VARIANTS:                            # LDS-DMA ring: twice, a DMA / barrier race is not deterministic
             gpu_engine.set_tuning(impl=0, variant=v)
             for rep in range(2):

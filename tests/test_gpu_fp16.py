@@ -173,7 +173,7 @@ def test_fp16_graph_vs_emulation_and_fp32_oracle(gpu_engine, scale, nc, kpt, hw,
 
 
 def test_fused_sppf_fp16_matches_three_pool_launches(gpu_engine):
-    """sppf_f16_kernel (tuning fuse_sppf=5; opt-in until it has been timed): same head maps (as numbers: a maximum does not depend on the walk, the sign of a zero
+    """sppf_f16_kernel (the default of fp16 graphs since round 5: 0.34 -> 0.24 ms per c4 step, profiles/r5e_sppf_f16.txt; fuse_sppf=0: three launches): same head maps (as numbers: a maximum does not depend on the walk, the sign of a zero
     may) and the same detections as the three pool5_kernel launches."""
     from padel_analytics_amd import yolo_arch
     from tests import synth
@@ -183,10 +183,10 @@ def test_fused_sppf_fp16_matches_three_pool_launches(gpu_engine):
         m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None, dtype="f16"))
         m.set_max_batch(2)
         try:
-            gpu_engine.set_tuning(fuse_sppf=1)
+            gpu_engine.set_tuning(fuse_sppf=0)
             b0, _, c0 = m.yolo_infer(frames, 2, h, w, imgsz=imgsz, conf=0.25, iou=0.7)
             h0 = [m.read_head(l, 2) for l in range(3)]
-            gpu_engine.set_tuning(fuse_sppf=5)
+            gpu_engine.set_tuning(fuse_sppf=1)
             b1, _, c1 = m.yolo_infer(frames, 2, h, w, imgsz=imgsz, conf=0.25, iou=0.7)
             h1 = [m.read_head(l, 2) for l in range(3)]
         finally:

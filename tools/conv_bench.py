@@ -6,7 +6,7 @@ profiling on and prints TFLOP/s per (shape, tile).  Kernel / tile selection goes
 (no environment variables, one process).
 
     python tools/conv_bench.py                                  # sweep: auto + every tap tile
-    python tools/conv_bench.py --tiles auto,T7,T13,L7,Ap3       # Tn tap tile n, Ln LDS-kernel tile n, Ap3 = auto, 1x1 PD 3
+    python tools/conv_bench.py --tiles auto,T7,T13,Ap3          # Tn tap tile n, Ap3 = auto, 1x1 PD 3
     python tools/conv_bench.py --shapes P3.bneck,1x1 --reps 5
 """
 import argparse
@@ -80,8 +80,6 @@ def main():
             kw = dict(impl=0, variant=-1, tap_pd=2)        # "auto" / Tn / Apn: the fp32-MFMA tap kernels
             if t.startswith("T"):
                 kw.update(variant=int(t[1:]))
-            elif t.startswith("L"):
-                kw.update(impl=1, variant=int(t[1:]))
             elif t.startswith("B"):                       # bf16x3 kernels: B = auto tile, Bn = tile n
                 kw.update(impl=2, variant=int(t[1:]) if len(t) > 1 else -1)
             elif t.startswith("Ap"):

@@ -45,9 +45,7 @@ cmp("B=2 run twice", a2, heads(2, frames[:2]))
 cmp("B=64 vs B=2 (default)", a64, a2)
 cmp("B=64 vs B=4", a64, heads(4, frames[:4]))
 cmp("B=64 vs B=2, alias=0 both", heads(64, frames, alias=0), heads(2, frames[:2], alias=0))
-cmp("B=64 vs B=2, LDS kernel both", heads(64, frames, impl=1), heads(2, frames[:2], impl=1))
 for v in (7, 11):
     cmp(f"B=64 vs B=2, tap variant {v} both", heads(64, frames, variant=v), heads(2, frames[:2], variant=v))
-cmp("B=2: tap auto vs LDS auto", a2, heads(2, frames[:2], impl=1))
 cmp("B=2: tap auto vs tap variant 7", a2, heads(2, frames[:2], variant=7))
 cmp("B=64: tap auto vs tap variant 7", a64, heads(64, frames, variant=7))

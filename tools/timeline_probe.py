@@ -56,7 +56,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/timeline.txt")
     ap.add_argument("--dump", default="/tmp/padel_conv_timeline.bin")
-    ap.add_argument("--kernel", default="tap", choices=["lds", "tap", "h2q"],
+    ap.add_argument("--kernel", default="tap", choices=["tap", "h2q"],
                     help="tap = conv_tap_kernel (v5) timeline instantiation; h2q = conv_h2q_kernel (h2 quad patch kernel)")
     ap.add_argument("--cin", type=int, default=192)
     ap.add_argument("--cout", type=int, default=192)
