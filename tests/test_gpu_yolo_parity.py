@@ -45,6 +45,34 @@ def _calib(scale, nc, kpt, srcs, imgsz, conf, seed, dfl_scale=1.0, kpt_scale=1.0
     return sd
 
 
+def _check_heads(tag, m, sd, nc, kpt, srcs, S, n):
+    """Raw head maps of the engine (pa_yolo_read_head: [..., 64 + nc + nk] per level, fp32) against the oracle evaluated in
+    fp64 — the evidence for the CONV STACK that the attenuated-head coordinate tests cannot give (VERDICT r4 #6b).  Errors
+    relative to the largest value of the map; the fp32 CPU oracle's own distance from its fp64 evaluation is the yardstick:
+    L-inf <= max(2e-5, 1.5 x the oracle's), RMS <= max(2e-6, 1.25 x the oracle's) per level."""
+    o64 = ref.YoloV8Ref(sd, nc, kpt, dtype=torch.float64)
+    o32 = ref.YoloV8Ref(sd, nc, kpt)
+    x = ref.preprocess(list(srcs), S)
+    with torch.no_grad():
+        det, kp = o64.head_raw(o64.features(x.double()))
+        det32, kp32 = o32.head_raw(o32.features(x))
+    rep = {"linf_engine": [], "linf_oracle_fp32": [], "rms_engine": [], "rms_oracle_fp32": []}
+    for l in range(3):
+        want = (det[l] if not kp else torch.cat((det[l], kp[l]), 1)).permute(0, 2, 3, 1).numpy()
+        w32 = (det32[l] if not kp32 else torch.cat((det32[l], kp32[l]), 1)).permute(0, 2, 3, 1).numpy().astype(np.float64)
+        hd = m.read_head(l, n)[..., :want.shape[-1]].astype(np.float64)
+        sc = max(1.0, float(np.abs(want).max()))
+        e_inf, f_inf = float(np.abs(hd - want).max()) / sc, float(np.abs(w32 - want).max()) / sc
+        e_rms, f_rms = float(np.sqrt(np.mean((hd - want) ** 2))) / sc, float(np.sqrt(np.mean((w32 - want) ** 2))) / sc
+        for k, v in zip(rep, (e_inf, f_inf, e_rms, f_rms)):
+            rep[k].append(v)
+        assert e_inf <= max(2e-5, 1.5 * f_inf), f"{tag}: head level {l}: L-inf rel err vs fp64 {e_inf:.3e} (fp32 oracle: {f_inf:.3e})"
+        assert e_rms <= max(2e-6, 1.25 * f_rms), f"{tag}: head level {l}: RMS rel err vs fp64 {e_rms:.3e} (fp32 oracle: {f_rms:.3e})"
+    REPORT[f"{tag} head maps (rel. to max |value|, per level)"] = rep
+    print(f"{tag} head maps: engine L-inf {rep['linf_engine']} oracle {rep['linf_oracle_fp32']}; engine RMS {rep['rms_engine']} oracle {rep['rms_oracle_fp32']}")
+    return rep
+
+
 MODES = ("h2", "bx3")      # arithmetic of the fp32-equivalent path (engine.fp32_mode): fp16 pairs / exact bf16 triples
 
 
@@ -176,6 +204,7 @@ def test_pose_parity(gpu_engine, scale, S, kpt):
     sd = _calib(scale, 1, kpt, srcs, S, 0.25, seed=11)
     m, got = _engine_predict(gpu_engine, sd, 1, kpt, frames, imgsz=S, conf=0.25, iou=0.7, classes=[0],
                              pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
+    _check_heads(f"pose-{scale}-{S}-{kpt[0]}x{kpt[1]}", m, sd, 1, kpt, srcs, S, len(frames))
     _check(f"pose-{scale}-{S}-{kpt[0]}x{kpt[1]}", sd, 1, kpt, srcs, got, 0.25, 0.7, S)
     m.close()
 
@@ -194,17 +223,18 @@ def test_pose_parity_tight(gpu_engine, scale, S, f, mode):
     sd = _calib(scale, 1, kpt, srcs, S, 0.25, seed=11, dfl_scale=f, kpt_scale=f)
     m, got = _engine_predict(gpu_engine, sd, 1, kpt, frames, mode=mode, imgsz=S, conf=0.25, iou=0.7, classes=[0],
                              pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
+    _check_heads(f"pose-{scale}-{S}-tight [{mode}]", m, sd, 1, kpt, srcs, S, len(frames))
     _check(f"pose-{scale}-{S}-tight [{mode}]", sd, 1, kpt, srcs, got, 0.25, 0.7, S, tight=True)
     m.close()
 
 
-def _ratio_over_seeds(gpu_engine, label, runs, bound_rms=1.0, bound_linf=1.15):
+def _ratio_over_seeds(gpu_engine, label, runs, bound_rms=1.0, bound_linf=1.15, tight=True):
     """Shared body of the multi-seed statements: `runs` yields (tag, sd, nc, kpt, srcs, got, conf, S); every draw must
     pass the literal 1e-3 px bar on its low-noise heads, and the GEOMETRIC MEAN of engine-vs-fp64 / fp32-oracle-vs-fp64
     must not exceed bound_rms (RMS) / bound_linf (L-inf)."""
     ratios_rms, ratios_linf = [], []
     for tag, sd, nc, kpt, srcs, got, conf, S in runs:
-        _check(tag, sd, nc, kpt, srcs, got, conf, 0.7, S, tight=True)
+        _check(tag, sd, nc, kpt, srcs, got, conf, 0.7, S, tight=tight)
         r = REPORT[tag]
         ratios_rms.append(r["rms_engine_vs_fp64_px"] / r["rms_fp32_oracle_vs_fp64_px"])
         ratios_linf.append(r["engine_vs_fp64_px"] / r["fp32_oracle_vs_fp64_px"])
@@ -241,6 +271,61 @@ def test_pose_m_1280_tight_ratio_over_seeds(gpu_engine):
     _ratio_over_seeds(gpu_engine, "pose-m-1280-tight", runs())
 
 
+def test_pose_m_1280_full_noise_ratio_over_seeds(gpu_engine):
+    """VERDICT r4 #6a: the same statement on the FULL-NOISE heads of the bench's pose graph (no scaled-down last convs: the
+    fp32 oracle itself is 0.02-0.07 px from its fp64 evaluation there, and a single draw of the maximum over ~6 000
+    coordinates ranged 0.85-1.30 x the oracle's).  Four independently seeded clips + checkpoints: every draw inside the
+    noise-floor criterion of `_check`, geometric means of engine / oracle error <= 1.0 (RMS) and <= 1.15 (L-inf)."""
+    from PIL import Image
+
+    def runs():
+        kpt, S = (13, 3), 1280
+        for fseed, wseed in ((7, 11), (19, 29), (33, 39), (47, 53)):
+            frames = synth.synthetic_frames(1, 720, 1280, seed=fseed)
+            pil = [np.asarray(Image.fromarray(fr[..., ::-1].copy()).resize((S, S))) for fr in frames]
+            srcs = [p[..., ::-1] for p in pil]
+            sd = _calib("m", 1, kpt, srcs, S, 0.25, seed=wseed)
+            m, got = _engine_predict(gpu_engine, sd, 1, kpt, frames, imgsz=S, conf=0.25, iou=0.7, classes=[0],
+                                     pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
+            m.close()
+            yield f"pose-m-1280-full-noise seeds {fseed}/{wseed} [{E.fp32_mode()}]", sd, 1, kpt, srcs, got, 0.25, S
+    _ratio_over_seeds(gpu_engine, "pose-m-1280-full-noise", runs(), tight=False)
+
+
+def test_detect_m_tight_outlier_is_decode_rounding(gpu_engine):
+    """VERDICT r4 #6c: on seeds 13 / 17 the players graph's L-inf vs fp64 is 3.0 x the fp32 oracle's (3.7e-4 vs 1.2e-4 px)
+    while its RMS ratio is 1.1.  If that maximum came from the convolution arithmetic it would move with the arithmetic;
+    it does not: the fp16-pair kernels (h2) and the exact bf16-triple kernels (bx3) — different products, different
+    summation trees — put the SAME worst error on the SAME coordinate.  It is rounding in the fp32 decode / rescale chain
+    (DFL expectation, dist2bbox, x stride, the letterbox inverse): a grid coordinate of the stride-32 level (16 .. 20 cells)
+    has an fp32 ulp of 1.9e-6 cells, which x 32 (stride) x 2 (1 / gain of the 720p letterbox) is 1.2e-4 px — the oracle's
+    torch ops and the kernel's fused form round those few operations differently by three such ulps (3.7e-4 px, measured
+    identically to the last digit on both arithmetics: profiles/parity_report_r5.json)."""
+    frames = synth.synthetic_frames(3, 720, 1280, seed=13)
+    srcs = [f[..., ::-1] for f in frames]
+    sd = _calib("m", 80, None, srcs, 640, 0.5, seed=17, dfl_scale=0.02)
+    r64 = ref.predict(ref.YoloV8Ref(sd, 80, None, dtype=torch.float64), srcs, 0.5, 0.7, 640, classes=[0])
+    b64, _, c64 = _as_arrays(r64)
+    errs = {}
+    for mode in MODES:
+        m, (boxes, _, counts) = _engine_predict(gpu_engine, sd, 80, None, frames, mode=mode, imgsz=640, conf=0.5, iou=0.7, classes=[0])
+        m.close()
+        assert np.array_equal(counts, c64)
+        errs[mode] = np.abs(boxes[..., :4].astype(np.float64) - b64[..., :4].astype(np.float64))
+    wh, wb = errs["h2"].max(), errs["bx3"].max()
+    ih, ib = np.unravel_index(errs["h2"].argmax(), errs["h2"].shape), np.unravel_index(errs["bx3"].argmax(), errs["bx3"].shape)
+    coord = float(b64[ih[0], ih[1], ih[2]])
+    ulp = float(np.spacing(np.float32(abs(coord))))
+    REPORT["detect-m-tight seeds 13/17: where the maximum sits"] = {
+        "h2": {"worst_px": float(wh), "at": [int(v) for v in ih]}, "bx3": {"worst_px": float(wb), "at": [int(v) for v in ib]},
+        "coordinate_px": coord, "fp32_ulp_there_px": ulp, "worst_in_ulps": float(wh / ulp)}
+    print("worst h2", wh, ih, "worst bx3", wb, ib, "coordinate", coord, "ulp", ulp)
+    grid_ulp_px = float(np.spacing(np.float32(16.0))) * 32 * 2       # one ulp of a stride-32 grid coordinate, in frame pixels
+    assert tuple(ih) == tuple(ib), (ih, ib)                           # same coordinate of the same box ...
+    assert abs(wh - wb) <= 1e-6, (wh, wb)                             # ... with the same error, whatever the conv arithmetic
+    assert wh <= 4 * grid_ulp_px, (wh, grid_ulp_px)
+
+
 def test_ball_n_nc1_tight_ratio_over_seeds(gpu_engine):
     """The same statement for the bench's ball graph (yolov8n detect, nc = 1, 720p letterboxed to 384 x 640)."""
     def runs():
@@ -250,6 +335,8 @@ def test_ball_n_nc1_tight_ratio_over_seeds(gpu_engine):
             sd = _calib("n", 1, None, srcs, 640, 0.25, seed=wseed, dfl_scale=0.02)
             m, got = _engine_predict(gpu_engine, sd, 1, None, frames, imgsz=640, conf=0.25, iou=0.7, classes=None,
                                      channel_reverse=False)
+            if fseed == 5:                         # head maps of the bench's ball graph against fp64 (once)
+                _check_heads(f"detect-n-nc1 seeds {fseed}/{wseed} [{E.fp32_mode()}]", m, sd, 1, None, srcs, 640, len(frames))
             m.close()
             yield f"detect-n-nc1-tight seeds {fseed}/{wseed} [{E.fp32_mode()}]", sd, 1, None, srcs, got, 0.25, 640
     _ratio_over_seeds(gpu_engine, "detect-n-nc1-tight", runs())
