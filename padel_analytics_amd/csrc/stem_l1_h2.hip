@@ -5,8 +5,14 @@
 // the stem phase is stem_mfma_kernel's arithmetic (kernels_misc.hip), the conv phase walks K like conv_h2_kernel.
 //
 // A workgroup owns 4 x 16 output pixels of layer 1 and all of its 2c channels.
-//   phase 1: the 9 x 33 stem pixels under that tile (19 fragments of 16 positions over the 4 waves; fp32 MFMA, K = 27 -> 32,
-//            bias, fast SiLU, pair encoding) go to LDS — zeros where layer 1 sees its padding — in COLUMN-PARITY planes:
+//   phase 1: the 9 x 33 stem pixels under that tile (19 fragments of 16 positions over the 4 waves; ROUND 5: on the F16 matrix
+//            pipe — the u8 input bytes ARE fp16 numbers (0..255, exact, no correction part), the stem weights divided by 255
+//            are split into row-scaled fp16 pairs in the kernel's prologue, so a 16 x 16 fragment is TWO
+//            v_mfma_f32_16x16x32_f16 (main wh x v, correction wm x v; K = 27 -> 32) instead of the EIGHT
+//            v_mfma_f32_16x16x4_f32 (32 cycles each) of the stand-alone stem kernel: 32 instead of 256 matrix-pipe cycles
+//            per fragment, 3 600 of a wave's ~15 700 busy cycles per tile.  sum w (v / 255) becomes sum (w / 255) v: the same
+//            value to fp32 rounding (the stand-alone stem kernel keeps the literal order; tests/test_gpu_h2.py compares the
+//            two to 2e-5 of the head maps).  Then bias, fast SiLU, pair encoding) go to LDS — zeros where layer 1 sees its padding — in COLUMN-PARITY planes:
 //            entry ((row * 2 + (col & 1)) * 17 + col / 2), so that the stride-2 window of a tap (cols 2 ox + kx) is 16
 //            CONSECUTIVE entries, read as MFMA operands exactly like the stride-1 patch kernels read theirs;
 //   phase 2: layer 1 from those planes: waves as 2 row pairs x 2 channel halves (2 x NF fragments each), weights through the
@@ -46,9 +52,8 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
     static_assert(S_B + NSTG * BSTAGE_B + 1024 <= 80 * 1024, "2 workgroups per CU");
     __shared__ __attribute__((aligned(16))) float lds[(S_B + NSTG * BSTAGE_B + 1024) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
-    float* const lut = lds + (S_B + NSTG * BSTAGE_B) / 4;
+    float* const s_osc = lds + (S_B + NSTG * BSTAGE_B) / 4;        // 1 / row scale of the stem's weight rows (NF x 16 floats)
     const int tid = threadIdx.x;
-    lut[tid] = (float)tid / 255.0f;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 1, wc = wave >> 1;
@@ -93,29 +98,52 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
     } while (0)
     PADEL_FS_DMAB(0);
     PADEL_FS_DMAB(1);
-    __syncthreads();                                 // the u8 -> float table
 
-    // ---- phase 1 operands: per owned fragment i (global fragment wave + 4 i) the 8 K slots of this lane (k = 4 kk + lq ->
-    // tap (dy, dx), colour byte), gathered with UNCONDITIONAL loads from clamped coordinates and masked afterwards
-    float wreg[NF][8];
-    f32x4 bias4[NF];
+    // ---- phase 1 operands.  K slot kk of lane group lq is k = 8 lq + kk -> tap (dy, dx) = (k / 9, k / 3 % 3), colour byte k % 3
+    // (k >= 27: zero weights AND zero data).  Weights of row lr = channel 16 j + lr: w / 255, scaled by the power of two that
+    // puts the row's largest magnitude into [2^12, 2^13) (graph.py:h2_row_scale), split into fp16 pairs like the packed weights
+    // of every other h2 layer; every wave computes all NF rows sets (24 values per lane), wave 0 publishes the inverse scales.
+    h16x8 wfh[NF], wfm[NF];
+    f32x4 bias4[NF], osc4[NF];
     int kdy[8], kdx[8], ksh[8];
     bool kval[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) {
-        const int k = 4 * kk + lq;
+        const int k = 8 * lq + kk;
         kval[kk] = k < 27;
         const int t = k / 3;
         ksh[kk] = 8 * (k - 3 * t);
         kdy[kk] = t / 3;
         kdx[kk] = t - 3 * kdy[kk];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) wreg[j][kk] = kval[kk] ? st.w[(j * 16 + lr) * 27 + k] : 0.0f;
     }
 #pragma unroll
-    for (int j = 0; j < NF; ++j) bias4[j] = *reinterpret_cast<const f32x4*>(st.bias + j * 16 + lq * 4);
+    for (int j = 0; j < NF; ++j) {
+        float wv[8], mx = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            wv[kk] = kval[kk] ? st.w[(j * 16 + lr) * 27 + 8 * lq + kk] / 255.0f : 0.0f;
+            mx = fmaxf(mx, fabsf(wv[kk]));
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));              // the row's largest |w / 255| (its 27 weights sit in the 4 lanes lr + 16 q)
+        const int ex = (int)((__float_as_uint(mx) >> 23) & 255u);          // biased exponent: floor(log2 mx) + 127
+        const int e = ex == 0 ? 0 : min(max(139 - ex, -100), 100);         // 12 - floor(log2 mx); denormal / all-zero rows: scale 1
+        const float sc = __uint_as_float((unsigned)(e + 127) << 23), isc = __uint_as_float((unsigned)(127 - e) << 23);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float x = wv[kk] * sc;
+            const _Float16 hh = (_Float16)x;
+            wfh[j][kk] = hh;
+            wfm[j][kk] = (_Float16)((x - (float)hh) * kH2Scale);
+        }
+        if (wave == 0 && lq == 0) s_osc[j * 16 + lr] = isc;
+        bias4[j] = *reinterpret_cast<const f32x4*>(st.bias + j * 16 + lq * 4);
+    }
+    __syncthreads();                                 // the inverse scales
+#pragma unroll
+    for (int j = 0; j < NF; ++j) osc4[j] = *reinterpret_cast<const f32x4*>(s_osc + j * 16 + lq * 4);
     const uint32_t* const img = reinterpret_cast<const uint32_t*>(st.in) + (long long)n * st.H * st.W;
-    float av[kFPerWave][8];
+    h16x8 apx[kFPerWave];                            // per owned position fragment: the 8 K slots of this lane as fp16 (exact bytes)
     int s_ent[kFPerWave];                            // LDS entry of the fragment's position of this lane, -1: no such position
     bool s_in[kFPerWave];                            // the position lies inside the stem map (else layer 1 sees its zero padding)
 #pragma unroll
@@ -130,7 +158,7 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
         uint32_t pxw[8];
         bool okk[8];
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk < 8; ++kk) {             // UNCONDITIONAL loads from clamped coordinates, masked afterwards
             const int iy = sy * 2 - 1 + kdy[kk], ix = sx * 2 - 1 + kdx[kk];
             okk[kk] = s_in[i] && kval[kk] && (unsigned)iy < (unsigned)st.H && (unsigned)ix < (unsigned)st.W;
             const int iyc = min(max(iy, 0), st.H - 1), ixc = min(max(ix, 0), st.W - 1);
@@ -138,8 +166,8 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
         }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            const float v = lut[(pxw[kk] >> ksh[kk]) & 255u];
-            av[i][kk] = okk[kk] ? v : 0.0f;
+            const int v = okk[kk] ? (int)((pxw[kk] >> ksh[kk]) & 255u) : 0;
+            apx[i][kk] = (_Float16)v;
         }
     }
     bool bad = false;
@@ -148,16 +176,16 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
 #define PADEL_FS_STEM(J0_, NJ_, TL_)                                                                              \
     do {                                                                                                          \
         _Pragma("unroll") for (int i = 0; i < kFPerWave; ++i) {                                                   \
-            f32x4 sacc[NJ_];                                                                                      \
-            _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) sacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};              \
-            _Pragma("unroll") for (int kk = 0; kk < 8; ++kk)                                                      \
-                _Pragma("unroll") for (int j = 0; j < (NJ_); ++j)                                                 \
-                    sacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[(J0_) + j][kk], av[i][kk], sacc[j], 0, 0, 0); \
+            f32x4 smain[NJ_], scross[NJ_];                                                                        \
+            _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                                   \
+                scross[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfm[(J0_) + j], apx[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
+                smain[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wfh[(J0_) + j], apx[i], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);  \
+            }                                                                                                     \
             if (s_ent[i] >= 0) {                                                                                  \
                 _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                               \
                     f32x4 v;                                                                                      \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                               \
-                        const float x = h2_act<ACT_SILU>(sacc[j][r] + bias4[(J0_) + j][r]);                       \
+                        const float x = h2_act<ACT_SILU>(fmaf(fmaf(scross[j][r], kH2InvScale, smain[j][r]), osc4[(J0_) + j][r], bias4[(J0_) + j][r])); \
                         v[r] = s_in[i] ? x : 0.0f;                                                                \
                     }                                                                                             \
                     h16x4 hv, mv;                                                                                 \

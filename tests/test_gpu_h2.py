@@ -334,9 +334,12 @@ def test_fused_sppf_matches_three_pool_launches(gpu_engine, scale, hw, imgsz):
 @pytest.mark.parametrize("scale,hw,imgsz", [("n", (360, 640), 640), ("s", (180, 320), 288), ("m", (180, 320), 288), ("m", (360, 640), 640)],
                          ids=["n-640", "s-288", "m-288", "m-640"])
 def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
-    """Tuning "fuse_stem" (csrc/stem_l1_h2.hip, on by default since round 4): model.0 + model.1 as one kernel — the stem map stays in LDS.  Same
-    arithmetic in the same order as the two kernels it replaces: head maps and detections are bitwise those of the unfused
-    run (c = 16: tail-only K walk; 32: one chunk; 48: chunk + tail with the LDS region reused; partial tiles at 288)."""
+    """Tuning "fuse_stem" (csrc/stem_l1_h2.hip, on by default since round 4): model.0 + model.1 as one kernel — the stem map stays in
+    LDS (c = 16: tail-only K walk; 32: one chunk; 48: chunk + tail with the LDS region reused; partial tiles at 288).  Layer 1 is
+    the arithmetic of the kernel it replaces; the stem phase runs on the f16 matrix pipe since round 5 — sum (w / 255) v over the
+    exact input bytes v with w / 255 as an fp16 pair, two MFMAs per fragment, instead of sum w (v / 255) on the fp32-input MFMA:
+    the same numbers to fp32 rounding, so the head maps of the two runs agree like two fp32 evaluations of one graph do
+    (measured 2e-6 .. 6e-6 of the largest head value) and the detections are the same set within a fraction of the noise floor."""
     from padel_analytics_amd import yolo_arch
     from tests import synth
     h, w = hw
@@ -364,5 +367,8 @@ def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
     assert n_convs1 == n_convs0 - 1, "the fused kernel did not run (layer 1 was launched on its own)"
     for l, (x, y) in enumerate(zip(h0, h1)):
         assert np.isfinite(y).all()
-        assert np.array_equal(x, y), f"head {l}: max difference {np.abs(x - y).max():.3e}"
-    assert np.array_equal(c0, c1) and np.array_equal(b0, b1)
+        rel = float(np.abs(x - y).max()) / max(1.0, float(np.abs(x).max()))
+        print(f"fused vs unfused stem, {scale} {hw}: head {l} rel diff {rel:.2e}")
+        assert rel <= 3e-5, f"head {l}: relative difference {rel:.3e}"
+    assert np.array_equal(c0, c1) and int(c0.sum()) > 0
+    assert np.array_equal(b0[..., 5], b1[..., 5]) and float(np.abs(b0[..., :4] - b1[..., :4]).max()) <= 2e-2 and float(np.abs(b0[..., 4] - b1[..., 4]).max()) <= 1e-4
