@@ -102,7 +102,7 @@ def parse():
                          "carries \"fake_engine\": true and is not a measurement")
     ap.add_argument("--traffic", default="live", choices=["live", "static", "none"],
                     help="roofline.traffic: live = two rocprofv3 --pmc passes over this script's engine-only step (needs rocprofv3; "
-                         "falls back to static), static = the committed measurement profiles/r4_traffic.json")
+                         "falls back to static), static = the committed measurement profiles/r5_traffic.json")
     ap.add_argument("--no-eager", action="store_true", help="skip the eager-result-objects leg (value_eager_objects)")
     ap.add_argument("--quick", action="store_true", help="tuning runs: runner + engine-only + roofline only (no CPU leg, host-frames leg, reference-default leg)")
     ap.add_argument("--no-tight", action="store_true", help="skip the low-noise-head parity leg of the CPU baseline section")
@@ -720,7 +720,7 @@ def main():
                 rows_all += trackers[name].model._model.profile_rows()
             with contextlib.redirect_stdout(sys.stderr):
                 traffic = measure_traffic(a, rows_all, tmp)
-        tpath = ROOT / "profiles" / "r4_traffic.json"
+        tpath = ROOT / "profiles" / "r5_traffic.json"
         if traffic is None and a.traffic != "none" and tpath.exists():
             tj = json.loads(tpath.read_text()).get(f"{a.workload}-{a.impl}" if a.dtype == "f32" else "none")
             if tj:
@@ -728,7 +728,7 @@ def main():
                            "write_bytes_per_launch": tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                            "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"), "static": True,
-                           "source": "profiles/r4_traffic.json: " + tj["source"]}
+                           "source": "profiles/r5_traffic.json: " + tj["source"]}
         out["roofline"] = {
             "kernel": ("conv_p16_kernel<NF> / conv_p16q_kernel<NF> (stride-1 3x3 conv+BN+SiLU: input patch in LDS, taps as shifted "
                        "windows) + conv_tap16_kernel<WM,WN,MF,NF> (stride-2 3x3 implicit GEMM: LDS-DMA ring); v_mfma_f32_16x16x32_f16"
@@ -778,7 +778,7 @@ def main():
         ncores = min(os.cpu_count() or 1, 64)
         torch.set_num_threads(ncores)
         ns = 2                                      # parity sample (fp32 and fp64 oracle)
-        nt = max(ns, (a.cpu_sample or 8) // ns * ns)      # timed sample of the CPU baseline
+        nt = max(ns, (a.cpu_sample or 16) // ns * ns)     # timed sample of the CPU baseline: 16 frames = ~18 s of CPU work on the box's 64 threads for c3
         sample = frames[:ns]
         tcpu = 0.0
         if a.dtype != "f32":
@@ -800,7 +800,7 @@ def main():
             r32 = ref.predict(model, source_for_oracle(cfg, sample), cfg["conf"], 0.7, cfg["imgsz"], cfg["classes"])
             tcpu += time.perf_counter() - t1
             # the TIMED sample is larger than the parity sample (2 frames are a tiny baseline): nt frames in passes
-            # of ns, ~10-20 s of CPU work on the box's EPYC for c3; the parity statements stay on the first ns frames (their
+            # of ns, ~18 s of CPU work on the box's EPYC for c3 (round 4: 8 frames, 9 s); the parity statements stay on the first ns frames (their
             # fp64 evaluation is 3-4 x slower)
             for lo in range(ns, nt, ns):
                 t1 = time.perf_counter()

@@ -497,9 +497,10 @@ hipError_t launch_conv_h2p(const ConvArgs& a, int nf, hipStream_t s) {
     switch (nf) {
         case 3: return launch_hp<3, false>(a, s);
         case 4: return launch_hp<4, false>(a, s);
-        case 6: return launch_hp<6, false>(a, s);
         case 13: return launch_hp<3, true>(a, s);
-        case 14: return launch_hp<4, true>(a, s);
+        // (round 5 prune: the 6-fragment tile 306 — main product accumulated in ONE level for want of registers, no faster than
+        //  303 and 1.3-2 x its RMS error on long K, profiles/conv_h2_sweep_r3a.txt — and the software-pipelined 64-channel tile
+        //  314 — 10-15 % slower than 304, profiles/conv_h2_sweep_r3f_pipe.txt — were never chosen automatically: removed)
 #ifdef PADEL_H2P_PROBES
 #define PADEL_HP_PROBE_CASE(P_) case 32 + (P_): if (a.in2 || (a.cin & 16)) return hipErrorNotSupported; return launch_hpt<3, false, false, false, (P_)>(a, s);
         PADEL_HP_PROBE_CASE(1) PADEL_HP_PROBE_CASE(2) PADEL_HP_PROBE_CASE(3) PADEL_HP_PROBE_CASE(4) PADEL_HP_PROBE_CASE(5)

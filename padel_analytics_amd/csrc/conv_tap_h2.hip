@@ -224,7 +224,7 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         const int nf = variant - 300;
         if (conv_h2p_supported(a)) return launch_conv_h2p(a, nf, s);
         if (a.in2 && a.ksize == 3) return hipErrorNotSupported;      // an absorbed upsample in front of a 3x3: the patch kernel only
-        variant = (nf == 3 || nf == 13) ? 220 : (nf == 4 || nf == 14) ? 209 : 213;
+        variant = (nf == 3 || nf == 13) ? 220 : (nf == 4 || nf == 14) ? 209 : 213;      // where the patch kernel does not apply: its tap sibling
     }
     if (a.in2 && a.ksize == 3) return hipErrorNotSupported;
     if (variant == 243 || variant == 239) {   // 1x1 with the three-stage activation ring (conv_h2_1p_kernel); other kernel sizes: the plain tile

@@ -18,8 +18,8 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 303, 304, 306, 313, 314, 323, 341, 342, 343)      # 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
-H2_SINGLE_LEVEL = (306,)        # patch tile with 6 fragments: main product accumulated in one level (registers)
+H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 303, 304, 313, 323, 341, 342, 343)      # 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
+H2_SINGLE_LEVEL = ()            # (the 6-fragment patch tile 306 — main product accumulated in ONE level — was removed in round 5)
 
 def _graph(case, w, b, wr, dtype):
     B, H, W, cin, cout, k, s, act, use_res = case
@@ -98,10 +98,8 @@ def test_h2_conv_variants(gpu_engine, case):
         if not single:
             assert np.array_equal(y, ref), f"{name} differs bitwise from {ref_name} (max {np.abs(y - ref).max():.3e})"
     rms = lambda y: float(np.sqrt(np.mean((y - want) ** 2)))
-    print(f"case {case}: RMS error vs fp64  fp32-MFMA {rms(y32):.3e}  bf16x3 {rms(y3):.3e}  h2 {rms(ref):.3e}  h2 single-level {rms(outs['H306.0']):.3e}")
+    print(f"case {case}: RMS error vs fp64  fp32-MFMA {rms(y32):.3e}  bf16x3 {rms(y3):.3e}  h2 {rms(ref):.3e}")
     assert rms(ref) <= 1.25 * rms(y32) + 1e-9, (rms(ref), rms(y32))
-    # the single-level tile (never chosen automatically) pays for its one-level main sum on long K: bounded, not admitted
-    assert rms(outs["H306.0"]) <= 2.0 * rms(y32) + 1e-9, (rms(outs["H306.0"]), rms(y32))
 
 
 @pytest.mark.parametrize("xs,ws", [(1e-4, 1.0), (3e-6, 1e-3), (200.0, 1e-5), (1.0, 64.0)], ids=["tiny-x", "tiny-x-w", "big-x-tiny-w", "big-w"])
@@ -186,7 +184,7 @@ def test_h2_upsample_absorbed(gpu_engine, shape):
         gpu_engine.set_profiling(False)
         return y, n_up
 
-    absorbing = (220, 209, 213, 207, 243, 239) if k == 1 else (303, 304, 306)
+    absorbing = (220, 209, 213, 207, 243, 239) if k == 1 else (303, 304)
     keeping = () if k == 1 else (220,)
     try:
         ref, n_up = run(variant=220 if k == 1 else 303, fold_up=0)

@@ -292,38 +292,62 @@ def test_pose_m_1280_full_noise_ratio_over_seeds(gpu_engine):
     _ratio_over_seeds(gpu_engine, "pose-m-1280-full-noise", runs(), tight=False)
 
 
-def test_detect_m_tight_outlier_is_decode_rounding(gpu_engine):
-    """VERDICT r4 #6c: on seeds 13 / 17 the players graph's L-inf vs fp64 is 3.0 x the fp32 oracle's (3.7e-4 vs 1.2e-4 px)
-    while its RMS ratio is 1.1.  If that maximum came from the convolution arithmetic it would move with the arithmetic;
-    it does not: the fp16-pair kernels (h2) and the exact bf16-triple kernels (bx3) — different products, different
-    summation trees — put the SAME worst error on the SAME coordinate.  It is rounding in the fp32 decode / rescale chain
-    (DFL expectation, dist2bbox, x stride, the letterbox inverse): a grid coordinate of the stride-32 level (16 .. 20 cells)
-    has an fp32 ulp of 1.9e-6 cells, which x 32 (stride) x 2 (1 / gain of the 720p letterbox) is 1.2e-4 px — the oracle's
-    torch ops and the kernel's fused form round those few operations differently by three such ulps (3.7e-4 px, measured
-    identically to the last digit on both arithmetics: profiles/parity_report_r5.json)."""
+def test_detect_m_tight_outlier_in_grid_ulps(gpu_engine):
+    """VERDICT r4 #6c: on seeds 13 / 17 the players graph's L-inf vs fp64 was 3.0 x the fp32 oracle's (3.7e-4 vs 1.2e-4 px) while
+    its RMS ratio is 1.1.  What that "3.0" is: on this low-noise head every coordinate error is a small whole number of
+    GRID ULPS — one fp32 ulp of a stride-32 grid coordinate (16 .. 20 cells: 1.9e-6 cells) x 32 (stride) x 2 (1 / gain of the 720p
+    letterbox) = 1.22e-4 px.  Measured here and written to the report: the engine's decode / NMS / rescale kernels fed the
+    ORACLE's fp64 head maps (pa_yolo_postprocess, no engine convolution upstream) are 1 ulp from the fp64 decode — the fp32
+    oracle's own maximum; the full pipeline is 2-3 ulps at ONE or two of ~230 coordinates (3 under bx3, 2.5 - 3 under h2, not
+    always the same coordinate: logit noise of ~1e-6 at one anchor moves a DFL expectation by that much), 0-1 everywhere else.
+    The ratio of two maxima that are 3 and 1 quanta is the coarse statistic; the distribution is the statement, asserted: decode
+    alone <= 1.5 ulps, pipeline maximum <= 4 ulps under both arithmetics, at most 2 % of the coordinates above 1.5 ulps, and the
+    RMS within 1.5 x the oracle's (`_check`)."""
     frames = synth.synthetic_frames(3, 720, 1280, seed=13)
     srcs = [f[..., ::-1] for f in frames]
     sd = _calib("m", 80, None, srcs, 640, 0.5, seed=17, dfl_scale=0.02)
-    r64 = ref.predict(ref.YoloV8Ref(sd, 80, None, dtype=torch.float64), srcs, 0.5, 0.7, 640, classes=[0])
+    o64 = ref.YoloV8Ref(sd, 80, None, dtype=torch.float64)
+    r64 = ref.predict(o64, srcs, 0.5, 0.7, 640, classes=[0])
+    r32 = ref.predict(ref.YoloV8Ref(sd, 80, None), srcs, 0.5, 0.7, 640, classes=[0])
     b64, _, c64 = _as_arrays(r64)
-    errs = {}
+    b32, _, c32 = _as_arrays(r32)
+    assert np.array_equal(c32, c64)
+    valid = (np.arange(300)[None, :] < c64[:, None])[..., None] & np.ones(4, bool)
+    ulp = float(np.spacing(np.float32(16.0))) * 32 * 2
+    in_ulps = lambda b: (np.abs(b[..., :4].astype(np.float64) - b64[..., :4].astype(np.float64)) / ulp)[valid]
+    dist = {"fp32 oracle": in_ulps(b32)}
     for mode in MODES:
-        m, (boxes, _, counts) = _engine_predict(gpu_engine, sd, 80, None, frames, mode=mode, imgsz=640, conf=0.5, iou=0.7, classes=[0])
+        m, got = _engine_predict(gpu_engine, sd, 80, None, frames, mode=mode, imgsz=640, conf=0.5, iou=0.7, classes=[0])
+        assert np.array_equal(got[2], c64)
+        dist[mode] = in_ulps(got[0])
+        _check(f"detect-m-tight seeds 13/17 (ulp study) [{mode}]", sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
+        if mode == MODES[0]:
+            with torch.no_grad():
+                det, _ = o64.head_raw(o64.features(ref.preprocess(srcs, 640).double()))
+            cs = m.head_shapes(720, 1280, 640)[0][2]
+            heads = []
+            for l in range(3):
+                hm = det[l].permute(0, 2, 3, 1).numpy().astype(np.float32)
+                full = np.zeros(hm.shape[:3] + (cs,), np.float32)
+                full[..., :hm.shape[-1]] = hm
+                heads.append(full)
+            pb, _, pc = m.yolo_postprocess(heads, 720, 1280, imgsz=640, conf=0.5, iou=0.7, classes=[0])
+            assert np.array_equal(pc, c64)
+            dist["engine decode on the oracle's fp64 head maps"] = in_ulps(pb)
         m.close()
-        assert np.array_equal(counts, c64)
-        errs[mode] = np.abs(boxes[..., :4].astype(np.float64) - b64[..., :4].astype(np.float64))
-    wh, wb = errs["h2"].max(), errs["bx3"].max()
-    ih, ib = np.unravel_index(errs["h2"].argmax(), errs["h2"].shape), np.unravel_index(errs["bx3"].argmax(), errs["bx3"].shape)
-    coord = float(b64[ih[0], ih[1], ih[2]])
-    ulp = float(np.spacing(np.float32(abs(coord))))
-    REPORT["detect-m-tight seeds 13/17: where the maximum sits"] = {
-        "h2": {"worst_px": float(wh), "at": [int(v) for v in ih]}, "bx3": {"worst_px": float(wb), "at": [int(v) for v in ib]},
-        "coordinate_px": coord, "fp32_ulp_there_px": ulp, "worst_in_ulps": float(wh / ulp)}
-    print("worst h2", wh, ih, "worst bx3", wb, ib, "coordinate", coord, "ulp", ulp)
-    grid_ulp_px = float(np.spacing(np.float32(16.0))) * 32 * 2       # one ulp of a stride-32 grid coordinate, in frame pixels
-    assert tuple(ih) == tuple(ib), (ih, ib)                           # same coordinate of the same box ...
-    assert abs(wh - wb) <= 1e-6, (wh, wb)                             # ... with the same error, whatever the conv arithmetic
-    assert wh <= 4 * grid_ulp_px, (wh, grid_ulp_px)
+    rep = {k: {"max_ulps": round(float(v.max()), 2), "coords": int(v.size), "above_0.5": int((v > 0.5).sum()),
+               "above_1.5": int((v > 1.5).sum()), "above_2.5": int((v > 2.5).sum())} for k, v in dist.items()}
+    rep["grid_ulp_px"] = ulp
+    REPORT["detect-m-tight seeds 13/17: coordinate errors in grid ulps"] = rep
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, default=str)
+    print("errors in grid ulps:", rep)
+    assert dist["engine decode on the oracle's fp64 head maps"].max() <= 1.5
+    for mode in MODES:
+        assert dist[mode].max() <= 4.0, (mode, rep)
+        assert (dist[mode] > 1.5).mean() <= 0.02, (mode, rep)
 
 
 def test_ball_n_nc1_tight_ratio_over_seeds(gpu_engine):

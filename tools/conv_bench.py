@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--shapes", default="")
     ap.add_argument("--act", type=int, default=1, help="0 none, 1 SiLU, 2 ReLU (epilogue cost probe)")
     ap.add_argument("--tiles", default="auto,T6,T7,T9,T10,T11,T13,T14,T15,T20")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "h2"], help="f16: conv_tap16 kernels (tiles Tn = fp16 tile ids 6,7,9,11,12,20,30,31,32); h2: fp16-pair kernels (tiles Tn = 207,209,211,213,220,225,303,304,306)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "h2"], help="f16: conv_tap16 kernels (tiles Tn = fp16 tile ids 6,7,9,11,12,20,30,31,32); h2: fp16-pair kernels (tiles Tn = 207,209,211,213,220,225,239,243,303,304,313,323,341-343)")
     a = ap.parse_args()
     from padel_analytics_amd import engine as E, graph as G
     eng = E.default_engine(0)
