@@ -39,6 +39,11 @@ SHAPES = [
     ("n.P4.bneck 64->64", 64, 48, 80, 64, 64, 3, 1),
     ("n.P2.bneck 16->16", 64, 192, 320, 16, 16, 3, 1),
     ("n.P5.bneck 128->128", 64, 12, 20, 128, 128, 3, 1),
+    # the players graph's real map sizes (384 x 640 network input): where the 8 x 16 patches do not tile the map
+    ("players.P3 96->96 48x80", 64, 48, 80, 96, 96, 3, 1),
+    ("players.P4 192->192 24x40", 64, 24, 40, 192, 192, 3, 1),
+    ("players.P5 288->288 12x20", 64, 12, 20, 288, 288, 3, 1),
+    ("players.head 192->256 48x80", 64, 48, 80, 192, 256, 3, 1),
 ]
 
 
