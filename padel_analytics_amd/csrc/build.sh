@@ -3,7 +3,8 @@
 set -e
 cd "$(dirname "$0")"
 # PADEL_EXTRA_FLAGS=-DPADEL_BX3_PROBES adds the (wrong-result) ceiling-probe tiles 420 / 520 of conv_tap_bx3.hip,
-# -DPADEL_H2P_PROBES the ablation tiles 332.. of conv_patch_h2.hip; PADEL_OUT / PADEL_BUILD_DIR keep such a build apart
+# -DPADEL_H2P_PROBES the ablation tiles 332.. of conv_patch_h2.hip, -DPADEL_STEM_PROBE=1|2|4|5 the ablations of stem_l1_h2.hip
+# (profiles/r5m_stem_ablation.txt); PADEL_OUT / PADEL_BUILD_DIR keep such a build apart
 # from the product library (tools only)
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -Wno-unused-value ${PADEL_EXTRA_FLAGS:-}"
 BUILD="${PADEL_BUILD_DIR:-build}"

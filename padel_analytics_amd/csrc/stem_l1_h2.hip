@@ -162,7 +162,11 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
             const int iy = sy * 2 - 1 + kdy[kk], ix = sx * 2 - 1 + kdx[kk];
             okk[kk] = s_in[i] && kval[kk] && (unsigned)iy < (unsigned)st.H && (unsigned)ix < (unsigned)st.W;
             const int iyc = min(max(iy, 0), st.H - 1), ixc = min(max(ix, 0), st.W - 1);
+#if defined(PADEL_STEM_PROBE) && (PADEL_STEM_PROBE == 2 || PADEL_STEM_PROBE == 5)
+            pxw[kk] = (uint32_t)(iyc * 3 + ixc * 7);      // probe: no input gathers
+#else
             pxw[kk] = img[(long long)iyc * st.W + ixc];
+#endif
         }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
@@ -171,6 +175,11 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
         }
     }
     bool bad = false;
+#if defined(PADEL_STEM_PROBE) && (PADEL_STEM_PROBE == 1 || PADEL_STEM_PROBE == 5)
+#define PADEL_STEM_ACT(x_) (x_)                      // probe: no SiLU in the stem phase (wrong results)
+#else
+#define PADEL_STEM_ACT(x_) h2_act<ACT_SILU>(x_)
+#endif
     // stem fragments [J0_, J0_ + NJ_) of every owned position -> pairs in LDS.  TL_: they are the 16-channel tail group
     // (32 bytes per entry and plane), else halves 0 / 1 of the 32-channel chunk (64 bytes per entry and plane)
 #define PADEL_FS_STEM(J0_, NJ_, TL_)                                                                              \
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
                 _Pragma("unroll") for (int j = 0; j < (NJ_); ++j) {                                               \
                     f32x4 v;                                                                                      \
                     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                               \
-                        const float x = h2_act<ACT_SILU>(fmaf(fmaf(scross[j][r], kH2InvScale, smain[j][r]), osc4[(J0_) + j][r], bias4[(J0_) + j][r])); \
+                        const float x = PADEL_STEM_ACT(fmaf(fmaf(scross[j][r], kH2InvScale, smain[j][r]), osc4[(J0_) + j][r], bias4[(J0_) + j][r])); \
                         v[r] = s_in[i] ? x : 0.0f;                                                                \
                     }                                                                                             \
                     h16x4 hv, mv;                                                                                 \
@@ -329,7 +338,13 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
     const int fw = NF * wc;
     const bool fast = oy0 + 4 <= a.Ho && ox0 + 16 <= a.Wo && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
                       (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
+#if defined(PADEL_STEM_PROBE) && (PADEL_STEM_PROBE == 4 || PADEL_STEM_PROBE == 5)
+    ConvArgs a_lin = a;                              // probe: layer 1's epilogue without its SiLU (wrong results)
+    a_lin.act = ACT_NONE;
+    h2_epilogue<MF, NF>(a_lin, acc, cross, mpix, fw, lq, fast);
+#else
     h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
+#endif
 }
 
 // stem (h2 output, c = 16 / 32 / 48 channels) followed by a 3x3 stride-2 conv over exactly those channels with 2c outputs

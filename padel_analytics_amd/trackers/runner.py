@@ -260,8 +260,9 @@ class TrackingRunner:
         import sys
         interval = sys.getswitchinterval()                 # see Tracker._predict_batches: the device stage must get the GIL back quickly
         sys.setswitchinterval(min(interval, 2e-4))
+        from .tracker import relaxed_gc
         try:
-            with ThreadPoolExecutor(max_workers=1) as post:
+            with relaxed_gc(), ThreadPoolExecutor(max_workers=1) as post:
                 pending = []
                 for sample in batches():
                     for t in batch:
