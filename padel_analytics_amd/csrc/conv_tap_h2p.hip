@@ -143,7 +143,8 @@ hipError_t launch_conv_h2_deep(const ConvArgs& a, int variant, hipStream_t s) {
     if (a.ksize == 1) {
         if (variant == 243) return launch_h2t1p<4, 1, 2, 6>(a, s);
         if (variant == 239) return launch_h2t1p<4, 1, 2, 4>(a, s);
-        if (variant == 237) return launch_h2t1p<2, 2, 2, 3>(a, s);      //  64 x 96, 48 KB of ring: three workgroups per CU
+        // (64 x 96 with the deep ring — 48 KB, three workgroups per CU — measured like its two-stage sibling 207: 10-18 % behind
+        //  128 x 96 on every 1x1 shape, profiles/r5o_tiles_237.txt; not kept)
         // (128 x 96 as 2 x 2 waves of 4 x 3 fragments — 14 instead of 16 operand reads per 36 MFMAs — measured 1-2 % slower than
         //  243's 4 x 1 waves of 2 x 6: profiles/r5h_tiles_1x1_wave_grid.txt; not kept)
     }
