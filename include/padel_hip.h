@@ -30,7 +30,7 @@ extern "C" {
 typedef struct pa_engine pa_engine;
 typedef struct pa_model pa_model;
 
-#define PA_ABI_VERSION 3
+#define PA_ABI_VERSION 4
 
 /* ---- graph description (built on the host from a state_dict; see padel_analytics_amd/graph.py) ---- */
 
@@ -62,7 +62,14 @@ typedef struct pa_op_desc {
                                            0: not provided.  PA_DTYPE_H2 models: offset (> 0) of the conv's npad per-output-
                                            channel inverse weight-row scales (fp32)                                  */
     int64_t w_off, b_off;               /* offsets (in floats) of packed weights / bias in the blob */
+    int32_t flags;                      /* PA_OP_CONV of PA_DTYPE_H2 models: PA_CONV_W_SINGLE = the correction (m) plane of the packed
+                                           weights is all zero — the weights are fp16 numbers (what an Ultralytics checkpoint stores)
+                                           times the row's power of two, BatchNorm's scale travels in the per-channel output scale
+                                           instead — so the kernels skip the wm x ah product: TWO MFMAs per operand pair, not three.
+                                           Results do not depend on the flag (the skipped product is exactly zero).  ABI v4 */
+    int32_t pad_;
 } pa_op_desc;
+#define PA_CONV_W_SINGLE 1
 
 enum pa_task { PA_TASK_DETECT = 0, PA_TASK_POSE = 1, PA_TASK_TRACKNET = 2 };
 

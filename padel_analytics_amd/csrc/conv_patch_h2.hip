@@ -51,7 +51,8 @@ __device__ __forceinline__ void hp_lds_fence() { asm volatile("s_waitcnt lgkmcnt
 // bitwise equal to the plain schedule.
 // PROBE (builds with -DPADEL_H2P_PROBES only; WRONG results, ceilings for tools/conv_bench.py): bit 0 no barrier on tap
 // steps 1..8, bit 1 no weight reads there, bit 2 no weight requests there, bit 3 no patch reads there, bit 4 no MFMAs
-template <int NF, bool TAIL, bool UP, bool PIPE, int PROBE = 0>
+// WS: the packed weights' m plane is all zero (ConvArgs::w_single): no wm x ah product, no m-plane requests / reads (conv_patch_h2q.hip)
+template <int NF, bool TAIL, bool UP, bool PIPE, int PROBE = 0, bool WS = false>
 __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h2p_kernel(const ConvArgs a) {
     constexpr int MF = 2;
     constexpr bool TWOL = NF <= 4;               // two-level main accumulation (part -> acc once per chunk) where registers allow
@@ -139,7 +140,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
         const unsigned lw_ = ((SR_) & 1) ? lw1 : lw0;                                                             \
         const unsigned sb_ = (SB_);                                                                               \
         PADEL_HP_DMAB1(0, sb_);                                                                                   \
-        PADEL_HP_DMAB1(1, sb_ + 64u);                                                                             \
+        if constexpr (!WS) PADEL_HP_DMAB1(1, sb_ + 64u);                                                          \
     } while (0)
 #define PADEL_HP_DMAB1(PL_, S_)                                                                                   \
     do {                                                                                                          \
@@ -188,7 +189,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
         const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
-            wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256));          \
+            if constexpr (!WS) wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256)); \
         }                                                                                                         \
     } while (0)
 #define PADEL_HP_MFMA()                                                                                           \
@@ -196,8 +197,10 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[f], cross[f][j], 0, 0, 0);             \
-        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
-            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);             \
+        if constexpr (!WS) {                                                                                      \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)         \
+                cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);         \
+        }                                                                                                         \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             pmain[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], pmain[f][j], 0, 0, 0);             \
         __builtin_amdgcn_s_setprio(0);                                                                            \
@@ -226,7 +229,7 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
         const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh2[S_][j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));               \
-            wm2[S_][j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256));     \
+            if constexpr (!WS) wm2[S_][j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BN * 16 + j * 256)); \
         }                                                                                                         \
     } while (0)
 #define PADEL_HP_MFMA_CROSS(S_)                                                                                   \
@@ -234,8 +237,10 @@ __global__ void __launch_bounds__(256, (NF <= 3 && !UP && !PIPE) ? 3 : 2) conv_h
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh2[S_][j], am2[S_][f], cross[f][j], 0, 0, 0);   \
-        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
-            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm2[S_][j], ah2[S_][f], cross[f][j], 0, 0, 0);   \
+        if constexpr (!WS) {                                                                                      \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)         \
+                cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm2[S_][j], ah2[S_][f], cross[f][j], 0, 0, 0); \
+        }                                                                                                         \
         __builtin_amdgcn_s_setprio(0);                                                                            \
     } while (0)
 #define PADEL_HP_MFMA_MAIN(S_)                                                                                    \
@@ -473,6 +478,12 @@ static hipError_t launch_hpt(const ConvArgs& a_in, hipStream_t s) {
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + NF - 1) / NF;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    if constexpr (PROBE == 0) {
+        if (a.w_single) {
+            hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP, PIPE, 0, true>), grid, dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((conv_h2p_kernel<NF, TAIL, UP, PIPE, PROBE>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }

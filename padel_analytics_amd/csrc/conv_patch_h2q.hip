@@ -66,7 +66,11 @@ constexpr int kQDbgWords = 8 + 4 * kQDbgSteps * 5;
 
 }  // namespace
 
-template <int NF, bool DBG = false>
+// WS (round 5): the packed weights' m plane is all zero (ConvArgs::w_single — fp16 checkpoint weights, BatchNorm's scale in the
+// output scale): the wm x ah product, the m-plane weight requests and the wm operand reads are compiled out — 24 MFMAs, 2 weight
+// requests and 3 + 4 operand reads per tap and wave instead of 36 / 4 / 6 + 4.  Same results as the three-product kernel on such
+// weights (the skipped product is exactly zero).
+template <int NF, bool DBG = false, bool WS = false>
 __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
     constexpr int MF = 4;
     constexpr int BN = 2 * NF * 16;              // output channels per workgroup
@@ -161,8 +165,10 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
         const unsigned sb_ = (SB_);                                                                               \
         dma3<0>(voffB[0], rsrcB, sb_, lw_);                                                                       \
         dma3<1024>(voffB[1], rsrcB, sb_, lw_);                                                                    \
-        dma3<BPLANE_B>(voffB[0], rsrcB, sb_ + 64u, lw_);                                                          \
-        dma3<BPLANE_B + 1024>(voffB[1], rsrcB, sb_ + 64u, lw_);                                                   \
+        if constexpr (!WS) {                                                                                      \
+            dma3<BPLANE_B>(voffB[0], rsrcB, sb_ + 64u, lw_);                                                      \
+            dma3<BPLANE_B + 1024>(voffB[1], rsrcB, sb_ + 64u, lw_);                                               \
+        }                                                                                                         \
     } while (0)
     const int ld_off = (3 * wc) * 256 + lr * 16 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 2);      // floats
     const float* b_rd0 = lds + (2 * kQPatchB) / 4 + ld_off;
@@ -174,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
     for (int f = 0; f < MF; ++f)
 #pragma unroll
         for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
-    h16x8 ah[4], am[4], wh[NF], wm[NF];       // ah / am: input rows in 4 sliding slots (row r of the current kx in slot r & 3)
+    h16x8 ah[4], am[4], wh[NF], wm[NF];       // (wm unused with WS) ah / am: input rows in 4 sliding slots (row r of the current kx in slot r & 3)
     // input row R_ (0..5 of the wave's window) at column shift KX_ into its slot
 #define PADEL_HQ_READROW(R_, KX_)                                                                                 \
     do {                                                                                                          \
@@ -187,7 +193,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
         const float* const br_ = ((T_) & 1) ? b_rd1 : b_rd0;                                                      \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
-            wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256));     \
+            if constexpr (!WS) wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256)); \
         }                                                                                                         \
     } while (0)
     // the 9 products of output row F_ at tap row KY_ (its input row F_ + KY_ sits in slot (F_ + KY_) & 3)
@@ -196,8 +202,10 @@ __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
         constexpr int s_ = ((F_) + (KY_)) & 3;                                                                    \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[s_], cross[F_][j], 0, 0, 0);          \
-        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
-            cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[s_], cross[F_][j], 0, 0, 0);          \
+        if constexpr (!WS) {                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                        \
+                cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[s_], cross[F_][j], 0, 0, 0);      \
+        }                                                                                                         \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[s_], part[F_][j], 0, 0, 0);            \
     } while (0)
@@ -313,7 +321,8 @@ hipError_t launch_conv_h2q(const ConvArgs& a_in, hipStream_t s) {
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((conv_h2q_kernel<3>), grid, dim3(256), 0, s, a);
+    if (a.w_single) hipLaunchKernelGGL((conv_h2q_kernel<3, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_h2q_kernel<3>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -31,7 +31,8 @@ __device__ __forceinline__ unsigned hw_tail_off(int p, int s) { return (unsigned
 
 }  // namespace
 
-template <int NF, bool CHUNK, bool TAIL>
+// WS: the packed weights' m plane is all zero (ConvArgs::w_single): no wm x ah product, no m-plane requests / reads (conv_patch_h2q.hip)
+template <int NF, bool CHUNK, bool TAIL, bool WS = false>
 __global__ void __launch_bounds__(256, 2) conv_h2w_kernel(const ConvArgs a) {
     static_assert(CHUNK || TAIL, "cin = 32 CHUNK + 16 TAIL");
     constexpr int MF = 4;
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2w_kernel(const ConvArgs a) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int sp = wave + 4 * k;
-        haveB[k] = sp < 2 * NF;
+        haveB[k] = sp < (WS ? NF : 2 * NF);          // spans NF .. 2 NF - 1 are the m plane
         const int pl = sp / NF, g = sp - pl * NF;
         const int frag = min(f0 + min(g, NF - 1), a.n16 - 1);
         voffB[k] = (unsigned)(((frag - f0) * 16 + b_row) * rowb + pl * 64 + b_sc * 16);
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2w_kernel(const ConvArgs a) {
         const float* const br_ = ((ST_) & 1) ? b_rd1 : b_rd0;                                                     \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
-            wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256));     \
+            if constexpr (!WS) wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256)); \
         }                                                                                                         \
     } while (0)
     // the 3 NF products of output row F_ with the operands in slot S_
@@ -162,8 +163,10 @@ __global__ void __launch_bounds__(256, 2) conv_h2w_kernel(const ConvArgs a) {
     do {                                                                                                          \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[S_], cross[F_][j], 0, 0, 0);          \
-        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
-            cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[S_], cross[F_][j], 0, 0, 0);          \
+        if constexpr (!WS) {                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                        \
+                cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[S_], cross[F_][j], 0, 0, 0);      \
+        }                                                                                                         \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[S_], part[F_][j], 0, 0, 0);            \
     } while (0)
@@ -282,7 +285,11 @@ static hipError_t launch_hw(const ConvArgs& a_in, hipStream_t s) {
     a.n_mtiles = batch * ((a.Ho + 15) / 16) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + NF - 1) / NF;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    if (a.cin == 48) hipLaunchKernelGGL((conv_h2w_kernel<NF, true, true>), grid, dim3(256), 0, s, a);
+    if (a.w_single) {
+        if (a.cin == 48) hipLaunchKernelGGL((conv_h2w_kernel<NF, true, true, true>), grid, dim3(256), 0, s, a);
+        else if (a.cin == 32) hipLaunchKernelGGL((conv_h2w_kernel<NF, true, false, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2w_kernel<NF, false, true, true>), grid, dim3(256), 0, s, a);
+    } else if (a.cin == 48) hipLaunchKernelGGL((conv_h2w_kernel<NF, true, true>), grid, dim3(256), 0, s, a);
     else if (a.cin == 32) hipLaunchKernelGGL((conv_h2w_kernel<NF, true, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_h2w_kernel<NF, false, true>), grid, dim3(256), 0, s, a);
     return hipGetLastError();

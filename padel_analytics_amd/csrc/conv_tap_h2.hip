@@ -17,7 +17,7 @@
 namespace padel {
 
 // =====================================================================================================  3x3
-template <int WM, int WN, int MF, int NF>
+template <int WM, int WN, int MF, int NF, bool WS = false>
 __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_kernel(const ConvArgs a) {
     PADEL_H2T_GEOMETRY()
     unsigned voffA[AP][9];
@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_ke
 // =====================================================================================================  1x1
 // UP: the first a.up_c channels (whole 32-channel chunks) are read from a.in2, a map of half the spatial size, at
 // [y >> 1][x >> 1] — an nn.Upsample(2) + torch.cat in front of this conv that is never materialised
-template <int WM, int WN, int MF, int NF, bool UP>
+template <int WM, int WN, int MF, int NF, bool UP, bool WS = false>
 __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_1_kernel(const ConvArgs a) {
     PADEL_H2T_GEOMETRY()
     unsigned voffA[AP], voffT[AP], voffU[AP];
@@ -198,12 +198,15 @@ static hipError_t launch_h2t(const ConvArgs& a_in, hipStream_t s) {
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
     if (a.ksize == 3) {
         if (a.in2) return hipErrorNotSupported;
-        hipLaunchKernelGGL((conv_h2_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
+        if (a.w_single) hipLaunchKernelGGL((conv_h2_kernel<WM, WN, MF, NF, true>), grid, dim3(64 * WM * WN), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2_kernel<WM, WN, MF, NF>), grid, dim3(64 * WM * WN), 0, s, a);
     } else if (a.in2) {
         if (a.stride != 1 || (a.up_c & 31) || a.up_c <= 0 || a.up_c > a.cin || ((a.H | a.W) & 1)) return hipErrorNotSupported;
-        hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, true>), grid, dim3(64 * WM * WN), 0, s, a);
+        if (a.w_single) hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, true, true>), grid, dim3(64 * WM * WN), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, true>), grid, dim3(64 * WM * WN), 0, s, a);
     } else {
-        hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, false>), grid, dim3(64 * WM * WN), 0, s, a);
+        if (a.w_single) hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, false, true>), grid, dim3(64 * WM * WN), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2_1_kernel<WM, WN, MF, NF, false>), grid, dim3(64 * WM * WN), 0, s, a);
     }
     return hipGetLastError();
 }

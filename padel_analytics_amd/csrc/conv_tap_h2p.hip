@@ -25,7 +25,7 @@ namespace padel {
         const unsigned kb_ = (KB_);                                                                               \
         const unsigned lw_ = ((WS_) & 1) ? lwb1 : lwb0;                                                           \
         PADEL_H2P_WPL(lw_, 0, kb_);                                                                               \
-        PADEL_H2P_WPL(lw_, 1, kb_ + 64u);                                                                         \
+        if constexpr (!WS) PADEL_H2P_WPL(lw_, 1, kb_ + 64u);                                                      \
     } while (0)
 
 // =====================================================================================================  1x1, deep A ring
@@ -38,7 +38,7 @@ namespace padel {
 // W(J + 1) first, then A(J + 2); vmcnt is in-order per wave, so "all but the 2 AP newest" at the top of step J + 1 means
 // W(J + 1) and A(J + 1) have landed while A(J + 2) stays in flight.  Same products in the same order: bitwise the results
 // of conv_h2_1_kernel.
-template <int WM, int WN, int MF, int NF, bool UP>
+template <int WM, int WN, int MF, int NF, bool UP, bool WS = false>
 __global__ void __launch_bounds__(64 * WM * WN, MF * NF <= 6 ? 3 : 2) conv_h2_1p_kernel(const ConvArgs a) {
     constexpr int ASTG_ = 2 * (WM * MF * 16) * 16, WSTG_ = 2 * (WN * NF * 16) * 16;      // words per activation / weight stage
     PADEL_H2T_GEOMETRY_(3 * ASTG_ + 2 * WSTG_)
@@ -126,9 +126,11 @@ static hipError_t launch_h2t1p(const ConvArgs& a_in, hipStream_t s) {
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
     if (a.in2) {
         if (a.stride != 1 || (a.up_c & 31) || a.up_c <= 0 || a.up_c > a.cin || ((a.H | a.W) & 1)) return hipErrorNotSupported;
-        hipLaunchKernelGGL((conv_h2_1p_kernel<WM, WN, MF, NF, true>), grid, dim3(64 * WM * WN), 0, s, a);
+        if (a.w_single) hipLaunchKernelGGL((conv_h2_1p_kernel<WM, WN, MF, NF, true, true>), grid, dim3(64 * WM * WN), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2_1p_kernel<WM, WN, MF, NF, true>), grid, dim3(64 * WM * WN), 0, s, a);
     } else {
-        hipLaunchKernelGGL((conv_h2_1p_kernel<WM, WN, MF, NF, false>), grid, dim3(64 * WM * WN), 0, s, a);
+        if (a.w_single) hipLaunchKernelGGL((conv_h2_1p_kernel<WM, WN, MF, NF, false, true>), grid, dim3(64 * WM * WN), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2_1p_kernel<WM, WN, MF, NF, false>), grid, dim3(64 * WM * WN), 0, s, a);
     }
     return hipGetLastError();
 }

@@ -33,6 +33,8 @@ struct Tuning {
     int timeline = 0;    // 1: 3x3 tap launches of the 64x96 tile run the s_memtime-instrumented instantiation
     int alias = 1;       // 1: activation buffers share one arena by liveness, 0: disjoint ranges
     int fuse_stem = 1;   // 1: h2 YOLOv8 graphs run model.0 (stem) + model.1 (3x3 stride 2) as ONE kernel (stem_l1_h2.hip; default since round 4, 0 = two kernels)
+    int w_single = 1;    // 1 (default): h2 convs whose packed weights have an all-zero m plane (PA_CONV_W_SINGLE) skip the wm x ah product;
+                         // 0 (tests): all three products everywhere — bitwise the same results
     int fuse_sppf = 1;   // 1: h2 graphs run the three chained 5x5 max-pools of SPPF as ONE kernel (sppf_h2_kernel: keys in LDS, separable passes); 0 = three launches.  Bitwise the same maps
     int fold_up = 1;     // 1: an nn.Upsample(2) whose only reader is a bf16x3 1x1 conv is never materialised (the conv
                          // fetches those channels at [y >> 1][x >> 1] of the coarse map), 0: run the upsample kernel
@@ -181,6 +183,7 @@ int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     else if (k == "fold_up") e->t.fold_up = value ? 1 : 0;
     else if (!strcmp(key, "fuse_stem")) e->t.fuse_stem = value;
     else if (!strcmp(key, "fuse_sppf")) e->t.fuse_sppf = value;
+    else if (!strcmp(key, "w_single")) e->t.w_single = value ? 1 : 0;
     else PA_FAIL(e, "pa_engine_set_tuning: unknown key '%s'", key);
     e->tuning_epoch++;
     return 0;
@@ -710,6 +713,7 @@ static int conv_launch_args(const pa_model* m, size_t i, int n, ConvArgs& a) {
     if (h2) {
         a.oscale = m->d_w + o.reserved;
         a.ovf_flag = m->d_ovf;
+        a.w_single = (o.flags & PA_CONV_W_SINGLE) && e->t.w_single ? 1 : 0;
         const int lv = e->t.variant >= 0 ? e->t.variant : choose_conv_h2_variant(a);
         if (fold_active(m, (int)i) && (o.ksize == 1 || (lv >= 300 && lv < 400 && conv_h2p_supported(a)))) {
             const pa_op_desc& u = m->ops[m->fold_src[i]];       // the first up_c channels come from the coarse map

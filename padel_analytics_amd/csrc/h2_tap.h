@@ -1,5 +1,6 @@
 // The implicit-GEMM TAP machine of the h2 kernels (conv_tap_h2.hip: 2-stage ring; conv_tap_h2p.hip: 3-stage activation ring):
-// geometry, ring requests, the k-step and the epilogue call as macros shared by both files.
+// geometry, ring requests, the k-step and the epilogue call as macros shared by both files.  Every kernel that uses them has a
+// template parameter `bool WS` (the packed weights' m plane is all zero: ConvArgs::w_single — conv_patch_h2q.hip).
 #pragma once
 #include "h2_common.h"
 
@@ -17,13 +18,15 @@
         }                                                                                                         \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>((BR_) + j * 256));                  \
-            wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>((BR_) + BN * 16 + j * 256));        \
+            if constexpr (!WS) wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>((BR_) + BN * 16 + j * 256)); \
         }                                                                                                         \
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[f], cross[f][j], 0, 0, 0);             \
-        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
-            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);             \
+        if constexpr (!WS) {                /* WS: the weights' m plane is all zero (ConvArgs::w_single): product skipped */ \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)         \
+                cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);         \
+        }                                                                                                         \
         if constexpr (FIRST_) {                /* first step of an accumulation block: the main chain starts from the constant 0 */ \
             _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)         \
                 part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0); \
@@ -53,7 +56,7 @@
         dma3<BM * 64>((V0_), rsrcA, sa_ + 32u, PADEL_H2T_LW(SR_));                                                \
         if constexpr (AP >= 2) dma3<BM * 64 + RP * 64>((V1_), rsrcA, sa_ + 32u, PADEL_H2T_LW(SR_));               \
         PADEL_H2T_DMAB(SR_, 0, sb_);                                                                              \
-        PADEL_H2T_DMAB(SR_, 1, sb_ + 64u);                                                                        \
+        if constexpr (!WS) PADEL_H2T_DMAB(SR_, 1, sb_ + 64u);                                                     \
     } while (0)
 #define PADEL_H2T_DMAB(SR_, PL_, SB_)                                                                             \
     do {                                                                                                          \

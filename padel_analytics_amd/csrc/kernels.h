@@ -39,6 +39,8 @@ struct ConvArgs {
     int out_f32;          // fp16 / h2 kernels only: 1 = `out` is an fp32 buffer (convs that feed the Detect/Pose decode)
     const float* oscale;  // h2 kernels: [Npad] 1 / (power-of-two scale of the weight row), applied before the bias
     unsigned* ovf_flag;   // h2 kernels: set to 1 when an output value does not fit the fp16 range (h2_common.h)
+    int w_single;         // h2 kernels: 1 = the m plane of the packed weights is all zero (PA_CONV_W_SINGLE): the wm x ah product, its
+                          // weight requests and operand reads are skipped — two MFMAs per operand pair (same results: the product is 0)
     unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_tap.hip
     // m / (Ho*Wo) and rem / Wo without an integer-division sequence (conv_tap.hip prologue): q = (umulhi(n, magic) + n) >> shift,
     // exact for 0 <= n < 2^31 (fill_fastdiv below; the conv kernels' rows satisfy n < 2^31)

@@ -38,7 +38,8 @@ __device__ __forceinline__ int fs_entry(int srow, int scol) { return (srow * 2 +
 }  // namespace
 
 // NF = c / 16 = stem channel fragments = layer-1 fragments per wave (layer 1 has 2c channels: 2 NF fragments per channel half pair)
-template <int NF>
+// WS: layer 1's packed weights have an all-zero m plane (ConvArgs::w_single): no wm x ah product, no m-plane requests / reads
+template <int NF, bool WS = false>
 __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, const ConvArgs a) {
     constexpr bool CHUNK = NF >= 2, TAIL = (NF & 1) != 0;
     constexpr int NCF = CHUNK ? 2 : 0;               // stem fragments that form the 32-channel chunk
@@ -227,7 +228,7 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
         const float* const br_ = ((ST_) % 3) == 0 ? b_rd0 : ((ST_) % 3) == 1 ? b_rd1 : b_rd2;                     \
         _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             wh[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + j * 256));                    \
-            wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256));     \
+            if constexpr (!WS) wm[j] = __builtin_bit_cast(h16x8, *reinterpret_cast<const f32x4*>(br_ + BPLANE_B / 4 + j * 256)); \
         }                                                                                                         \
     } while (0)
 #define PADEL_FS_MFMA()                                                                                           \
@@ -235,8 +236,10 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
         __builtin_amdgcn_s_setprio(1);                                                                            \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], am[f], cross[f][j], 0, 0, 0);             \
-        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
-            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);             \
+        if constexpr (!WS) {                                                                                      \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)         \
+                cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wm[j], ah[f], cross[f][j], 0, 0, 0);         \
+        }                                                                                                         \
         _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
             part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[j], ah[f], part[f][j], 0, 0, 0);               \
         __builtin_amdgcn_s_setprio(0);                                                                            \
@@ -363,9 +366,15 @@ hipError_t launch_stem_l1_h2(const StemArgs& st, const ConvArgs& a_in, hipStream
     a.n_ntiles = 1;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8), 1, 1);
     switch (st.cout / 16) {
-        case 1: hipLaunchKernelGGL((stem_l1_h2_kernel<1>), grid, dim3(256), 0, s, st, a); break;
-        case 2: hipLaunchKernelGGL((stem_l1_h2_kernel<2>), grid, dim3(256), 0, s, st, a); break;
-        case 3: hipLaunchKernelGGL((stem_l1_h2_kernel<3>), grid, dim3(256), 0, s, st, a); break;
+        case 1: if (a.w_single) hipLaunchKernelGGL((stem_l1_h2_kernel<1, true>), grid, dim3(256), 0, s, st, a);
+                else hipLaunchKernelGGL((stem_l1_h2_kernel<1>), grid, dim3(256), 0, s, st, a);
+                break;
+        case 2: if (a.w_single) hipLaunchKernelGGL((stem_l1_h2_kernel<2, true>), grid, dim3(256), 0, s, st, a);
+                else hipLaunchKernelGGL((stem_l1_h2_kernel<2>), grid, dim3(256), 0, s, st, a);
+                break;
+        case 3: if (a.w_single) hipLaunchKernelGGL((stem_l1_h2_kernel<3, true>), grid, dim3(256), 0, s, st, a);
+                else hipLaunchKernelGGL((stem_l1_h2_kernel<3>), grid, dim3(256), 0, s, st, a);
+                break;
         default: return hipErrorNotSupported;
     }
     return hipGetLastError();

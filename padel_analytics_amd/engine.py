@@ -51,7 +51,7 @@ class pa_op_desc(C.Structure):
                 ("out_buf", C.c_int32), ("out_choff", C.c_int32), ("cout", C.c_int32),
                 ("ksize", C.c_int32), ("stride", C.c_int32), ("act", C.c_int32),
                 ("res_buf", C.c_int32), ("res_choff", C.c_int32), ("npad", C.c_int32), ("reserved", C.c_int32),
-                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+                ("w_off", C.c_int64), ("b_off", C.c_int64), ("flags", C.c_int32), ("pad_", C.c_int32)]
 
 
 class pa_model_desc(C.Structure):
@@ -161,7 +161,7 @@ def load_library():
     lib.pa_host_unregister.argtypes = [vp, vp]
     lib.pa_model_take_overflow.argtypes = [vp, C.POINTER(i32)]
     lib.pa_yolo_postprocess.argtypes = [vp, C.POINTER(vp), i32, i32, i32, C.POINTER(pa_yolo_params), vp, vp, vp]
-    if lib.pa_abi_version() != 3:
+    if lib.pa_abi_version() != 4:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
     return lib

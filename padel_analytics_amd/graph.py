@@ -191,6 +191,30 @@ def pack_conv_weight_h2(w: np.ndarray):
     return out, (1.0 / sc).astype(np.float32)
 
 
+def h2_weights_single(planes: np.ndarray) -> bool:
+    """True if the correction (m) plane of packed h2 weights is all zero: every weight is an fp16 number times its row's
+    power of two (include/padel_hip.h PA_CONV_W_SINGLE)."""
+    return not bool((planes[:, :, 1, :] & 0x7FFF).any())
+
+
+def fold_bn_split(sd, prefix: str, eps: float):
+    """The pieces of ``fold_bn`` kept apart: (raw conv weight, per-channel BatchNorm scale, folded bias) — the same fp32
+    operations in the same order for scale and bias; ``fold_bn``'s weight is ``raw * scale`` rounded to fp32."""
+    w = np.asarray(sd[f"{prefix}.conv.weight"], np.float32)
+    g = np.asarray(sd[f"{prefix}.bn.weight"], np.float32)
+    beta = np.asarray(sd[f"{prefix}.bn.bias"], np.float32)
+    mu = np.asarray(sd[f"{prefix}.bn.running_mean"], np.float32)
+    var = np.asarray(sd[f"{prefix}.bn.running_var"], np.float32)
+    scale = (g / np.sqrt(np.float32(eps) + var)).astype(np.float32)
+    bf = (beta - (g * mu) / np.sqrt(var + np.float32(eps))).astype(np.float32)
+    return w, scale, bf
+
+
+def fp16_exact(w: np.ndarray) -> bool:
+    w = np.asarray(w, np.float32)
+    return bool(np.array_equal(w.astype(np.float16).astype(np.float32), w))
+
+
 def fold_bn(sd, prefix: str, eps: float):
     """Conv+BN fold in fp32, same operation order as ultralytics' fuse_conv_and_bn."""
     w = np.asarray(sd[f"{prefix}.conv.weight"], np.float32)
@@ -243,10 +267,12 @@ class Graph:
         self.n_floats += arr.size + padn
         return off
 
-    def conv(self, src, dst, w, b, k, s, act, res=None, out_width=None):
+    def conv(self, src, dst, w, b, k, s, act, res=None, out_width=None, out_scale=None):
         """src = (buf, choff, width read), dst = (buf, choff).  ``w`` is (cout, cin, k, k) with the
         real channel counts; input channels are zero-padded up to the slice width, output channels up
-        to ``out_width`` (those rows are zero, so the kernel writes act(0) there)."""
+        to ``out_width`` (those rows are zero, so the kernel writes act(0) there).
+        ``out_scale`` (h2 graphs only): per-output-channel factor applied to the accumulated sum before the bias — BatchNorm's
+        scale kept out of the weights, so that a checkpoint's fp16 weights stay fp16 numbers (PA_CONV_W_SINGLE)."""
         sb, so, sw = src
         cout, cin = w.shape[:2]
         if sw % self.kalign:
@@ -265,12 +291,19 @@ class Graph:
         bp = np.zeros(npad, np.float32)
         bp[:cout] = b
         w3_off = 0
+        flags = 0
+        assert out_scale is None or self.dtype == DTYPE_H2, "out_scale: h2 graphs only"
         if self.dtype == DTYPE_F16:
             w_off = self._add(np.ascontiguousarray(pack_conv_weight(wp, 32).astype(np.float16)).view(np.float32))
         elif self.dtype == DTYPE_H2:
             planes, inv_scale = pack_conv_weight_h2(wp)
+            if out_scale is not None:             # (1 / row scale is a power of two: the product is the scale's own bits)
+                osc = np.ones(npad, np.float32)
+                osc[:cout] = np.asarray(out_scale, np.float32)
+                inv_scale = (inv_scale * osc).astype(np.float32)
+            flags = FLAG_W_SINGLE if h2_weights_single(planes) else 0
             w_off = self._add(np.ascontiguousarray(planes).view(np.float32))
-            w3_off = self._add(inv_scale)         # `reserved` of an h2 conv: its per-output-channel 1 / row scale
+            w3_off = self._add(inv_scale)         # `reserved` of an h2 conv: its per-output-channel output scale (1 / row scale [x BN scale])
         else:
             w_off = self._add(pack_conv_weight(wp))
             if self.bx3:            # the same weights pre-split for the bf16x3 kernels (engine tuning impl=2)
@@ -278,7 +311,8 @@ class Graph:
         b_off = self._add(bp)
         self.ops.append(dict(kind=OP_CONV, in_buf=sb, in_choff=so, cin=sw, out_buf=dst[0], out_choff=dst[1],
                              cout=ow, ksize=k, stride=s, act=act, res_buf=-1 if res is None else res[0],
-                             res_choff=0 if res is None else res[1], npad=npad, w_off=w_off, b_off=b_off, reserved=w3_off))
+                             res_choff=0 if res is None else res[1], npad=npad, w_off=w_off, b_off=b_off, reserved=w3_off,
+                             flags=flags))
 
     def blob(self) -> np.ndarray:
         return np.concatenate(self.chunks) if self.chunks else np.zeros(0, np.float32)
@@ -295,6 +329,10 @@ class Graph:
             total += 2.0 * hw * o["cout"] * kk
         return total
 
+
+FLAG_W_SINGLE = 1          # pa_op_desc.flags: PA_CONV_W_SINGLE (include/padel_hip.h)
+# tests / tuning (PADEL_UNFOLDED_BN=0): fold BatchNorm into the weights of h2 graphs even when the checkpoint's weights are fp16 numbers
+UNFOLDED_BN: bool = os.environ.get("PADEL_UNFOLDED_BN", "1") != "0"
 
 # tests / tuning (PADEL_HEAD_SPLIT=0|1): force the Detect / Pose head's first convs merged (False) or per branch (True)
 HEAD_SPLIT: Optional[bool] = {"0": False, "1": True}.get(os.environ.get("PADEL_HEAD_SPLIT", ""))
@@ -316,9 +354,25 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f
     eps = yolo_arch.BN_EPS
     fuse = lambda p: fold_bn(sd, p, eps)
 
-    def cbs(prefix, src, dst, k, s, res=None, out_width=None):
+    # h2 graphs: a checkpoint whose conv weights are fp16 numbers (Ultralytics stores `model.half()`) keeps them that way —
+    # BatchNorm's scale goes into the conv's per-channel output scale instead of into the weights, the correction plane of
+    # the packed weights is zero and the kernels run two products per operand pair instead of three (PA_CONV_W_SINGLE).
+    # sum(w a) * scale + shift instead of sum(fl32(w * scale) a) + shift: the same value to fp32 rounding (the head maps move
+    # by 0.12-0.18 x the fp32 oracle's own distance from its fp64 evaluation: DESIGN.md 3.5).  Any other weights: folded as before.
+    split_bn = g.dtype == DTYPE_H2 and UNFOLDED_BN
+
+    def parts(prefix):
+        """-> (weights to pack, bias, out_scale | None)"""
+        if split_bn:
+            w, sc, b = fold_bn_split(sd, prefix, eps)
+            if fp16_exact(w):
+                return w, b, sc
         w, b = fuse(prefix)
-        g.conv(src, dst, w, b, k, s, ACT_SILU, res, out_width)
+        return w, b, None
+
+    def cbs(prefix, src, dst, k, s, res=None, out_width=None):
+        w, b, sc = parts(prefix)
+        g.conv(src, dst, w, b, k, s, ACT_SILU, res, out_width, out_scale=sc)
 
     def nblocks(i):
         n = 0
@@ -418,20 +472,27 @@ def build_yolov8(sd, nc: int, kpt_shape: Optional[tuple] = None, dtype: str = "f
         tot = sum(widths)
         wcat = np.zeros((tot, chn, 3, 3), np.float32)
         bcat = np.zeros(tot, np.float32)
+        scat = np.ones(tot, np.float32)
         offs = []
         o = 0
-        for (br, wd, _, _), pw in zip(branches, widths):
-            w, b = fuse(f"model.22.{br}.{l}.0")
+        br_parts = [parts(f"model.22.{br}.{l}.0") for (br, _, _, _) in branches]
+        if any(p[2] is None for p in br_parts):           # one branch has to be folded: fold them all (one conv, one rule)
+            br_parts = [fuse(f"model.22.{br}.{l}.0") + (None,) for (br, _, _, _) in branches]
+        for (br, wd, _, _), pw, (w, b, sc) in zip(branches, widths, br_parts):
             wcat[o:o + wd] = w
             bcat[o:o + wd] = b
+            if sc is not None:
+                scat[o:o + wd] = sc
             offs.append(o)
             o += pw
+        use_sc = br_parts[0][2] is not None
         h0 = g.buf(lvl, tot)
         if split_head(lvl, tot):
             for (br, wd, _, _), pw, o in zip(branches, widths, offs):
-                g.conv((feat, 0, chn), (h0, o), wcat[o:o + wd], bcat[o:o + wd], 3, 1, ACT_SILU, out_width=pw)
+                g.conv((feat, 0, chn), (h0, o), wcat[o:o + wd], bcat[o:o + wd], 3, 1, ACT_SILU, out_width=pw,
+                       out_scale=scat[o:o + wd] if use_sc else None)
         else:
-            g.conv((feat, 0, chn), (h0, 0), wcat, bcat, 3, 1, ACT_SILU)
+            g.conv((feat, 0, chn), (h0, 0), wcat, bcat, 3, 1, ACT_SILU, out_scale=scat if use_sc else None)
         hd = g.buf(lvl, head_cs)
         for (br, wd, nout, hoff), pw, o in zip(branches, widths, offs):
             h1 = g.buf(lvl, pw)

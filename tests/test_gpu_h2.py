@@ -102,6 +102,82 @@ def test_h2_conv_variants(gpu_engine, case):
     assert rms(ref) <= 1.25 * rms(y32) + 1e-9, (rms(ref), rms(y32))
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[5], CASES[7], CASES[8], CASES[11], CASES[12]],
+                         ids=["3x3", "3x3-tail-res", "1x1", "1x1-res", "s2-res", "odd-size", "quad-192", "1x1-long-K"])
+def test_h2_two_product_mode_on_fp16_weights(gpu_engine, case):
+    """Round 5: a checkpoint's conv weights are fp16 numbers (Ultralytics stores ``model.half()``); with BatchNorm's scale kept
+    in the conv's per-channel OUTPUT scale instead of multiplied into them (``Graph.conv(out_scale=)``), the packed weights'
+    correction plane is all zero (``PA_CONV_W_SINGLE``) and the kernels run TWO products per operand pair instead of three
+    (wh x ah and wh x am; the skipped wm x ah is exactly zero).  Checked on every tile: the flag is set by the packer; the
+    two-product kernels give BITWISE the results of the three-product kernels on the same blob (tuning ``w_single=0``); against
+    fp64 conv2d with the exact weights w x scale the error stays inside the h2 bound (3e-6) and the RMS inside the admission
+    criterion against the fp32-input MFMA kernels run on the FOLDED fp32 weights (what the reference's fused model holds)."""
+    B, H, W, cin, cout, k, s, act, use_res = case
+    rng = np.random.default_rng(cin * 17 + cout + k)
+    x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32)
+    w = rng.normal(0, (2.0 / (cin * k * k)) ** 0.5, (cout, cin, k, k)).astype(np.float16).astype(np.float32)      # fp16 numbers
+    scale = rng.uniform(0.5, 2.0, cout).astype(np.float32)
+    b = rng.normal(0, 0.5, cout).astype(np.float32)
+    wr = rng.normal(0, (1.0 / cin) ** 0.5, (cout, cin, 1, 1)).astype(np.float32)
+    w_fold = (w.reshape(cout, -1) * scale[:, None]).reshape(w.shape).astype(np.float32)                        # fold_bn's product
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double()
+    w_exact = torch.from_numpy(w).double() * torch.from_numpy(scale).double()[:, None, None, None]
+    want = F.conv2d(xt, w_exact, torch.from_numpy(b).double(), stride=s, padding=k // 2)
+    want = {G.ACT_SILU: F.silu, G.ACT_RELU: F.relu, G.ACT_SIGMOID: torch.sigmoid, G.ACT_NONE: lambda t: t}[act](want)
+    if use_res:
+        want = want + F.conv2d(xt, torch.from_numpy(wr).double(), stride=s)
+    want = want.permute(0, 2, 3, 1).numpy()
+    sc = max(1.0, float(np.abs(want).max()))
+
+    def graph(dtype, weights, out_scale):
+        g = G.Graph(task=G.TASK_TRACKNET, dtype=dtype)
+        b0 = g.buf(0, cin)
+        lvl = 1 if s == 2 else 0
+        res = None
+        if use_res:
+            b2 = g.buf(lvl, G.pad16(cout))
+            g.conv((b0, 0, cin), (b2, 0), wr, np.zeros(cout, np.float32), 1, s, G.ACT_NONE)
+            res = (b2, 0)
+        b1 = g.buf(lvl, G.pad16(cout))
+        g.conv((b0, 0, cin), (b1, 0), weights, b, k, s, act, res=res, out_scale=out_scale)
+        g.head_buf = (b1, -1, -1)
+        return g
+
+    def run(g):
+        m = E.Model(gpu_engine, g)
+        m.set_max_batch(B)
+        y = m.tracknet_infer(x)[..., :cout]
+        assert not m.take_overflow()
+        m.close()
+        return y
+
+    g2 = graph(G.DTYPE_H2, w, scale)
+    assert g2.ops[-1]["flags"] & G.FLAG_W_SINGLE, "fp16 weights + out_scale must pack with an all-zero m plane"
+    g3 = graph(G.DTYPE_H2, w_fold, None)
+    assert not (g3.ops[-1]["flags"] & G.FLAG_W_SINGLE), "folded weights are not fp16 numbers"
+    outs = {}
+    try:
+        for v in H2_TILES + (-1,):
+            gpu_engine.set_tuning(variant=v, w_single=1)
+            outs[f"two-product H{v}"] = run(g2)
+            gpu_engine.set_tuning(variant=v, w_single=0)
+            outs[f"three-product kernels, same blob H{v}"] = run(g2)
+        gpu_engine.set_tuning(variant=-1, w_single=1)
+        y_fold = run(g3)                                                                  # the round-4 path: folded weights, 3 products
+        gpu_engine.set_tuning(impl=0, variant=-1)
+        y32 = run(graph(G.DTYPE_F32, w_fold, None))                                       # fp32-input MFMA kernels on the folded weights
+    finally:
+        gpu_engine.set_tuning(impl=2, variant=-1, w_single=1)
+    ref_name, ref = next(iter(outs.items()))
+    for name, y in outs.items():
+        err = float(np.abs(y - want).max()) / sc
+        assert err < 3e-6, f"{name}: rel err {err:.2e} vs fp64 conv2d on the exact weights"
+        assert np.array_equal(y, ref), f"{name} differs bitwise from {ref_name} (max {np.abs(y - ref).max():.3e})"
+    rms = lambda y: float(np.sqrt(np.mean((y - want) ** 2)))
+    print(f"case {case}: RMS vs fp64(w x scale)  two-product {rms(ref):.3e}  folded weights, three products {rms(y_fold):.3e}  fp32-MFMA on folded weights {rms(y32):.3e}")
+    assert rms(ref) <= 1.25 * rms(y32) + 1e-9, (rms(ref), rms(y32))
+
+
 @pytest.mark.parametrize("xs,ws", [(1e-4, 1.0), (3e-6, 1e-3), (200.0, 1e-5), (1.0, 64.0)], ids=["tiny-x", "tiny-x-w", "big-x-tiny-w", "big-w"])
 def test_h2_dynamic_range(gpu_engine, xs, ws):
     """fp16 subnormal parts (|x| < 6.1e-5: h is subnormal or 0, m carries the value) must survive the MFMA, and the

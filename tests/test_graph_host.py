@@ -205,3 +205,51 @@ def test_head_first_convs_per_branch_equal_the_merged_conv(nc, kpt, monkeypatch)
     assert count(G.build_yolov8(sd_m, nc, kpt, dtype="h2")) == count(G.build_yolov8(sd_m, nc, kpt, dtype="f32")) + extra
     sd_s = yolo_arch.synth_state_dict("s", nc, kpt, seed=2)           # 64 + 128 (+ 48) channels: whole 64- / 48-channel tiles
     assert count(G.build_yolov8(sd_s, nc, kpt, dtype="h2")) == count(G.build_yolov8(sd_s, nc, kpt, dtype="f32"))
+
+
+def test_unfolded_batchnorm_keeps_fp16_checkpoint_weights_single_plane():
+    """Round 5 (PA_CONV_W_SINGLE): an h2 YOLOv8 graph built from a checkpoint whose conv weights are fp16 numbers keeps them
+    unfolded — raw weights x row power of two in the h plane, an all-zero m plane, BatchNorm's scale in the per-channel output
+    scale — and flags every such conv; one weight that is not an fp16 number sends THAT conv back to the folded packing; other
+    dtypes never flag; PADEL_UNFOLDED_BN=0 folds everything.  The packed pieces reproduce fold_bn's numbers: h / rowscale x
+    output scale == w x BN scale exactly (products of a 11-bit and a 24-bit number fit a double)."""
+    from padel_analytics_amd import yolo_arch
+    sd = yolo_arch.synth_state_dict("n", 80, None, seed=3, cls_bias=-1.0)
+    assert all(G.fp16_exact(np.asarray(v)) for k, v in sd.items() if k.endswith("conv.weight"))
+    g = G.build_yolov8(sd, 80, None, dtype="h2")
+    convs = [o for o in g.ops if o["kind"] == G.OP_CONV]
+    assert convs and all(o["flags"] & G.FLAG_W_SINGLE for o in convs)
+    assert not any(o.get("flags", 0) for o in G.build_yolov8(sd, 80, None, dtype="f32").ops)
+    assert not any(o.get("flags", 0) for o in G.build_yolov8(sd, 80, None, dtype="f16").ops)
+    # the first conv after the stem (model.1): its packed planes and output scale against fold_bn
+    blob = g.blob()
+    o = convs[0]
+    w_raw, bn_scale, bf = G.fold_bn_split(sd, "model.1", yolo_arch.BN_EPS)
+    wf, bf2 = G.fold_bn(sd, "model.1", yolo_arch.BN_EPS)
+    assert np.array_equal(bf, bf2)
+    cout, cin = w_raw.shape[:2]
+    nsteps = len(G.bx3_ksteps(o["cin"], 3))
+    planes = blob[o["w_off"]:o["w_off"] + o["npad"] * nsteps * 2 * 32 // 2].view(np.uint16).reshape(o["npad"], nsteps, 2, 32)
+    assert not (planes[:, :, 1] & 0x7FFF).any()
+    osc = blob[o["reserved"]:o["reserved"] + o["npad"]]
+    h = planes[:, :, 0].view(np.float16).astype(np.float64)
+    # k-step t of the full chunk = tap (ky, kx) = (t % 3, t // 3), slots = channels (cin = 16 here: the tail pairs taps; use the sum)
+    got = (h * osc[:, None, None].astype(np.float64)).reshape(o["npad"], -1).sum(1)[:cout]
+    want = (w_raw.astype(np.float64) * bn_scale.astype(np.float64)[:, None, None, None]).reshape(cout, -1).sum(1)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-12)
+    assert np.allclose(got, wf.astype(np.float64).reshape(cout, -1).sum(1), rtol=2e-6)          # fold_bn's fp32 products: same to fp32 rounding
+    # one weight off the fp16 grid: that conv folds, the others stay single
+    sd2 = dict(sd)
+    w2 = np.asarray(sd["model.3.conv.weight"], np.float32).copy()
+    w2.flat[0] = np.float32(w2.flat[0]) * np.float32(1.0 + 2.0 ** -20)
+    sd2["model.3.conv.weight"] = w2
+    ops2 = [o2 for o2 in G.build_yolov8(sd2, 80, None, dtype="h2").ops if o2["kind"] == G.OP_CONV]
+    assert sum(1 for o2 in ops2 if not (o2["flags"] & G.FLAG_W_SINGLE)) == 1
+    old = G.UNFOLDED_BN
+    try:
+        G.UNFOLDED_BN = False
+        # (the head's last 1x1 convs have no BatchNorm: their weights are the checkpoint's fp16 numbers either way)
+        assert all(o2["act"] == G.ACT_NONE and o2["ksize"] == 1 for o2 in G.build_yolov8(sd, 80, None, dtype="h2").ops
+                   if o2["kind"] == G.OP_CONV and o2["flags"])
+    finally:
+        G.UNFOLDED_BN = old
