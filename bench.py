@@ -448,14 +448,17 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         # what the path computes in: NOT plain fp32 arithmetic on the default path — fp32-equivalent pairs of fp16
         "dtype": ("f16" if a.dtype == "f16" else
-                  "f32-equivalent (h2: activations / weights as fp16 pairs h + m/2048, 3 x f16 MFMA products, fp32 accumulate)" if a.impl == "h2" else
+                  "f32-equivalent (h2: activations as fp16 pairs h + m/2048, weights as pairs or — checkpoint weights that are fp16 numbers — as themselves with BatchNorm's scale applied after the sum; 3 or 2 f16 MFMA products, fp32 accumulate)" if a.impl == "h2" else
                   "f32 (bx3: exact 3-way bf16 split of fp32 operands, 6 x bf16 MFMA products, fp32 accumulate)" if a.impl == "bx3" else
                   "f32 (fp32-input MFMA)"),
         "data": "synthetic",
         "arithmetic": ("fp32-equivalent: every activation is an fp16 PAIR x ~ h + m/2048 (22-23 significant bits, 4 bytes per "
                        "channel) written once by its producer, weights pre-split the same way per scaled row; a product is "
                        "ah*wh + (ah*wm + am*wh)/2048 = 3 x v_mfma_f32_16x16x32_f16 with the corrections in their own fp32 "
-                       "accumulator — per-conv RMS error vs fp64 <= 1.25 x the fp32-MFMA kernels' (tests/test_gpu_h2.py), same "
+                       "accumulator (2 x where wm = 0: conv weights that are fp16 numbers, as Ultralytics checkpoints store them, are not "
+                       "multiplied by BatchNorm's scale on the host — the scale is applied per channel to the accumulated sum, "
+                       "sum(w a) * s + b instead of sum(fl32(w s) a) + b: the head maps move by 0.12-0.18 x the fp32 oracle's own distance "
+                       "from its fp64 evaluation and end up closer to it) — per-conv RMS error vs fp64 <= 1.25 x the fp32-MFMA kernels' (tests/test_gpu_h2.py), same "
                        "parity criteria; |x| > 65504 raises a flag and the call repeats on the bf16x3 kernels" if a.impl == "h2" else
                        "fp32 storage; conv products as an EXACT 3-way bf16 split of both operands, 6 of the 9 cross "
                        "products (dropped: < 2^-24 relative) on v_mfma_f32_16x16x32_bf16, fp32 accumulation — per-conv RMS "
@@ -710,6 +713,24 @@ def main():
         ms_all = sum(r["ms"] for r in recs)
         ach = fl3 / (ms3 * 1e-3) / 1e12 if ms3 > 0 else 0.0
         PEAK = PEAK_FP16_MFMA_TFLOPS if a.dtype == "f16" else PEAK_BY_IMPL[a.impl]
+        # h2: MFMA products per multiply actually ISSUED — 3, or 2 on convs whose packed weights have an all-zero correction plane
+        # (PA_CONV_W_SINGLE: fp16 checkpoint weights, BatchNorm's scale in the output scale).  FLOP-weighted over the graphs;
+        # the fp32-equivalent peak of the f16 pipe is 2500 / that, so that `frac` stays what it was: matrix-pipe utilisation
+        prod = {3: 3.0, 1: 3.0}
+        if a.dtype == "f32" and a.impl == "h2":
+            from padel_analytics_amd import graph as G_
+            for ks in (3, 1):
+                num = den = 0.0
+                for name in names:
+                    g_ = trackers[name].model._model.graph
+                    for o_ in g_.ops:
+                        if o_["kind"] == G_.OP_CONV and o_["ksize"] == ks:
+                            w_ = float(o_["cout"]) * o_["cin"] * ks * ks / 4.0 ** g_.bufs[o_["out_buf"]][0] * flops_per_frame[name] / max(g_.conv_flops(64, 64), 1.0)
+                            num += w_ * (2.0 if (o_.get("flags", 0) & 1) else 3.0)
+                            den += w_
+                prod[ks] = num / den if den else 3.0
+            PEAK = round(PEAK_FP16_MFMA_TFLOPS / prod[3], 1)
+        PEAK1 = round(PEAK_FP16_MFMA_TFLOPS / prod[1], 1) if (a.dtype == "f32" and a.impl == "h2") else PEAK
         traffic = None
         # PMC FETCH_SIZE / WRITE_SIZE passes over this script's own engine-only step (measure_traffic); when rocprofv3 is not
         # available (or --traffic static) the committed measurement of the same command line, marked "static"
@@ -735,29 +756,34 @@ def main():
                        if a.dtype == "f16" else
                        "conv_h2p_kernel<NF> / conv_h2q_kernel<3> / conv_h2w_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16- or 16x16-pixel patch of fp16-pair activations "
                        "staged once per 32-channel chunk as h / m planes in LDS, 9 shifted-window taps; 48 or 96 channels per "
-                       "workgroup) + conv_h2_kernel<...> (stride-2 3x3: LDS-DMA ring); 3 x v_mfma_f32_16x16x32_f16 per 16x16x32 "
-                       "block, output encoded to pairs in the epilogue"
+                       "workgroup) + conv_h2_kernel<...> (stride-2 3x3: LDS-DMA ring); 3 — or, on fp16-number weights, 2 — x "
+                       "v_mfma_f32_16x16x32_f16 per 16x16x32 block, output encoded to pairs in the epilogue"
                        if a.impl == "h2" else
                        "conv_bx3p_kernel<NF> (stride-1 3x3 conv+BN+SiLU: 8x16-pixel patch split once per 32-channel chunk into "
                        "bf16 hi/mid/lo planes in LDS, 9 shifted-window taps) + conv_bx3_kernel<...> (stride-2 3x3: LDS-DMA ring, "
                        "split in registers); exact bf16x3, 6 x v_mfma_f32_16x16x32_bf16 per 16x16x32 block" if a.impl == "bx3" else
                        "conv_tap_kernel<WM,WN,MF,NF> (3x3 conv+BN+SiLU implicit GEMM: LDS-DMA ring, v_mfma_f32_16x16x4_f32)"),
-            "peak_note": ("fp32-equivalent TFLOP/s: f16 MFMA dense peak 2500 / 3 products per multiply (round 2's bf16x3 kernels: "
-                          "/ 6 = 416.7; fp32-input MFMA: 157.3); matrix-pipe utilisation = frac" if (a.dtype == "f32" and a.impl == "h2") else
+            "peak_note": ("fp32-equivalent TFLOP/s: f16 MFMA dense peak 2500 / MFMA products issued per multiply (`products_per_multiply`: 3, "
+                          "or 2 where the checkpoint's conv weights are fp16 numbers and BatchNorm's scale stays out of them — "
+                          "PA_CONV_W_SINGLE; rounds 3-4 and the first half of round 5 ran 3 everywhere: peak 833.3, see "
+                          "`frac_of_three_product_peak`; bf16x3: / 6 = 416.7; fp32-input MFMA: 157.3); frac = matrix-pipe utilisation"
+                          if (a.dtype == "f32" and a.impl == "h2") else
                           "fp32-equivalent TFLOP/s: bf16 MFMA dense peak 2500 / 6 products per multiply; the fp32-input MFMA "
                           "peak this replaces is 157.3" if (a.dtype == "f32" and a.impl == "bx3") else None),
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK, "unit": "TFLOP/s",
             "frac": round(ach / PEAK, 4), "traffic": traffic if a.dtype == "f32" else None,
+            "products_per_multiply": ({"conv3x3": round(prod[3], 3), "conv1x1": round(prod[1], 3)} if (a.dtype == "f32" and a.impl == "h2") else None),
+            "frac_of_three_product_peak": (round(ach / PEAK_H2_TFLOPS, 4) if (a.dtype == "f32" and a.impl == "h2") else None),
             # what a kernel of nothing but v_mfma_f32_16x16x32_f16 (or 32x32x16) sustains on this chip with random operands (clock
             # under matrix load; 2.2-2.5 PFLOP/s with all-zero operands, 2.5 nominal): tools/mfma_f16_ubench.hip, a static figure
-            "sustained_mfma_peak": ({"value": round(SUSTAINED_FP16_MFMA_TFLOPS / (3.0 if a.dtype == "f32" else 1.0), 1), "unit": "TFLOP/s",
-                                     "frac": round(ach / (SUSTAINED_FP16_MFMA_TFLOPS / (3.0 if a.dtype == "f32" else 1.0)), 4), "static": True,
+            "sustained_mfma_peak": ({"value": round(SUSTAINED_FP16_MFMA_TFLOPS / (prod[3] if a.dtype == "f32" else 1.0), 1), "unit": "TFLOP/s",
+                                     "frac": round(ach / (SUSTAINED_FP16_MFMA_TFLOPS / (prod[3] if a.dtype == "f32" else 1.0)), 4), "static": True,
                                      "source": "profiles/r4a_mfma_f16_ubench.txt: 1.71-1.85 PFLOP/s on random operands at 2-3 waves per SIMD, v_mfma_f32_16x16x32_f16 and 32x32x16 alike"}
                                     if (a.dtype == "f16" or a.impl == "h2") else None),
             "launches": len(c3), "avg_launch_ms": round(ms3 / max(len(c3), 1), 4),
             "flops_per_step": fl3, "kernel_ms_per_step": round(ms3, 3),
             "conv1x1": {"achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2) if ms1 > 0 else 0.0, "ms_per_step": round(ms1, 3),
-                        "frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK, 4) if ms1 > 0 else 0.0},
+                        "peak": PEAK1, "frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK1, 4) if ms1 > 0 else 0.0},
             "all_kernels_ms_per_step": round(ms_all, 3),
             "other_ms_per_step": {str(k): round(sum(r["ms"] for r in recs if r["kind"] == k), 3)
                                   for k in sorted({r["kind"] for r in recs}) if k != 2},

@@ -69,7 +69,9 @@ constexpr int kQDbgWords = 8 + 4 * kQDbgSteps * 5;
 // WS (round 5): the packed weights' m plane is all zero (ConvArgs::w_single — fp16 checkpoint weights, BatchNorm's scale in the
 // output scale): the wm x ah product, the m-plane weight requests and the wm operand reads are compiled out — 24 MFMAs, 2 weight
 // requests and 3 + 4 operand reads per tap and wave instead of 36 / 4 / 6 + 4.  Same results as the three-product kernel on such
-// weights (the skipped product is exactly zero).
+// weights (the skipped product is exactly zero).  192 -> 192: 408 -> 532 TFLOP/s fp32-equivalent, 96 -> 96: 350 -> 424.
+// (Tried on top, gpurun r5r: the freed m-plane stages as a THIRD h-only weight stage, weights requested two steps ahead with a
+//  counted vmcnt(2) — bitwise, but 320 / 271 TFLOP/s: slower than the two-stage ring by 40 %; reverted.)
 template <int NF, bool DBG = false, bool WS = false>
 __global__ void __launch_bounds__(256, 2) conv_h2q_kernel(const ConvArgs a) {
     constexpr int MF = 4;

@@ -51,6 +51,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--w16", action="store_true", help="h2: weights that are fp16 numbers (the two-product kernels: PA_CONV_W_SINGLE)")
     ap.add_argument("--act", type=int, default=1, help="0 none, 1 SiLU, 2 ReLU (epilogue cost probe)")
     ap.add_argument("--tiles", default="auto,T6,T7,T9,T10,T11,T13,T14,T15,T20")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f16", "h2"], help="f16: conv_tap16 kernels (tiles Tn = fp16 tile ids 6,7,9,11,12,20,30,31,32); h2: fp16-pair kernels (tiles Tn = 207,209,211,213,220,225,239,243,303,304,313,323,341-343)")
@@ -70,6 +71,8 @@ def main():
         b0 = g.buf(0, cin_p)
         b1 = g.buf(1 if s == 2 else 0, g.padk(cout))
         w = rng.normal(0, (2.0 / (cin * k * k)) ** 0.5, (cout, cin, k, k)).astype(np.float32)
+        if a.w16:
+            w = w.astype(np.float16).astype(np.float32)
         g.conv((b0, 0, cin_p), (b1, 0), w, np.zeros(cout, np.float32), k, s, a.act, out_width=g.padk(cout) if (f16 or h2) else None)
         if f16 or h2:                     # the measured conv writes fp16; a tiny fp32 head keeps pa_tracknet_infer's contract
             hd = g.buf(1 if s == 2 else 0, 16)
