@@ -1,10 +1,11 @@
 #!/bin/bash
 # matrix-pipe utilisation, wait breakdown, LDS and L2 behaviour of the h2 conv kernels (default arithmetic since round 3):
-# three --pmc passes, kernel-trace only, over tools/conv_bench.py --dtype h2 (tile "auto" = the per-layer default)
+# three --pmc passes, kernel-trace only, over tools/conv_bench.py --dtype h2 (tile "auto" = the per-layer default); W16=1: weights that
+# are fp16 numbers, i.e. the two-product kernels (PA_CONV_W_SINGLE)
 mkdir -p gpurun_out; R=${GRAFT_REPO_ROOT:-$(pwd)}; export TMPDIR=/tmp
 SHAPES=${1:-"m.P4.bneck,m.P3.bneck,m.P2.bneck,pose.P2.bneck,m.L3 96,m.c2f.cv2 1x1 576,m.c2f.cv1 1x1 96->96 P2,m.c2f.cv2 1x1 1152"}
 cd /tmp
-run() { n=$1; shift; rm -rf $R/gpurun_out/pmch$n; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmch$n -o p -- python $R/tools/conv_bench.py --dtype h2 --tiles auto --reps 2 --shapes "$SHAPES" > $R/gpurun_out/pmch$n.log 2>&1; echo "pass $n rc=$?"; }
+run() { n=$1; shift; rm -rf $R/gpurun_out/pmch$n; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $R/gpurun_out/pmch$n -o p -- python $R/tools/conv_bench.py --dtype h2 ${W16:+--w16} --tiles auto --reps 2 --shapes "$SHAPES" > $R/gpurun_out/pmch$n.log 2>&1; echo "pass $n rc=$?"; }
 run 1 SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU
 run 2 GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
 run 3 GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM TCC_HIT_sum TCC_MISS_sum
