@@ -13,6 +13,12 @@
 // scaled by a per-output-channel power of two on the host (graph.py:pack_conv_weight_h2) so that both planes sit in
 // the normal fp16 range whatever the magnitude of the BN-folded weights; the epilogue multiplies by 1 / scale.
 //
+// Round 5 — TWO products where the weights allow it: a checkpoint's conv weights are fp16 numbers (Ultralytics stores
+// model.half()); when the host keeps BatchNorm's scale out of them (graph.py: Graph.conv(out_scale=), the scale is folded into
+// `oscale` instead) their packed m plane is exactly zero, the op is flagged PA_CONV_W_SINGLE and the kernels' WS instantiations
+// drop the wm * ah product with its requests and reads:  a * w = ah*wh + am*wh / 2048.  Bitwise the three-product kernels on the
+// same blob; DESIGN.md 3.5.
+//
 // Layout in HBM (4 bytes per channel, like fp32): per pixel and 16-channel GROUP 64 bytes = [h of channels 0..15 |
 // m of channels 0..15].  The PRODUCER encodes once in its epilogue; consumers fetch ready-made MFMA operands
 // (LDS-DMA straight into the operand planes, no VALU in the K loop).
