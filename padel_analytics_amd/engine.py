@@ -7,6 +7,7 @@ path must fail loudly rather than silently route through a CPU restatement).
 from __future__ import annotations
 
 import ctypes as C
+import sys as _sys
 import os
 from pathlib import Path
 from typing import Optional, Sequence
@@ -336,9 +337,9 @@ class _PinnedBlock:
                 self.engine.unpin(self.block)
             except Exception as exc:
                 # the pages stay registered and their memory is about to be freed: say so (a later copy from memory that
-                # lands on these addresses fails inside the runtime)
-                import sys
-                print(f"padel_analytics_amd: hipHostUnregister of a result block failed ({exc}); pages left registered", file=sys.stderr)
+                # lands on these addresses fails inside the runtime) — except at interpreter shutdown, when the engine is gone
+                if _sys is not None and getattr(_sys, "meta_path", None) is not None and getattr(self.engine, "handle", None):
+                    print(f"padel_analytics_amd: hipHostUnregister of a result block failed ({exc}); pages left registered", file=_sys.stderr)
 
     def __del__(self):
         self.release()

@@ -104,3 +104,44 @@ def test_recycled_output_arrays_hold_the_same_results(gpu_engine):
     assert held[E.Model.OUT_RING][0][0] is held[0][0][0]                          # the first set came round again
     assert int(sum(f[2].sum() for f in fresh)) > 0
     m.close()
+
+
+def test_sharded_runner_on_the_real_engine_equals_the_sequential_run(gpu_engine, tmp_path):
+    """``TrackingRunner(distributed=True)`` — the path ``bench.py --gpus N`` times since round 5 — on the real engine with a
+    world of one (no process group: every collective degenerates, everything else is the real thing): ``predict_partial``
+    through the two-call device stage over HBM-resident frames, the partials packed to arrays and unpacked again
+    (``Tracker.pack_partials``), ByteTrack / containers in ``merge_partials`` — must serialise to exactly what the
+    reference-order run produces, for the players, pose and ball-detector trackers, with eager objects on."""
+    from padel_analytics_amd import trackers as T
+    from padel_analytics_amd.trackers import BallDetectTracker
+    from padel_analytics_amd import yolo_arch
+    frames = synth.synthetic_frames(13, 360, 640, seed=15)
+    clip = video.DeviceClip(gpu_engine, frames)                              # 13 frames, batch 5: a short last batch
+    checkpoint.save_checkpoint(tmp_path / "players.pt", yolo_arch.synth_state_dict("n", 80, None, seed=3, cls_bias=0.5), "detect", 80, None, "n", {0: "person"})
+    checkpoint.save_checkpoint(tmp_path / "pose.pt", yolo_arch.synth_state_dict("n", 1, (13, 3), seed=4, cls_bias=0.5), "pose", 1, (13, 3), "n", {0: "person"})
+    checkpoint.save_checkpoint(tmp_path / "ball.pt", yolo_arch.synth_state_dict("n", 1, None, seed=5, cls_bias=0.5), "detect", 1, None, "n", {0: "ball"})
+    zone = D.PolygonZone(np.array([[40, 40], [600, 40], [600, 340], [40, 340]]), frame_resolution_wh=(640, 360))
+
+    def run(**kw):
+        players = PlayerTracker(str(tmp_path / "players.pt"), zone, batch_size=5)
+        pose = PlayerKeypointsTracker(str(tmp_path / "pose.pt"), 640, batch_size=5)
+        ball = BallDetectTracker(str(tmp_path / "ball.pt"), batch_size=5)
+        r = TrackingRunner([players, pose, ball], clip, tmp_path / "out.mp4", **kw)
+        r.run()
+        out = {str(t): [o.serialize() for o in t.results] for t in (players, pose, ball)}
+        for t in (players, pose, ball):
+            t.model.close()
+        return out
+
+    T.set_eager_objects(True)
+    try:
+        want = run()
+        got = run(distributed=True)
+    finally:
+        T.set_eager_objects(False)
+        clip.free()
+    assert set(got) == set(want)
+    for k in want:
+        assert len(want[k]) == 13
+        assert json.dumps(got[k]) == json.dumps(want[k]), k
+    assert sum(len(f) for f in want["players_tracker"]) > 0 and sum(len(f) for f in want["players_keypoints_tracker"]) > 0
