@@ -23,6 +23,7 @@ Written from scratch; host logic only (the numeric engines live behind ``padel_a
 from __future__ import annotations
 
 import sys
+import threading
 
 import json
 from abc import ABC, abstractmethod
@@ -109,16 +110,28 @@ class relaxed_gc:
     young-generation threshold is raised (never lowered); the previous thresholds come back on exit."""
 
     YOUNG = 100_000
+    _lock = threading.Lock()
+    _depth = 0                      # contexts alive in the process (any thread): the first one in raises, the last one out restores
+    _saved = None
 
     def __enter__(self):
         import gc
-        self._old = gc.get_threshold()
-        gc.set_threshold(max(self._old[0], self.YOUNG), *self._old[1:])
+        cls = relaxed_gc
+        with cls._lock:
+            if cls._depth == 0:
+                cls._saved = gc.get_threshold()
+                gc.set_threshold(max(cls._saved[0], cls.YOUNG), *cls._saved[1:])
+            cls._depth += 1
         return self
 
     def __exit__(self, *exc):
         import gc
-        gc.set_threshold(*self._old)
+        cls = relaxed_gc
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._saved is not None:
+                gc.set_threshold(*cls._saved)
+                cls._saved = None
         return False
 
 

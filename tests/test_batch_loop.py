@@ -162,3 +162,28 @@ def test_drain_releases_the_ticket_without_a_fresh_inference():
     t3.model._model.handle = None                              # ... or closed it
     it.close()
     assert t3.model._model.waited == []
+
+
+def test_relaxed_gc_is_reentrant_across_threads_and_restores_the_thresholds():
+    """The sharded runner's merge thread and a batch loop on the main thread may both be inside ``relaxed_gc``: the first one in
+    raises the young-generation threshold, the LAST one out restores what the first one found."""
+    import gc
+    import threading
+    from padel_analytics_amd.trackers.tracker import relaxed_gc
+    before = gc.get_threshold()
+    inside, leave = threading.Event(), threading.Event()
+
+    def worker():
+        with relaxed_gc():
+            inside.set()
+            leave.wait(10)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    inside.wait(10)
+    with relaxed_gc():
+        assert gc.get_threshold()[0] >= relaxed_gc.YOUNG
+    assert gc.get_threshold()[0] >= relaxed_gc.YOUNG          # the worker is still inside: not restored yet
+    leave.set()
+    t.join()
+    assert gc.get_threshold() == before
