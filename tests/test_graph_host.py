@@ -245,6 +245,20 @@ def test_unfolded_batchnorm_keeps_fp16_checkpoint_weights_single_plane():
     sd2["model.3.conv.weight"] = w2
     ops2 = [o2 for o2 in G.build_yolov8(sd2, 80, None, dtype="h2").ops if o2["kind"] == G.OP_CONV]
     assert sum(1 for o2 in ops2 if not (o2["flags"] & G.FLAG_W_SINGLE)) == 1
+    # a head branch off the fp16 grid: the first head convs of that level share one rule — merged (one conv) or split per branch
+    # (two convs on a detect head), they are all folded
+    sd3 = dict(sd)
+    w3 = np.asarray(sd["model.22.cv3.0.0.conv.weight"], np.float32).copy()
+    w3.flat[5] = np.float32(w3.flat[5]) * np.float32(1.0 + 2.0 ** -20)
+    sd3["model.22.cv3.0.0.conv.weight"] = w3
+    hs = G.HEAD_SPLIT
+    try:
+        for split, n_folded in ((False, 1), (True, 2)):
+            G.HEAD_SPLIT = split
+            ops3 = [o3 for o3 in G.build_yolov8(sd3, 80, None, dtype="h2").ops if o3["kind"] == G.OP_CONV]
+            assert sum(1 for o3 in ops3 if not (o3["flags"] & G.FLAG_W_SINGLE)) == n_folded, (split, [o3["flags"] for o3 in ops3])
+    finally:
+        G.HEAD_SPLIT = hs
     old = G.UNFOLDED_BN
     try:
         G.UNFOLDED_BN = False
