@@ -11,16 +11,23 @@ BUILD="${PADEL_BUILD_DIR:-build}"
 OUT="${PADEL_OUT:-../libpadel_hip.so}"
 mkdir -p "$BUILD"
 pids=()
-for f in conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_tap_h2.hip conv_tap_h2p.hip conv_patch_h2.hip conv_patch_h2q.hip conv_patch_h2w.hip conv_patch16.hip kernels_misc.hip stem_l1_h2.hip postproc.hip tracknet_post.hip; do
+# PADEL_ONLY="a.hip b.hip": recompile only these translation units and relink with the objects already in $BUILD (iteration)
+ALL="conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_tap_h2.hip conv_tap_h2p.hip conv_patch_h2.hip conv_patch_h2q.hip conv_patch_h2r.hip conv_patch_h2w.hip conv_patch16.hip kernels_misc.hip stem_l1_h2.hip postproc.hip tracknet_post.hip"
+for f in ${PADEL_ONLY:-$ALL}; do
   [ -f "$f" ] || continue
+  [ "$f" = engine.cpp ] && continue
   hipcc $FLAGS -c "$f" -o "$BUILD/${f%.hip}.o" &
   pids+=($!)
 done
+if [ -z "${PADEL_ONLY:-}" ] || [[ " $PADEL_ONLY " == *" engine.cpp "* ]]; then
 hipcc $FLAGS -x hip -c engine.cpp -o "$BUILD/engine.o" &
 pids+=($!)
+fi
 # host code; -ffp-contract=off: the tracker's doubles are pinned against the Python twin (no fused multiply-adds)
+if [ -z "${PADEL_ONLY:-}" ]; then
 g++ -O3 -ffp-contract=off -std=c++17 -fPIC -Wall -c bytetrack.cpp -o "$BUILD/bytetrack.o" &
 pids+=($!)
+fi
 for p in "${pids[@]}"; do wait "$p"; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$BUILD"/*.o -Wl,-rpath,/opt/rocm/lib
 echo "built $OUT"

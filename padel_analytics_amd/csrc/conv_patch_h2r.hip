@@ -1,0 +1,294 @@
+// K3r "h2 register-weights quad patch" (round 6) — the stride-1 3x3 convolution of h2 graphs whose weights are fp16 numbers
+// (PA_CONV_W_SINGLE: two products per operand pair), for layers with whole 32-channel chunks and a multiple of 96 output
+// channels: the tile of conv_patch_h2q.hip (8 x 16 pixels x 96 channels per workgroup, a wave 4 rows x 16 pixels x 48
+// channels) with a main loop built for the two-product regime.
+//
+// Why: with two products a tap is 24 MFMAs = 384 matrix-pipe cycles per wave; conv_patch_h2q.hip wraps every tap in a serial
+// chain of ~775 cycles (vmcnt(0) on the weight stage, one s_barrier, 3 + 4 dependent ds_read_b128) that only the OTHER
+// workgroup's wave on the SIMD can cover: MfmaUtil 0.40-0.48 (profiles/r5t_conv_h2_pmc.txt).  The chain exists because the
+// weights travel through a workgroup-shared LDS ring.  Here
+//   * the WEIGHTS never touch LDS: a wave fetches the three 16 x 32 operand fragments of its 48 channels straight into
+//     registers, TWO taps ahead, through three rotating register sets; waits are counted (vmcnt(6) keeps the two younger taps
+//     in flight).  They come from a second copy of the h plane in MFMA operand order — [fragment][k-step][lane][16 bytes]:
+//     1 KB = 8 whole cache lines per buffer_load_dwordx4 (h2r_repack_kernel, run once per model by the engine).  Reading the
+//     row-major blob directly ([row][k-step][h | m]: 16 half-used lines per load) was measured first: 350 / 406 TFLOP/s on
+//     96 -> 96 / 192 -> 192 against 441 / 517 for conv_patch_h2q.hip — 48 KB of lines per tap and CU is the whole L2 -> L1
+//     fill rate (64 B/clk).  The two waves of a channel half read the same 3 KB per tap;
+//   * there is NO per-tap barrier and no per-tap wait on anything another wave did: one s_barrier per 32-channel CHUNK (9 taps,
+//     216 MFMAs = 3 456 pipe cycles per wave) hands over the double-buffered input patch;
+//   * the input rows are prefetched: the six rows of a kernel column slide through four register slots as before, but every
+//     read is issued as soon as its slot's last products have been issued — row 4 under tap ky = 0, row 5 under ky = 1, and
+//     the next column's rows 0..3 under ky = 2, whose row order (2, 3, 0, 1) frees the slots in the order the new rows need
+//     them — at least 12 MFMAs (192 cycles) before their first use; no read is exposed in the steady state;
+//   * the patch of chunk c + 2 is requested by ALL FOUR waves (three 16-pixel spans of both planes each) right behind the
+//     chunk barrier in tap 8 of chunk c, into the buffer that barrier just freed: a whole chunk to land.  vmcnt is in order
+//     per wave, so the weights issued behind those six requests retire after them: the requests sit where two taps of
+//     weights are already in flight in front of them.
+// Same products in the same order per accumulator as every other h2 kernel (cross: wh am; main: wh ah, flushed into acc once
+// per chunk; the rows of a tap touch different accumulators, so their order is free): bitwise identical results.
+//
+// LDS: 2 patch buffers x 2 planes x 192 pixels x 64 B = 49 152 B; registers bound the occupancy (2 workgroups per CU).
+#include "h2_common.h"
+
+namespace padel {
+
+namespace {
+
+constexpr int kRPW = 18;                        // patch width in pixels (16 + halo)
+constexpr int kRNPix = 180;                     // 10 x 18
+constexpr int kRPlaneB = 192 * 64;              // one fp16 plane of a 32-channel chunk, padded to 12 spans of 16 pixels
+constexpr int kRPatchB = 2 * kRPlaneB;
+
+// byte offset, inside a plane, of logical 16-byte chunk q (K slots 8q..8q+7) of patch pixel p (conv_patch_h2.hip:hp_off)
+__device__ __forceinline__ unsigned hr_off(int p, int q) { return (unsigned)(p * 64 + ((q ^ (((p >> 2) & 1) << 1)) << 4)); }
+
+typedef int hr_i32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace
+
+template <int NF, int NBUF>
+__global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
+    constexpr int MF = 4;
+    static_assert(NF == 3, "a wave owns 3 channel fragments; 12 patch spans = 3 per wave");
+    static_assert(NBUF == 2, "double-buffered patch");
+    __shared__ __attribute__((aligned(16))) float lds[(NBUF * kRPatchB) / 4];
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;      // pixel half (rows 4 wr ..), channel half (fragments 3 wc ..)
+    const int lr = lane & 15, lq = lane >> 4;
+
+    // XCD-aware 1-D tile map: the channel tiles of one pixel patch are neighbours on one XCD (conv_patch_h2q.hip)
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;
+    const int bid = blockIdx.x;
+    const int q8 = nmt >> 3, r8 = nmt & 7, xcd = bid & 7, idx = bid >> 3;
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;
+    if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
+    const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
+    const int txN = (a.Wo + 15) >> 4, tyN = (a.Ho + 7) >> 3;
+    const int tpi = tyN * txN;
+    const int n = mt / tpi, rt = mt - n * tpi;
+    const int ty = rt / txN, tx = rt - ty * txN;
+    const int y0 = ty * 8, x0 = tx * 16;
+    const int f0 = nt * 2 * NF;
+    const int nch = a.cin >> 5;
+
+    // ---- the patch: span s of a plane = 16 pixels x 64 bytes, lane i -> pixel 16 s + i / 4, physical 16-byte slot i & 3 =
+    // logical chunk q of that pixel (hr_off), which is piece (q & 1) of group (q >> 1) of the pixel's 128 bytes [h0 m0 h1 m1]
+    // in HBM; the plane's 32 bytes go in through the scalar offset.  Wave w requests spans 3 w .. 3 w + 2 of both planes.
+    const float* const in0 = a.in + (((long long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.in_cs + a.in_choff;
+    const i32x4 rsrcP = make_rsrc3(in0);
+    const int p_lane = lane >> 2;
+    const int p_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const unsigned p_piece = (unsigned)((p_q >> 1) * 64 + (p_q & 1) * 16);
+    const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+    const unsigned lpw = __builtin_amdgcn_readfirstlane(lp0 + (unsigned)wave * 3072u);
+    // the lane offsets of the wave's three spans do not depend on the chunk (it enters through the scalar offset): hoisted, 3 VGPRs
+    unsigned voP[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int pp = (3 * wave + k) * 16 + p_lane;
+        const int py = pp / kRPW, px = pp - py * kRPW;
+        const bool ok = pp < kRNPix && (unsigned)(y0 - 1 + py) < (unsigned)a.H && (unsigned)(x0 - 1 + px) < (unsigned)a.W;
+        voP[k] = ok ? (unsigned)((py * a.W + px) * a.in_cs * 4) + p_piece : kOOR3;
+    }
+    // the wave's six requests of chunk CH_ into buffer BUF_.  Chunks beyond the last go through a descriptor of zero records (every
+    // lane out of range: zeros into a free buffer), so that the request count per tap — and with it every counted wait — is static
+#define PADEL_HR_PATCH(CH_, BUF_)                                                                                 \
+    do {                                                                                                          \
+        const unsigned so_ = (unsigned)(CH_) * 128u;                                                              \
+        const unsigned lb_ = lpw + (unsigned)(BUF_) * (unsigned)kRPatchB;                                         \
+        i32x4 rs_ = rsrcP;                                                                                        \
+        rs_[2] = (CH_) < nch ? (int)0x80000000u : 0;                                                              \
+        dma3<0>(voP[0], rs_, so_, lb_); dma3<kRPlaneB>(voP[0], rs_, so_ + 32u, lb_);                              \
+        dma3<1024>(voP[1], rs_, so_, lb_); dma3<kRPlaneB + 1024>(voP[1], rs_, so_ + 32u, lb_);                    \
+        dma3<2048>(voP[2], rs_, so_, lb_); dma3<kRPlaneB + 2048>(voP[2], rs_, so_ + 32u, lb_);                    \
+    } while (0)
+
+    // ---- weights: a.wr = [fragment][k-step][lane][16 bytes] (h plane only): lane l of fragment j reads bytes [16 l, 16 l + 16)
+    // of the k-step's 1 KB — its MFMA A operand (row l & 15 at k = 8 (l >> 4)).  One descriptor per fragment, one lane offset
+    const unsigned fragb = (unsigned)(nch * 9) * 1024u;
+    const unsigned voffW = (unsigned)lane * 16u;
+    i32x4 rsrcW[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int frag = min(f0 + NF * wc + j, a.n16 - 1);  // fragments beyond the matrix: any valid rows (never stored)
+        rsrcW[j] = make_rsrc3(reinterpret_cast<const char*>(a.wr) + (long long)frag * fragb);
+    }
+    hr_i32x4 w[3][NF];
+    unsigned s_kb = 0;                            // byte offset of the current chunk's first k-step inside a fragment
+    // tap TT_ (0..10, relative to the current chunk: 9 and 10 are the next chunk's first two) into register set SET_; the reads of
+    // the last chunk's 9 / 10 run up to 2 KB past a fragment (into the next fragment, or the slack behind the copy)
+#define PADEL_HR_LOADW(SET_, TT_)                                                                                 \
+    do {                                                                                                          \
+        const unsigned so_ = s_kb + (unsigned)((TT_) * 1024);                                                     \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"                                               \
+                         : "=v"(w[SET_][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory");                    \
+    } while (0)
+    // the counted wait that publishes set SET_ to the compiler: the registers pass through it
+#define PADEL_HR_WAITW(SET_, N_)                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(N_) : "memory")
+
+    const int rd_pix = 4 * wr * kRPW + lr;        // patch pixel of the wave's row 0, kx = 0
+
+    f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
+    h16x8 ah[4], am[4];                           // input rows in 4 sliding slots (row r of the current kx in slot r & 3)
+    // input row R_ (0..5 of the wave's window) at column shift KX_ of patch buffer PB_ into slot R_ & 3
+#define PADEL_HR_READROW(PB_, R_, KX_)                                                                            \
+    do {                                                                                                          \
+        int rp_ = rd_pix;                                                                                         \
+        asm volatile("" : "+v"(rp_));                      /* addresses recomputed per read (3 VALU): 18 hoisted ones would spill */ \
+        const char* p_ = (PB_) + hr_off(rp_ + (R_) * kRPW + (KX_), lq);                                           \
+        ah[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_);                                                       \
+        am[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_ + kRPlaneB);                                            \
+    } while (0)
+    // the 6 products of output row F_ at tap row KY_ (its input row F_ + KY_ sits in slot (F_ + KY_) & 3) with weight set SET_
+#define PADEL_HR_MFMA_ROW(F_, KY_, SET_)                                                                          \
+    do {                                                                                                          \
+        constexpr int s_ = ((F_) + (KY_)) & 3;                                                                    \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), am[s_], cross[F_][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), ah[s_], part[F_][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    // tap step T_ = 3 kx + ky of the current chunk (weight set T_ % 3 — 9 % 3 == 0, so a tap uses the same set in every chunk).
+    // Queue of the wave behind W(T_) when it waits: [P, issued in tap 8] W(T_ + 1) [P] W(T_ + 2): 6 requests, 12 in taps 0 / 1.
+#define PADEL_HR_STEP(T_)                                                                                         \
+    do {                                                                                                          \
+        constexpr int kx_ = h2_tap_kx(T_), ky_ = h2_tap_ky(T_), set_ = (T_) % 3;                                  \
+        PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                                                                 \
+        PADEL_HR_WAITW(set_, (T_) < 2 ? 12 : 6);                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if constexpr (ky_ == 0) {                                                                                 \
+            PADEL_HR_MFMA_ROW(0, 0, set_);                                                                        \
+            PADEL_HR_READROW(pcur, 4, kx_);                /* slot 0, first used by row 3 of ky = 1 */            \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(1, 0, set_); PADEL_HR_MFMA_ROW(2, 0, set_); PADEL_HR_MFMA_ROW(3, 0, set_);          \
+        } else if constexpr (ky_ == 1) {                                                                          \
+            PADEL_HR_MFMA_ROW(0, 1, set_);                                                                        \
+            PADEL_HR_READROW(pcur, 5, kx_);                /* slot 1, first used by row 3 of ky = 2 */            \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(1, 1, set_); PADEL_HR_MFMA_ROW(2, 1, set_); PADEL_HR_MFMA_ROW(3, 1, set_);          \
+        } else if constexpr (kx_ < 2) {                    /* ky = 2: rows 2, 3, 0, 1 free slots 0, 1, 2, 3 for the next column */ \
+            PADEL_HR_MFMA_ROW(2, 2, set_);                                                                        \
+            PADEL_HR_READROW(pcur, 0, kx_ + 1);                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(3, 2, set_);                                                                        \
+            PADEL_HR_READROW(pcur, 1, kx_ + 1);                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(0, 2, set_);                                                                        \
+            PADEL_HR_READROW(pcur, 2, kx_ + 1);                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(1, 2, set_);                                                                        \
+            PADEL_HR_READROW(pcur, 3, kx_ + 1);                                                                   \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        } else {                                           /* tap 8: the chunk barrier sits behind the first row's products */ \
+            PADEL_HR_MFMA_ROW(2, 2, set_);                                                                        \
+            /* every read of this chunk's patch has returned (row 5 was read under tap 7; lgkmcnt(0) costs nothing here), */ \
+            /* and the wave's own requests of the next chunk's patch landed long ago (in order in front of W(8)) */ \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+            __builtin_amdgcn_s_barrier();                                                                         \
+            asm volatile("" ::: "memory");                                                                        \
+            PADEL_HR_READROW(pnxt, 0, 0);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(3, 2, set_);                                                                        \
+            PADEL_HR_READROW(pnxt, 1, 0);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_PATCH(c + 2, c & 1);                  /* into the buffer this chunk read */                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(0, 2, set_);                                                                        \
+            PADEL_HR_READROW(pnxt, 2, 0);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+            PADEL_HR_MFMA_ROW(1, 2, set_);                                                                        \
+            PADEL_HR_READROW(pnxt, 3, 0);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+    } while (0)
+
+    // prologue: P(0), W(0), W(1), P(1) — the order the steady state leaves behind tap 8
+    PADEL_HR_PATCH(0, 0);
+    PADEL_HR_LOADW(0, 0);
+    PADEL_HR_LOADW(1, 1);
+    PADEL_HR_PATCH(1, 1);
+    wait_vm3<12>();                               // P(0) landed (W(0), W(1), P(1) may be in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    PADEL_HR_READROW(ldsb, 0, 0); PADEL_HR_READROW(ldsb, 1, 0); PADEL_HR_READROW(ldsb, 2, 0); PADEL_HR_READROW(ldsb, 3, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        const char* const pcur = ldsb + (c & 1) * kRPatchB;
+        const char* const pnxt = ldsb + ((c + 1) & 1) * kRPatchB;
+        PADEL_HR_STEP(0); PADEL_HR_STEP(1); PADEL_HR_STEP(2); PADEL_HR_STEP(3); PADEL_HR_STEP(4);
+        PADEL_HR_STEP(5); PADEL_HR_STEP(6); PADEL_HR_STEP(7); PADEL_HR_STEP(8);
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        s_kb += 9u * 1024u;
+    }
+    wait_vm3<0>();                                // the tail's requests (zeros into a free buffer, weights nobody uses) before the LDS is released
+#undef PADEL_HR_STEP
+#undef PADEL_HR_MFMA_ROW
+#undef PADEL_HR_READROW
+#undef PADEL_HR_WAITW
+#undef PADEL_HR_LOADW
+#undef PADEL_HR_PATCH
+
+    int mpix[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int oy = y0 + 4 * wr + f, ox = x0 + lr;
+        mpix[f] = (oy < a.Ho && ox < a.Wo) ? (n * a.Ho + oy) * a.Wo + ox : -1;
+    }
+    const int fw = f0 + NF * wc;
+    const bool fast = y0 + 8 <= a.Ho && x0 + 16 <= a.Wo && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
+                      (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
+    if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
+}
+
+// one thread per 16 bytes of the copy: [fragment f][k-step t][lane l] <- bytes [16 (l >> 4), +16) of the h half of k-step t of row
+// 16 f + (l & 15) of the packed blob ([row][k-step][h x 32 | m x 32] fp16)
+__global__ void __launch_bounds__(256) h2r_repack_kernel(const char* __restrict__ w, char* __restrict__ wr, int n16, int ksteps) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)n16 * ksteps * 64) return;
+    const int l = (int)(i & 63);
+    const long long ft = i >> 6;
+    const int t = (int)(ft % ksteps), f = (int)(ft / ksteps);
+    const h2_u32x4 v = *reinterpret_cast<const h2_u32x4*>(w + ((long long)(f * 16 + (l & 15)) * ksteps + t) * 128 + (l >> 4) * 16);
+    *reinterpret_cast<h2_u32x4*>(wr + i * 16) = v;
+}
+
+size_t conv_h2r_copy_bytes(int n16, int cin) { return (size_t)n16 * (size_t)((cin >> 5) * 9) * 1024; }
+
+hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s) {
+    const int ksteps = (cin >> 5) * 9;
+    const long long n = (long long)n16 * ksteps * 64;
+    hipLaunchKernelGGL(h2r_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const char*>(w),
+                       reinterpret_cast<char*>(wr), n16, ksteps);
+    return hipGetLastError();
+}
+
+bool conv_h2r_supported(const ConvArgs& a) {
+    return a.w_single && a.wr && a.ksize == 3 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 32 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr && !a.in2;
+}
+
+hipError_t launch_conv_h2r(const ConvArgs& a_in, hipStream_t s) {
+    if (!conv_h2r_supported(a_in)) return hipErrorNotSupported;
+    ConvArgs a = a_in;
+    const int batch = a.M / (a.Ho * a.Wo);
+    a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
+    a.n_ntiles = (a.n16 + 5) / 6;
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    hipLaunchKernelGGL((conv_h2r_kernel<3, 2>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace padel

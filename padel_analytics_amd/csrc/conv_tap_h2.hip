@@ -219,6 +219,10 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         if (conv_h2w_supported(a)) return launch_conv_h2w(a, variant - 340, s);
         variant = 303;
     }
+    if (variant == 324) {                  // the register-weights quad kernel (conv_patch_h2r.hip: two-product layers); elsewhere the quad kernel
+        if (conv_h2r_supported(a)) return launch_conv_h2r(a, s);
+        variant = 323;
+    }
     if (variant == 323) {                  // the quad patch kernel (conv_patch_h2q.hip); where it does not apply, the 48-channel patch tile
         if (conv_h2q_supported(a)) return launch_conv_h2q(a, s);
         variant = 303;
@@ -296,7 +300,7 @@ int choose_conv_h2_variant(const ConvArgs& a) {
             const long long blocks = patches * ntiles;
             const long long per_cu = (blocks + 255) / 256;
             const float sc = 1.21f * fill * (float)blocks / (256.f * (float)per_cu);
-            if (sc > best) { best = sc; bv = 323; }
+            if (sc > best) { best = sc; bv = a.w_single ? 324 : 323; }
         }
         // few input channels (16 / 32 / 48: 5-14 k-steps): the wide patch kernel keeps the whole K extent of a 16 x 16 pixel
         // tile in LDS (conv_patch_h2w.hip; measured against the 8 x 16 tiles in profiles/r3_sweep_h2w.txt)

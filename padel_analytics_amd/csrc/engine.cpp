@@ -85,6 +85,11 @@ struct pa_model {
     std::vector<int> fold_dst;             // upsample op j -> its absorbing conv (-1: none)
     float* d_w = nullptr;
     size_t n_w = 0;
+    // h2 models: the h planes of the two-product stride-1 3x3 convs once more in MFMA operand order (conv_patch_h2r.hip), built on
+    // the device from d_w before the first replay and again after a weight broadcast (ensure_operand_copies)
+    char* d_wr = nullptr;
+    std::vector<long long> wr_off;         // op -> byte offset into d_wr, -1: no copy
+    bool wr_valid = false;
     unsigned* d_ovf = nullptr;             // h2 models: sticky "a value did not fit fp16" flag (pa_model_take_overflow)
     float* d_stage = nullptr; size_t stage_cap = 0;   // h2 generic graphs: fp32 input staged here before it is encoded
     int max_batch = 64;
@@ -377,6 +382,7 @@ void pa_model_destroy(pa_model* m) {
     if (m->d_frames) hipFree(m->d_frames);
     if (m->d_classes) hipFree(m->d_classes);
     if (m->d_w) hipFree(m->d_w);
+    if (m->d_wr) hipFree(m->d_wr);
     if (m->d_ovf) hipFree(m->d_ovf);
     if (m->d_stage) hipFree(m->d_stage);
     if (m->h_pin) hipHostFree(m->h_pin);
@@ -714,6 +720,7 @@ static int conv_launch_args(const pa_model* m, size_t i, int n, ConvArgs& a) {
         a.oscale = m->d_w + o.reserved;
         a.ovf_flag = m->d_ovf;
         a.w_single = (o.flags & PA_CONV_W_SINGLE) && e->t.w_single ? 1 : 0;
+        a.wr = (m->wr_valid && i < m->wr_off.size() && m->wr_off[i] >= 0) ? (const void*)(m->d_wr + m->wr_off[i]) : nullptr;
         const int lv = e->t.variant >= 0 ? e->t.variant : choose_conv_h2_variant(a);
         if (fold_active(m, (int)i) && (o.ksize == 1 || (lv >= 300 && lv < 400 && conv_h2p_supported(a)))) {
             const pa_op_desc& u = m->ops[m->fold_src[i]];       // the first up_c channels come from the coarse map
@@ -767,7 +774,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             const bool use_tap = e->t.impl == 0 || f16;
             const bool use_bx3 = a.w3 != nullptr;
             int bm = 0, bn = 0;
-            if (h2 && lv == 323) { bm = 128; bn = 96; }
+            if (h2 && (lv == 323 || lv == 324)) { bm = 128; bn = 96; }
             else if (h2 && lv >= 341 && lv <= 343) { bm = 256; bn = (lv - 340) * 16; }      // wide patch kernel: 16 x 16 pixels                       // quad patch kernel: 8 x 16 pixels x 96 channels
             else if (h2 && (lv == 243 || lv == 239)) conv_variant_shape(lv - 230, &bm, &bn);      // deep-ring tap tiles: the shape of 213 / 209
             else if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
@@ -851,10 +858,38 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
     return 0;
 }
 
+// the operand-order weight copies of conv_patch_h2r.hip: allocated once, (re)built from the blob whenever it changed
+static int ensure_operand_copies(pa_model* m) {
+    if (m->wr_valid || m->d.dtype != PA_DTYPE_H2) return 0;
+    pa_engine* e = m->e;
+    if (m->wr_off.empty()) {
+        m->wr_off.assign(m->ops.size(), -1);
+        size_t total = 0;
+        for (size_t i = 0; i < m->ops.size(); ++i) {
+            const pa_op_desc& o = m->ops[i];
+            if (o.kind != PA_OP_CONV || !(o.flags & PA_CONV_W_SINGLE) || o.ksize != 3 || o.stride != 1 || (o.cin & 31) || o.cin < 32) continue;
+            m->wr_off[i] = (long long)total;
+            total += conv_h2r_copy_bytes(o.npad / 16, o.cin);
+        }
+        if (total) {
+            PA_HIP(e, hipMalloc((void**)&m->d_wr, total + 4096));          // the last chunk's look-ahead reads run 2 KB past a fragment
+            PA_HIP(e, hipMemsetAsync(m->d_wr + total, 0, 4096, e->stream));
+        }
+    }
+    for (size_t i = 0; i < m->ops.size(); ++i) {
+        if (m->wr_off[i] < 0) continue;
+        const pa_op_desc& o = m->ops[i];
+        PA_HIP(e, launch_h2r_repack(m->d_w + o.w_off, m->d_wr + m->wr_off[i], o.npad / 16, o.cin, e->stream));
+    }
+    m->wr_valid = true;
+    return 0;
+}
+
 // run_ops, or (tuning "graph", not while profiling) the replay of its capture for this batch size: the op list of
 // an n-scale graph is ~100 launches of 10-40 us each, where per-launch host work shows
 static int run_graph(pa_model* m, int n, size_t* pi) {
     pa_engine* e = m->e;
+    if (ensure_operand_copies(m)) return 1;
     if (!e->t.graph || e->profiling || e->t.timeline) return run_ops(m, n, pi);
     if (m->graph_epoch != e->tuning_epoch) {            // kernel choice may have changed since the capture
         PA_HIP(e, hipStreamSynchronize(e->stream));
@@ -1620,6 +1655,7 @@ int pa_engine_bcast(pa_engine* e, void* dev_ptr, size_t nbytes, int root) {
 // other GPU, HBM to HBM (north_star "one-time RCCL broadcast of weights over xGMI")
 int pa_engine_bcast_weights(pa_engine* e, pa_model* m, int root) {
     if (!e || !m || m->e != e) return 1;
+    m->wr_valid = false;
     return pa_engine_bcast(e, m->d_w, m->n_w * sizeof(float), root);
 }
 
@@ -1631,6 +1667,7 @@ int pa_engine_bcast_weights_from(pa_engine* e, pa_model* src, pa_model* dst, int
     if (!e || !dst || dst->e != e || (src && (src->e != e || src->n_w != dst->n_w))) return 1;
     if (!e->comm) PA_FAIL(e, "pa_engine_bcast_weights_from: call pa_engine_comm_init first");
     PA_HIP(e, hipSetDevice(e->dev));
+    dst->wr_valid = false;
     const void* send = src ? src->d_w : dst->d_w;
     const ncclResult_t r = e->comm->Broadcast(send, dst->d_w, dst->n_w * sizeof(float), ncclUint8, root, e->comm->comm, e->stream);
     if (r != ncclSuccess) PA_FAIL(e, "ncclBroadcast: %s", e->comm->GetErrorString(r));
