@@ -27,7 +27,7 @@
 // Same products in the same order per accumulator as every other h2 kernel (cross: wh am; main: wh ah, flushed into acc once
 // per chunk; the rows of a tap touch different accumulators, so their order is free): bitwise identical results.
 //
-// LDS: 2 patch buffers x 2 planes x 192 pixels x 64 B = 49 152 B; registers bound the occupancy (2 workgroups per CU).
+// LDS: 2 patch buffers x 2 planes x 192 pixels x 64 B, 32 KB apart = 57 344 B; registers bound the occupancy (2 workgroups per CU).
 #include "h2_common.h"
 
 namespace padel {
@@ -38,24 +38,53 @@ constexpr int kRPW = 18;                        // patch width in pixels (16 + h
 constexpr int kRNPix = 180;                     // 10 x 18
 constexpr int kRPlaneB = 192 * 64;              // one fp16 plane of a 32-channel chunk, padded to 12 spans of 16 pixels
 constexpr int kRPatchB = 2 * kRPlaneB;
+constexpr int kRBufStride = 32768;              // the two patch buffers sit 32 KB apart: switching buffers is one XOR per read address
 
 // byte offset, inside a plane, of logical 16-byte chunk q (K slots 8q..8q+7) of patch pixel p (conv_patch_h2.hip:hp_off)
 __device__ __forceinline__ unsigned hr_off(int p, int q) { return (unsigned)(p * 64 + ((q ^ (((p >> 2) & 1) << 1)) << 4)); }
 
 typedef int hr_i32x4 __attribute__((ext_vector_type(4)));
 
+// DBG (tuning only, builds with -DPADEL_H2P_PROBES, pa_engine_set_tuning "timeline"): the record format of conv_patch_h2q.hip — every
+// wave stamps s_memtime at 5 points of every tap step into an LDS ring of 32 steps (tools/timeline_probe.py --kernel h2r):
+// 0 step top / 1 this tap's weights landed (counted wait passed) / 2 chunk barrier passed (tap 8; elsewhere = 1) / 3 the first
+// row's six products issued (its operands were in registers) / 4 last product issued
+constexpr int kRDbgSteps = 32;
+constexpr int kRDbgWords = 8 + 4 * kRDbgSteps * 5;
+
 }  // namespace
 
-template <int NF, int NBUF>
+template <int NF, int NBUF, bool DBG = false, int ABL = 0, int PRIO = 1>
 __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
     constexpr int MF = 4;
     static_assert(NF == 3, "a wave owns 3 channel fragments; 12 patch spans = 3 per wave");
     static_assert(NBUF == 2, "double-buffered patch");
-    __shared__ __attribute__((aligned(16))) float lds[(NBUF * kRPatchB) / 4];
+    constexpr int DBG_B = DBG ? (4 * kRDbgSteps * 5 + 4 * 64) * 8 : 0;
+    constexpr int PATCH_B = (NBUF - 1) * kRBufStride + kRPatchB;
+    __shared__ __attribute__((aligned(16))) float lds[(PATCH_B + DBG_B) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(ldsb + PATCH_B);
+    unsigned long long t_begin = 0;
+    int dbg_k = 0;
+    if constexpr (DBG) t_begin = __builtin_amdgcn_s_memtime();
+    (void)stamps; (void)t_begin; (void)dbg_k;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ablation probes (-DPADEL_H2P_PROBES instantiates ABL != 0, wrong results by construction; pa_engine_set_tuning "tune" selects
+    // one): bits switch pieces of the main loop off — 16 the patch requests, 32 the flushes, 64 the chunk barrier, 128 tap 8's row
+    // reads, 256 the weight requests
+#define PADEL_HR_ON(BIT_) (!(ABL & (BIT_)))
+#define PADEL_HR_PRIO(N_) do { if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(N_); } while (0)
+#define PADEL_HR_STAMP(J, slot)                                                                                   \
+    do {                                                                                                          \
+        if constexpr (DBG) {                                                                                      \
+            const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
+            const int real_ = (wave * kRDbgSteps + ((dbg_k + (J)) & (kRDbgSteps - 1))) * 5 + (slot);              \
+            const int dummy_ = 4 * kRDbgSteps * 5 + wave * 64 + lane;                                             \
+            stamps[lane == 0 ? real_ : dummy_] = t_;                                                              \
+        }                                                                                                         \
+    } while (0)
     const int wr = wave & 1, wc = wave >> 1;      // pixel half (rows 4 wr ..), channel half (fragments 3 wc ..)
     const int lr = lane & 15, lq = lane >> 4;
 
@@ -93,18 +122,18 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
         const bool ok = pp < kRNPix && (unsigned)(y0 - 1 + py) < (unsigned)a.H && (unsigned)(x0 - 1 + px) < (unsigned)a.W;
         voP[k] = ok ? (unsigned)((py * a.W + px) * a.in_cs * 4) + p_piece : kOOR3;
     }
-    // the wave's six requests of chunk CH_ into buffer BUF_.  Chunks beyond the last go through a descriptor of zero records (every
-    // lane out of range: zeros into a free buffer), so that the request count per tap — and with it every counted wait — is static
-#define PADEL_HR_PATCH(CH_, BUF_)                                                                                 \
+    // the wave's requests of span K_ (both planes) of chunk CH_ into buffer BUF_.  Chunks beyond the last go through a descriptor of
+    // zero records (every lane out of range: zeros into a free buffer), so that the request count per tap — and with it every
+    // counted wait — is static
+#define PADEL_HR_PSPAN(K_, CH_, BUF_)                                                                             \
     do {                                                                                                          \
         const unsigned so_ = (unsigned)(CH_) * 128u;                                                              \
-        const unsigned lb_ = lpw + (unsigned)(BUF_) * (unsigned)kRPatchB;                                         \
+        const unsigned lb_ = lpw + (unsigned)(BUF_) * (unsigned)kRBufStride;                                      \
         i32x4 rs_ = rsrcP;                                                                                        \
         rs_[2] = (CH_) < nch ? (int)0x80000000u : 0;                                                              \
-        dma3<0>(voP[0], rs_, so_, lb_); dma3<kRPlaneB>(voP[0], rs_, so_ + 32u, lb_);                              \
-        dma3<1024>(voP[1], rs_, so_, lb_); dma3<kRPlaneB + 1024>(voP[1], rs_, so_ + 32u, lb_);                    \
-        dma3<2048>(voP[2], rs_, so_, lb_); dma3<kRPlaneB + 2048>(voP[2], rs_, so_ + 32u, lb_);                    \
+        dma3<(K_) * 1024>(voP[K_], rs_, so_, lb_); dma3<kRPlaneB + (K_) * 1024>(voP[K_], rs_, so_ + 32u, lb_);    \
     } while (0)
+#define PADEL_HR_PATCH(CH_, BUF_) do { PADEL_HR_PSPAN(0, CH_, BUF_); PADEL_HR_PSPAN(1, CH_, BUF_); PADEL_HR_PSPAN(2, CH_, BUF_); } while (0)
 
     // ---- weights: a.wr = [fragment][k-step][lane][16 bytes] (h plane only): lane l of fragment j reads bytes [16 l, 16 l + 16)
     // of the k-step's 1 KB — its MFMA A operand (row l & 15 at k = 8 (l >> 4)).  One descriptor per fragment, one lane offset
@@ -131,7 +160,17 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
 #define PADEL_HR_WAITW(SET_, N_)                                                                                  \
     asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(N_) : "memory")
 
-    const int rd_pix = 4 * wr * kRPW + lr;        // patch pixel of the wave's row 0, kx = 0
+    // ---- row reads: patch pixel p = p0 + d with p0 = 72 wr + lr (the wave's row 0 at kx = 0) and d = 18 R + KX; hr_off's swizzle
+    // term depends on bit 2 of p only, i.e. on d & 7 (adding a multiple of 8 leaves bit 2 alone): eight lane addresses, everything
+    // else of a read is an immediate (64 d, + the m plane).  The two patch buffers sit 32 KB apart, so that the chunk hand-over is
+    // one XOR per address; a read costs no VALU at all (the first version recomputed ~8 VALU per read: the ky = 2 taps, four
+    // reads, took 570 ticks instead of 410 — profiles/r6d_timeline_h2r_192.txt)
+    unsigned rbase[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int p0 = 4 * wr * kRPW + lr;
+        rbase[r] = (unsigned)(p0 * 64 + ((lq ^ ((((p0 + r) >> 2) & 1) << 1)) << 4));
+    }
 
     f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
 #pragma unroll
@@ -139,77 +178,109 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
     h16x8 ah[4], am[4];                           // input rows in 4 sliding slots (row r of the current kx in slot r & 3)
-    // input row R_ (0..5 of the wave's window) at column shift KX_ of patch buffer PB_ into slot R_ & 3
-#define PADEL_HR_READROW(PB_, R_, KX_)                                                                            \
+    // input row R_ (0..5 of the wave's window) at column shift KX_ of the buffer rbase points into, into slot R_ & 3
+#define PADEL_HR_READROW(R_, KX_)                                                                                 \
     do {                                                                                                          \
-        int rp_ = rd_pix;                                                                                         \
-        asm volatile("" : "+v"(rp_));                      /* addresses recomputed per read (3 VALU): 18 hoisted ones would spill */ \
-        const char* p_ = (PB_) + hr_off(rp_ + (R_) * kRPW + (KX_), lq);                                           \
-        ah[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_);                                                       \
-        am[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_ + kRPlaneB);                                            \
+        constexpr int d_ = (R_) * kRPW + (KX_);                                                                   \
+        const char* p_ = ldsb + rbase[d_ & 7];                                                                    \
+        ah[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_ + d_ * 64);                                             \
+        am[(R_) & 3] = *reinterpret_cast<const h16x8*>(p_ + d_ * 64 + kRPlaneB);                                  \
     } while (0)
-    // the 6 products of output row F_ at tap row KY_ (its input row F_ + KY_ sits in slot (F_ + KY_) & 3) with weight set SET_
-#define PADEL_HR_MFMA_ROW(F_, KY_, SET_)                                                                          \
+    // the 6 products of output row F_ at tap row KY_ (its input row F_ + KY_ sits in slot (F_ + KY_) & 3) with weight set SET_;
+    // FIRST_: tap 0 starts the chunk's main chain from the MFMA's constant-0 C operand (bitwise 0 + x)
+#define PADEL_HR_MFMA_ROW(F_, KY_, SET_, FIRST_)                                                                  \
     do {                                                                                                          \
         constexpr int s_ = ((F_) + (KY_)) & 3;                                                                    \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), am[s_], cross[F_][j], 0, 0, 0); \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
-            part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), ah[s_], part[F_][j], 0, 0, 0); \
+            part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), ah[s_],   \
+                                                                 (FIRST_) ? (f32x4){0.f, 0.f, 0.f, 0.f} : part[F_][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    // the chunk's main sum of output row F_ into acc (two-level summation, as in every h2 kernel)
+#define PADEL_HR_FLUSH(F_)                                                                                        \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) acc[F_][j] += part[F_][j];                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
     // tap step T_ = 3 kx + ky of the current chunk (weight set T_ % 3 — 9 % 3 == 0, so a tap uses the same set in every chunk).
     // Queue of the wave behind W(T_) when it waits: [P, issued in tap 8] W(T_ + 1) [P] W(T_ + 2): 6 requests, 12 in taps 0 / 1.
+    // Tap 8 carries the chunk's bookkeeping between its MFMA rows, where the matrix pipe still holds the previous row's products:
+    // the chunk barrier, the buffer switch of the row addresses, the next chunk's first rows, the requests of the patch after
+    // next (a span per row) and the flush of the main sums (row k's behind row k + 1's products; the last one under tap 0).
 #define PADEL_HR_STEP(T_)                                                                                         \
     do {                                                                                                          \
         constexpr int kx_ = h2_tap_kx(T_), ky_ = h2_tap_ky(T_), set_ = (T_) % 3;                                  \
-        PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                                                                 \
+        PADEL_HR_STAMP(T_, 0);                                                                                    \
+        PADEL_HR_PRIO(0);                                                                                         \
+        if constexpr (PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                                           \
         PADEL_HR_WAITW(set_, (T_) < 2 ? 12 : 6);                                                                  \
+        PADEL_HR_STAMP(T_, 1);                                                                                    \
+        if constexpr ((T_) != 8) PADEL_HR_STAMP(T_, 2);                                                           \
+        PADEL_HR_PRIO(1);                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         if constexpr (ky_ == 0) {                                                                                 \
-            PADEL_HR_MFMA_ROW(0, 0, set_);                                                                        \
-            PADEL_HR_READROW(pcur, 4, kx_);                /* slot 0, first used by row 3 of ky = 1 */            \
+            PADEL_HR_MFMA_ROW(0, 0, set_, (T_) == 0 && !(ABL & 32));                                                             \
+            PADEL_HR_STAMP(T_, 3);                                                                                \
+            if constexpr ((T_) == 0 && !(ABL & 32)) PADEL_HR_FLUSH(1);/* the previous chunk's last row (chunk 0: + 0) */      \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(4, kx_);   /* slot 0, first used by row 3 of ky = 1 */            \
+            PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(1, 0, set_); PADEL_HR_MFMA_ROW(2, 0, set_); PADEL_HR_MFMA_ROW(3, 0, set_);          \
+            PADEL_HR_MFMA_ROW(1, 0, set_, (T_) == 0 && !(ABL & 32)); PADEL_HR_PRIO(3); PADEL_HR_MFMA_ROW(2, 0, set_, (T_) == 0 && !(ABL & 32)); PADEL_HR_MFMA_ROW(3, 0, set_, (T_) == 0 && !(ABL & 32)); \
         } else if constexpr (ky_ == 1) {                                                                          \
-            PADEL_HR_MFMA_ROW(0, 1, set_);                                                                        \
-            PADEL_HR_READROW(pcur, 5, kx_);                /* slot 1, first used by row 3 of ky = 2 */            \
+            PADEL_HR_MFMA_ROW(0, 1, set_, false);                                                                 \
+            PADEL_HR_STAMP(T_, 3);                                                                                \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(5, kx_);   /* slot 1, first used by row 3 of ky = 2 */            \
+            PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(1, 1, set_); PADEL_HR_MFMA_ROW(2, 1, set_); PADEL_HR_MFMA_ROW(3, 1, set_);          \
+            PADEL_HR_MFMA_ROW(1, 1, set_, false); PADEL_HR_PRIO(3); PADEL_HR_MFMA_ROW(2, 1, set_, false); PADEL_HR_MFMA_ROW(3, 1, set_, false); \
         } else if constexpr (kx_ < 2) {                    /* ky = 2: rows 2, 3, 0, 1 free slots 0, 1, 2, 3 for the next column */ \
-            PADEL_HR_MFMA_ROW(2, 2, set_);                                                                        \
-            PADEL_HR_READROW(pcur, 0, kx_ + 1);                                                                   \
+            PADEL_HR_MFMA_ROW(2, 2, set_, false);                                                                 \
+            PADEL_HR_STAMP(T_, 3);                                                                                \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(0, kx_ + 1);                                                                         \
+            PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(3, 2, set_);                                                                        \
-            PADEL_HR_READROW(pcur, 1, kx_ + 1);                                                                   \
+            PADEL_HR_MFMA_ROW(3, 2, set_, false);                                                                 \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(1, kx_ + 1);                                                                         \
+            PADEL_HR_PRIO(3);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(0, 2, set_);                                                                        \
-            PADEL_HR_READROW(pcur, 2, kx_ + 1);                                                                   \
+            PADEL_HR_MFMA_ROW(0, 2, set_, false);                                                                 \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(2, kx_ + 1);                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(1, 2, set_);                                                                        \
-            PADEL_HR_READROW(pcur, 3, kx_ + 1);                                                                   \
+            PADEL_HR_MFMA_ROW(1, 2, set_, false);                                                                 \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(3, kx_ + 1);                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
         } else {                                           /* tap 8: the chunk barrier sits behind the first row's products */ \
-            PADEL_HR_MFMA_ROW(2, 2, set_);                                                                        \
+            PADEL_HR_MFMA_ROW(2, 2, set_, false);                                                                 \
             /* every read of this chunk's patch has returned (row 5 was read under tap 7; lgkmcnt(0) costs nothing here), */ \
             /* and the wave's own requests of the next chunk's patch landed long ago (in order in front of W(8)) */ \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-            __builtin_amdgcn_s_barrier();                                                                         \
+            if constexpr (PADEL_HR_ON(64)) __builtin_amdgcn_s_barrier();                                                    \
             asm volatile("" ::: "memory");                                                                        \
-            PADEL_HR_READROW(pnxt, 0, 0);                                                                         \
+            PADEL_HR_STAMP(T_, 2); PADEL_HR_STAMP(T_, 3);                                                         \
+            _Pragma("unroll") for (int r = 0; r < 8; ++r) rbase[r] ^= (unsigned)kRBufStride;                      \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(0, 0);                                                         \
+            PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(3, 2, set_);                                                                        \
-            PADEL_HR_READROW(pnxt, 1, 0);                                                                         \
+            PADEL_HR_MFMA_ROW(3, 2, set_, false);                                                                 \
+            PADEL_HR_PRIO(3);                                                                 \
+            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(2);                                                               \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(1, 0);                                                         \
+            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN(0, c + 2, c & 1);   /* into the buffer this chunk read */         \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_PATCH(c + 2, c & 1);                  /* into the buffer this chunk read */                  \
+            PADEL_HR_MFMA_ROW(0, 2, set_, false);                                                                 \
+            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(3);                                                               \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(2, 0);                                                         \
+            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN(1, c + 2, c & 1);                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(0, 2, set_);                                                                        \
-            PADEL_HR_READROW(pnxt, 2, 0);                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(1, 2, set_);                                                                        \
-            PADEL_HR_READROW(pnxt, 3, 0);                                                                         \
+            PADEL_HR_MFMA_ROW(1, 2, set_, false);                                                                 \
+            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(0);                                                               \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(3, 0);                                                         \
+            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN(2, c + 2, c & 1);                                                 \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
         }                                                                                                         \
+        PADEL_HR_STAMP(T_, 4);                                                                                    \
     } while (0)
 
     // prologue: P(0), W(0), W(1), P(1) — the order the steady state leaves behind tap 8
@@ -217,23 +288,22 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
     PADEL_HR_LOADW(0, 0);
     PADEL_HR_LOADW(1, 1);
     PADEL_HR_PATCH(1, 1);
+    if constexpr ((ABL & 256) != 0) { wait_vm3<0>(); for (int j = 0; j < NF; ++j) w[2][j] = w[0][j]; }      // (probe: no weight requests inside the loop)
     wait_vm3<12>();                               // P(0) landed (W(0), W(1), P(1) may be in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    PADEL_HR_READROW(ldsb, 0, 0); PADEL_HR_READROW(ldsb, 1, 0); PADEL_HR_READROW(ldsb, 2, 0); PADEL_HR_READROW(ldsb, 3, 0);
+    PADEL_HR_READROW(0, 0); PADEL_HR_READROW(1, 0); PADEL_HR_READROW(2, 0); PADEL_HR_READROW(3, 0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-        const char* const pcur = ldsb + (c & 1) * kRPatchB;
-        const char* const pnxt = ldsb + ((c + 1) & 1) * kRPatchB;
         PADEL_HR_STEP(0); PADEL_HR_STEP(1); PADEL_HR_STEP(2); PADEL_HR_STEP(3); PADEL_HR_STEP(4);
         PADEL_HR_STEP(5); PADEL_HR_STEP(6); PADEL_HR_STEP(7); PADEL_HR_STEP(8);
-#pragma unroll
-        for (int f = 0; f < MF; ++f)
-#pragma unroll
-            for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
         s_kb += 9u * 1024u;
+        dbg_k += 9;
     }
+    PADEL_HR_PRIO(0);
+    PADEL_HR_FLUSH(1);
+    if constexpr ((ABL & 32) != 0) { PADEL_HR_FLUSH(0); PADEL_HR_FLUSH(2); PADEL_HR_FLUSH(3); }      // (probe: one main chain, flushed once)
     wait_vm3<0>();                                // the tail's requests (zeros into a free buffer, weights nobody uses) before the LDS is released
 #undef PADEL_HR_STEP
 #undef PADEL_HR_MFMA_ROW
@@ -241,6 +311,8 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
 #undef PADEL_HR_WAITW
 #undef PADEL_HR_LOADW
 #undef PADEL_HR_PATCH
+#undef PADEL_HR_PSPAN
+#undef PADEL_HR_FLUSH
 
     int mpix[MF];
 #pragma unroll
@@ -252,6 +324,23 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
     const bool fast = y0 + 8 <= a.Ho && x0 + 16 <= a.Wo && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
                       (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
     if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
+    if constexpr (DBG) {
+        if (a.dbg) {
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            unsigned long long* d = a.dbg + (long long)blockIdx.x * kRDbgWords;
+            for (int i = tid; i < 4 * kRDbgSteps * 5; i += 256) d[8 + i] = stamps[i];
+            if (lane == 0) {
+                const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+                const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+                d[wave] = ((unsigned long long)xcc << 32) | hw;
+                if (wave == 0) { d[4] = t_begin; d[5] = t_end; d[6] = (unsigned long long)(nch * 9); d[7] = (unsigned long long)bid; }
+            }
+        }
+    }
+#undef PADEL_HR_STAMP
+#undef PADEL_HR_PRIO
+#undef PADEL_HR_ON
 }
 
 // one thread per 16 bytes of the copy: [fragment f][k-step t][lane l] <- bytes [16 (l >> 4), +16) of the h half of k-step t of row
@@ -287,7 +376,20 @@ hipError_t launch_conv_h2r(const ConvArgs& a_in, hipStream_t s) {
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + 5) / 6;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    hipLaunchKernelGGL((conv_h2r_kernel<3, 2>), grid, dim3(256), 0, s, a);
+#ifdef PADEL_H2P_PROBES
+    if (a.dbg) {
+        hipLaunchKernelGGL((conv_h2r_kernel<3, 2, true>), grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+#define PADEL_HR_ABL(N_) case N_: hipLaunchKernelGGL((conv_h2r_kernel<3, 2, false, N_>), grid, dim3(256), 0, s, a); return hipGetLastError();
+    switch (a.tune & ~15) {
+        PADEL_HR_ABL(16) PADEL_HR_ABL(32) PADEL_HR_ABL(48) PADEL_HR_ABL(64) PADEL_HR_ABL(128) PADEL_HR_ABL(256) PADEL_HR_ABL(240) PADEL_HR_ABL(496) PADEL_HR_ABL(512) PADEL_HR_ABL(1008)
+        default: break;
+    }
+#undef PADEL_HR_ABL
+#endif
+    if (a.tune & 2) hipLaunchKernelGGL((conv_h2r_kernel<3, 2, false, 0, 0>), grid, dim3(256), 0, s, a);      // tuning only: no priority ladder
+    else hipLaunchKernelGGL((conv_h2r_kernel<3, 2>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

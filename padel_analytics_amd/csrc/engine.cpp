@@ -786,7 +786,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             // tuning only ("timeline"): collect the s_memtime timeline of this launch into timeline_path
             unsigned long long* dbg_dev = nullptr;
             size_t dbg_bytes = 0;
-            if (e->t.timeline && h2 && lv == 323 && conv_h2q_supported(a) && !e->timeline_path.empty()) {
+            if (e->t.timeline && h2 && ((lv == 323 && conv_h2q_supported(a)) || (lv == 324 && conv_h2r_supported(a))) && !e->timeline_path.empty()) {
                 const size_t patches = (size_t)n * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);          // conv_patch_h2q.hip: one record per workgroup of its 1-D grid
                 dbg_bytes = 8 * ((patches + 7) / 8) * (size_t)((a.n16 + 5) / 6) * (8 + 4 * 32 * 5) * 8;          // kQDbgWords of conv_patch_h2q.hip (32-step ring)
             } else if (e->t.timeline && !h2 && use_tap && lv == 7 && o.ksize == 3 && !e->timeline_path.empty()) {

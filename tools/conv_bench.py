@@ -86,8 +86,12 @@ def main():
         x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32)
         for t in tiles:
             kw = dict(impl=0, variant=-1, tap_pd=2)        # "auto" / Tn / Apn: the fp32-MFMA tap kernels
-            if t.startswith("T"):
-                kw.update(variant=int(t[1:]))
+            kw["tune"] = 1
+            if t.startswith("T"):                         # Tn = tile n; Tn:m = tile n with tuning word m (probe builds: ablation bits)
+                tt = t[1:].split(":")
+                kw.update(variant=int(tt[0]))
+                if len(tt) > 1:
+                    kw["tune"] = int(tt[1])
             elif t.startswith("B"):                       # bf16x3 kernels: B = auto tile, Bn = tile n
                 kw.update(impl=2, variant=int(t[1:]) if len(t) > 1 else -1)
             elif t.startswith("Ap"):
@@ -103,7 +107,7 @@ def main():
             except E.EngineError:
                 pass
         m.close()
-    eng.set_tuning(impl=2, variant=-1, tap_pd=2)
+    eng.set_tuning(impl=2, variant=-1, tap_pd=2, tune=1)
     print("%-30s" % "shape" + "".join("%9s" % t for t in tiles))
     for name, row in table.items():
         print("%-30s" % name + "".join("%9s" % (("%.1f" % row[t][0]) if t in row else "-") for t in tiles))

@@ -22,19 +22,24 @@ STEPS, WORDS = 64, 8 + 4 * 64 * 5
 
 
 def run_conv(dump, kernel="lds", B=64, H=48, W=80, cin=192, cout=192):
+    w16 = kernel == "h2r"
+    if kernel == "h2r":
+        kernel = "h2q"
     if kernel not in ("tap", "h2q"):
         raise SystemExit("the LDS kernel's DIAG instantiations were retired with round 2 (tools/legacy_conv/); use --kernel tap")
     from padel_analytics_amd import engine as E, graph as G
     eng = E.default_engine(0)
     eng.set_profiling(True)
     h2 = kernel == "h2q"
-    eng.set_tuning(impl=0, variant=323 if h2 else 7, timeline=1)
+    eng.set_tuning(impl=0, variant=(324 if w16 else 323) if h2 else 7, timeline=1)
     eng.lib.pa_engine_set_timeline_path(eng.handle, dump.encode())
     rng = np.random.default_rng(0)
     g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2 if h2 else G.DTYPE_F32)
     b0 = g.buf(0, cin)
     b1 = g.buf(0, G.pad16(cout))
     w = rng.normal(0, (2.0 / (cin * 9)) ** 0.5, (cout, cin, 3, 3)).astype(np.float32)
+    if w16:
+        w = w.astype(np.float16).astype(np.float32)          # fp16 numbers: PA_CONV_W_SINGLE, the two-product kernels
     g.conv((b0, 0, cin), (b1, 0), w, np.zeros(cout, np.float32), 3, 1, 1, out_width=G.pad16(cout) if h2 else None)
     if h2:                             # the measured conv writes pairs; a tiny fp32 head keeps pa_tracknet_infer's contract
         hd = g.buf(0, 16)
@@ -56,14 +61,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/timeline.txt")
     ap.add_argument("--dump", default="/tmp/padel_conv_timeline.bin")
-    ap.add_argument("--kernel", default="tap", choices=["tap", "h2q"],
+    ap.add_argument("--kernel", default="tap", choices=["tap", "h2q", "h2r"],
                     help="tap = conv_tap_kernel (v5) timeline instantiation; h2q = conv_h2q_kernel (h2 quad patch kernel)")
     ap.add_argument("--cin", type=int, default=192)
     ap.add_argument("--cout", type=int, default=192)
     ap.add_argument("--hw", default="48x80")
     a = ap.parse_args()
     global STEPS, WORDS
-    h2q = a.kernel == "h2q"
+    h2r = a.kernel == "h2r"
+    h2q = a.kernel in ("h2q", "h2r")
     if h2q:
         STEPS, WORDS = 32, 8 + 4 * 32 * 5            # conv_patch_h2q.hip:kQDbgSteps
     H_, W_ = (int(v) for v in a.hw.split("x"))
@@ -78,7 +84,7 @@ def main():
     nks = int(hdr[0, 6])
     out = []
     P = out.append
-    P(f"kernel: {'conv_h2q_kernel<3> (h2 quad patch)' if h2q else 'conv_tap_kernel<2,2,2,3> (v5)' if a.kernel == 'tap' else 'conv_lds_kernel<2,2,2,3,3,1> (v2)'}")
+    P(f"kernel: {'conv_h2r_kernel<3,2> (register-weights quad, two products)' if h2r else 'conv_h2q_kernel<3> (h2 quad patch)' if h2q else 'conv_tap_kernel<2,2,2,3> (v5)' if a.kernel == 'tap' else 'conv_lds_kernel<2,2,2,3,3,1> (v2)'}")
     P(f"conv {a.cin}->{a.cout} 3x3 on 64 x {a.hw}, {nblk} workgroups, {nks} k-steps, instrumented kernel time {ms:.3f} ms")
     life = (hdr[:, 5].astype(np.int64) - hdr[:, 4].astype(np.int64))
     P(f"workgroup lifetime (s_memtime ticks): mean {life.mean():.0f}  p10 {np.percentile(life, 10):.0f}  p90 {np.percentile(life, 90):.0f}"
@@ -96,6 +102,13 @@ def main():
             "t3->t4 36 MFMAs issued (576 if alone)": t[..., 4] - t[..., 3],
             "t4->t0' to the next step (chunk flush after tap 8)": nxt - t[..., 4],
             "whole tap step": nxt - t[..., 0],
+        } if not h2r else {
+            "t0->t1 weight requests of tap + 2 issued + counted wait for this tap's": t[..., 1] - t[..., 0],
+            "t1->t2 (tap 8 only: first row's 6 MFMAs + chunk barrier)": t[..., 2] - t[..., 1],
+            "t2->t3 first row's operands + its 6 MFMAs issued (96 if alone; tap 8: 0)": t[..., 3] - t[..., 2],
+            "t3->t4 the other 18 MFMAs + row prefetch reads (288 if alone)": t[..., 4] - t[..., 3],
+            "t4->t0' to the next step (chunk flush after tap 8)": nxt - t[..., 4],
+            "whole tap step (384 if alone)": nxt - t[..., 0],
         }
         for wv in range(4):
             v = (nxt - t[..., 0])[:, wv].reshape(-1)
@@ -141,7 +154,7 @@ def main():
     # prologue / epilogue (ring keeps steps nks-64 ..): epilogue = last MFMA issued -> end stamp
     first = max(nks - STEPS, 0)
     t_first = st[:, 0, first & (STEPS - 1), 0]
-    t_lastm = st[:, 0, (nks - 1) & (STEPS - 1), 4 if a.kernel in ("tap", "h2q") else 2]
+    t_lastm = st[:, 0, (nks - 1) & (STEPS - 1), 4 if a.kernel in ("tap", "h2q", "h2r") else 2]
     tb, te = hdr[:, 4].astype(np.int64), hdr[:, 5].astype(np.int64)
     epi = te - t_lastm
     mainloop = (t_lastm - t_first) / (nks - first)
@@ -178,7 +191,7 @@ def main():
             for s in steps:
                 e = st[b, wv, s & (STEPS - 1)]
                 n0 = st[b, wv, (s + 1) & (STEPS - 1), 0]
-                segs = (((e[0], e[1], "w"), (e[1], e[2], "b"), (e[2], e[3], "l"), (e[3], e[4], "M"), (e[4], n0, ".")) if a.kernel in ("tap", "h2q")
+                segs = (((e[0], e[1], "w"), (e[1], e[2], "b"), (e[2], e[3], "l"), (e[3], e[4], "M"), (e[4], n0, ".")) if a.kernel in ("tap", "h2q", "h2r")
                         else ((e[0], e[1], "l"), (e[1], e[2], "M"), (e[2], e[3], "w"), (e[3], e[4], "b"), (e[4], n0, ".")))
                 for (lo, hi, ch) in segs:
                     c0, c1 = int((lo - t_lo) // res), int((hi - t_lo) // res)
@@ -186,7 +199,7 @@ def main():
                         row[c] = ch
             P(f"     wg {int(hdr[b, 7]):5d} simd {simd}: " + "".join(row))
     P("  legend: " + ("w = counted vmcnt wait, b = barrier, l = DMA requests + ds_read wait, M = MFMA burst being issued"
-                     if a.kernel in ("tap", "h2q") else
+                     if a.kernel in ("tap", "h2q", "h2r") else
                      "l = prefetch issue + ds_read wait, M = MFMA burst being issued, w = vmcnt wait, b = ds_write + barrier")
       + f"; 1 column = {res} ticks")
     # compact copy of 16 CUs for offline analysis
