@@ -27,7 +27,7 @@
 // Same products in the same order per accumulator as every other h2 kernel (cross: wh am; main: wh ah, flushed into acc once
 // per chunk; the rows of a tap touch different accumulators, so their order is free): bitwise identical results.
 //
-// LDS: 2 patch buffers x 2 planes x 192 pixels x 64 B, 32 KB apart = 57 344 B; registers bound the occupancy (2 workgroups per CU).
+// LDS: 2 patch buffers x 2 planes x 192 pixels x 64 B, 32 KB apart = 57 344 B + 6 KB of request offsets; registers bound the occupancy (2 workgroups per CU).
 #include "h2_common.h"
 
 namespace padel {
@@ -54,27 +54,60 @@ constexpr int kRDbgWords = 8 + 4 * kRDbgSteps * 5;
 
 }  // namespace
 
-template <int NF, int NBUF, bool DBG = false, int ABL = 0, int PRIO = 1>
-__global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
+// the tile of virtual block id v: XCD-aware 1-D map — the channel tiles of one pixel patch are neighbours on one XCD
+// (conv_patch_h2q.hip).  Invalid ids (grid padding) sit at the end of every XCD's range: once a workgroup's id is invalid, all its
+// later ones are
+struct HrTile { int n, y0, x0, f0; bool valid; };
+__device__ __forceinline__ HrTile hr_tile(const ConvArgs& a, int v, int vmax) {
+    HrTile t;
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;
+    const int q8 = nmt >> 3, r8 = nmt & 7, xcd = v & 7, idx = v >> 3;
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;
+    t.valid = v < vmax && mloc < q8 + (xcd < r8 ? 1 : 0);
+    const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
+    const int txN = (a.Wo + 15) >> 4, tyN = (a.Ho + 7) >> 3;
+    const int tpi = tyN * txN;
+    t.n = mt / tpi;
+    const int rt = mt - t.n * tpi;
+    const int ty = rt / txN, tx = rt - ty * txN;
+    t.y0 = ty * 8; t.x0 = tx * 16;
+    t.f0 = nt * 6;
+    return t;
+}
+
+// PERSISTENT workgroups (2 per CU, gridDim.x of them): workgroup b walks the virtual block ids b, b + gridDim.x, ...  What that
+// buys is the prologue: a fresh workgroup spends ~9 k cycles between its first instruction and its first MFMA (tile arithmetic,
+// the first patch from HBM, a barrier) — with the epilogue (7.7 k) a fixed 17.7 k cycles per tile in which the OTHER workgroup of the
+// CU has the matrix pipe to itself but, on a 96 -> 96 layer (27 taps, 10.4 k pipe cycles), not enough work to fill it.  Measured on
+// the non-persistent form: with everything but the MFMAs compiled out of the main loop the kernel reaches 533 / 691 TFLOP/s on
+// 96 -> 96 / 192 -> 192 — the main loop (489 / 602 then) was within 12 % of free, the fixed cost was the bound
+// (profiles/r6h_ablate_h2r.txt).  Here chunk 0 of the NEXT tile's patch is requested in tap 8 of the second-last chunk (where the
+// non-persistent form requested zeros to keep its counted waits static) and lands during the last chunk and the epilogue; chunk 1
+// follows at the next tile's start behind its first weights — the request order a fresh workgroup's prologue has, so every
+// counted wait is the same in every chunk of every tile.
+template <int NF, int NBUF, bool DBG = false, int ABL = 0, int PRIO = 0>
+__global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, const int vmax) {
     constexpr int MF = 4;
     static_assert(NF == 3, "a wave owns 3 channel fragments; 12 patch spans = 3 per wave");
     static_assert(NBUF == 2, "double-buffered patch");
     constexpr int DBG_B = DBG ? (4 * kRDbgSteps * 5 + 4 * 64) * 8 : 0;
     constexpr int PATCH_B = (NBUF - 1) * kRBufStride + kRPatchB;
-    __shared__ __attribute__((aligned(16))) float lds[(PATCH_B + DBG_B) / 4];
+    constexpr int PVO_B = 2 * 3 * 256 * 4;       // the lane offsets of the patch requests, two tiles' worth
+    __shared__ __attribute__((aligned(16))) float lds[(PATCH_B + PVO_B + DBG_B) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
-    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(ldsb + PATCH_B);
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(ldsb + PATCH_B + PVO_B);
     unsigned long long t_begin = 0;
     int dbg_k = 0;
-    if constexpr (DBG) t_begin = __builtin_amdgcn_s_memtime();
     (void)stamps; (void)t_begin; (void)dbg_k;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ablation probes (-DPADEL_H2P_PROBES instantiates ABL != 0, wrong results by construction; pa_engine_set_tuning "tune" selects
     // one): bits switch pieces of the main loop off — 16 the patch requests, 32 the flushes, 64 the chunk barrier, 128 tap 8's row
-    // reads, 256 the weight requests
+    // reads, 256 the weight requests, 512 the other row reads
 #define PADEL_HR_ON(BIT_) (!(ABL & (BIT_)))
+    // (PRIO = 1, tuning only: a priority ladder over the rows of a tap, so that the wave further into its burst keeps the pipe —
+    //  measured -2 % .. +0 %, profiles/r6g_prio_ladder.txt; off)
 #define PADEL_HR_PRIO(N_) do { if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(N_); } while (0)
 #define PADEL_HR_STAMP(J, slot)                                                                                   \
     do {                                                                                                          \
@@ -87,64 +120,68 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
     } while (0)
     const int wr = wave & 1, wc = wave >> 1;      // pixel half (rows 4 wr ..), channel half (fragments 3 wc ..)
     const int lr = lane & 15, lq = lane >> 4;
-
-    // XCD-aware 1-D tile map: the channel tiles of one pixel patch are neighbours on one XCD (conv_patch_h2q.hip)
-    const int nmt = a.n_mtiles, nnt = a.n_ntiles;
-    const int bid = blockIdx.x;
-    const int q8 = nmt >> 3, r8 = nmt & 7, xcd = bid & 7, idx = bid >> 3;
-    const int mloc = idx / nnt, nt = idx - mloc * nnt;
-    if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
-    const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
-    const int txN = (a.Wo + 15) >> 4, tyN = (a.Ho + 7) >> 3;
-    const int tpi = tyN * txN;
-    const int n = mt / tpi, rt = mt - n * tpi;
-    const int ty = rt / txN, tx = rt - ty * txN;
-    const int y0 = ty * 8, x0 = tx * 16;
-    const int f0 = nt * 2 * NF;
-    const int nch = a.cin >> 5;
+    const int nch = a.cin >> 5;                   // >= 2 (launch_conv_h2r)
+    const int G = (int)gridDim.x;
+    int v = (int)blockIdx.x;
+    HrTile cur = hr_tile(a, v, vmax);
+    if (!cur.valid) return;
 
     // ---- the patch: span s of a plane = 16 pixels x 64 bytes, lane i -> pixel 16 s + i / 4, physical 16-byte slot i & 3 =
     // logical chunk q of that pixel (hr_off), which is piece (q & 1) of group (q >> 1) of the pixel's 128 bytes [h0 m0 h1 m1]
     // in HBM; the plane's 32 bytes go in through the scalar offset.  Wave w requests spans 3 w .. 3 w + 2 of both planes.
-    const float* const in0 = a.in + (((long long)n * a.H + (y0 - 1)) * a.W + (x0 - 1)) * a.in_cs + a.in_choff;
-    const i32x4 rsrcP = make_rsrc3(in0);
-    const int p_lane = lane >> 2;
-    const int p_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
-    const unsigned p_piece = (unsigned)((p_q >> 1) * 64 + (p_q & 1) * 16);
+    // The lane offsets of the wave's three spans do not depend on the chunk (it enters through the scalar offset): 3 VGPRs per tile.
+    // A tile that does not exist gets a descriptor of zero records: every lane out of range, zeros into a free buffer — the request
+    // count per tap, and with it every counted wait, is static.
     const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
     const unsigned lpw = __builtin_amdgcn_readfirstlane(lp0 + (unsigned)wave * 3072u);
-    // the lane offsets of the wave's three spans do not depend on the chunk (it enters through the scalar offset): hoisted, 3 VGPRs
-    unsigned voP[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int pp = (3 * wave + k) * 16 + p_lane;
-        const int py = pp / kRPW, px = pp - py * kRPW;
-        const bool ok = pp < kRNPix && (unsigned)(y0 - 1 + py) < (unsigned)a.H && (unsigned)(x0 - 1 + px) < (unsigned)a.W;
-        voP[k] = ok ? (unsigned)((py * a.W + px) * a.in_cs * 4) + p_piece : kOOR3;
-    }
-    // the wave's requests of span K_ (both planes) of chunk CH_ into buffer BUF_.  Chunks beyond the last go through a descriptor of
-    // zero records (every lane out of range: zeros into a free buffer), so that the request count per tap — and with it every
-    // counted wait — is static
-#define PADEL_HR_PSPAN(K_, CH_, BUF_)                                                                             \
+    // Two parameter sets exist during a tile's main loop: this tile's (chunks 2.. and, at the tile's start, chunk 1) and the next
+    // tile's (its chunk 0, requested in tap 8 of this tile's second-last chunk).  The lane offsets are needed once per chunk: they
+    // live in LDS (2 sets x 3 spans x 256 lanes x 4 B behind the patch buffers, every lane reads what it wrote), not in 6 VGPRs —
+    // the main loop has none to spare.  The next tile's are computed at the tile's start, while the accumulators are not live yet.
+    i32x4 rsrcP, rsrcPn;
+    unsigned* const pvo = reinterpret_cast<unsigned*>(ldsb + PATCH_B) + tid;       // [set][span][256]
+#define PADEL_HR_PARAMS(T_, RS_, SET_)                                                                            \
+    do {                                                                                                          \
+        const float* const in0_ = a.in + (((long long)(T_).n * a.H + ((T_).y0 - 1)) * a.W + ((T_).x0 - 1)) * a.in_cs + a.in_choff; \
+        RS_ = make_rsrc3(in0_);                                                                                   \
+        RS_[2] = (T_).valid ? (int)0x80000000u : 0;                                                               \
+        const int pl_ = lane >> 2;                                                                                \
+        const int pq_ = (lane & 3) ^ (((lane >> 4) & 1) << 1);                                                    \
+        const unsigned piece_ = (unsigned)((pq_ >> 1) * 64 + (pq_ & 1) * 16);                                     \
+        _Pragma("unroll") for (int k = 0; k < 3; ++k) {                                                           \
+            const int pp = (3 * wave + k) * 16 + pl_;                                                             \
+            const int py = pp / kRPW, px = pp - py * kRPW;                                                        \
+            const bool ok = pp < kRNPix && (unsigned)((T_).y0 - 1 + py) < (unsigned)a.H && (unsigned)((T_).x0 - 1 + px) < (unsigned)a.W; \
+            pvo[((SET_) * 3 + k) * 256] = ok ? (unsigned)((py * a.W + px) * a.in_cs * 4) + piece_ : kOOR3;        \
+        }                                                                                                         \
+    } while (0)
+    // the wave's requests of span K_ (both planes) of the chunk at scalar offset SO_ of the tile RS_ / parameter set SET_ describe,
+    // into buffer BUF_
+#define PADEL_HR_PSPAN(K_, SO_, BUF_, RS_, SET_)                                                                  \
+    do {                                                                                                          \
+        const unsigned lb_ = lpw + (unsigned)(BUF_) * (unsigned)kRBufStride;                                      \
+        const unsigned vo_ = pvo[((SET_) * 3 + (K_)) * 256];                                                      \
+        dma3<(K_) * 1024>(vo_, RS_, (SO_), lb_); dma3<kRPlaneB + (K_) * 1024>(vo_, RS_, (SO_) + 32u, lb_);        \
+    } while (0)
+#define PADEL_HR_PATCH(CH_, BUF_, RS_, SET_)                                                                      \
     do {                                                                                                          \
         const unsigned so_ = (unsigned)(CH_) * 128u;                                                              \
-        const unsigned lb_ = lpw + (unsigned)(BUF_) * (unsigned)kRBufStride;                                      \
-        i32x4 rs_ = rsrcP;                                                                                        \
-        rs_[2] = (CH_) < nch ? (int)0x80000000u : 0;                                                              \
-        dma3<(K_) * 1024>(voP[K_], rs_, so_, lb_); dma3<kRPlaneB + (K_) * 1024>(voP[K_], rs_, so_ + 32u, lb_);    \
+        PADEL_HR_PSPAN(0, so_, BUF_, RS_, SET_); PADEL_HR_PSPAN(1, so_, BUF_, RS_, SET_); PADEL_HR_PSPAN(2, so_, BUF_, RS_, SET_); \
     } while (0)
-#define PADEL_HR_PATCH(CH_, BUF_) do { PADEL_HR_PSPAN(0, CH_, BUF_); PADEL_HR_PSPAN(1, CH_, BUF_); PADEL_HR_PSPAN(2, CH_, BUF_); } while (0)
+    // tap 8 of chunk c: chunk c + 2 of this tile, or — in the second-last chunk — chunk 0 of the next one; in the last chunk the
+    // requests go through a descriptor of zero records (nothing is fetched; they retire in front of the next tile's first weights
+    // and leave every counted wait as it is).  Scalar selects only: tap 8 stays one basic block
+#define PADEL_HR_PSPAN8(K_)                                                                                       \
+    do {                                                                                                          \
+        const unsigned lb_ = lpw + (unsigned)gpar * (unsigned)kRBufStride;                                        \
+        dma3<(K_) * 1024>(vo8[K_], rs8, so8, lb_); dma3<kRPlaneB + (K_) * 1024>(vo8[K_], rs8, so8 + 32u, lb_);    \
+    } while (0)
 
     // ---- weights: a.wr = [fragment][k-step][lane][16 bytes] (h plane only): lane l of fragment j reads bytes [16 l, 16 l + 16)
     // of the k-step's 1 KB — its MFMA A operand (row l & 15 at k = 8 (l >> 4)).  One descriptor per fragment, one lane offset
     const unsigned fragb = (unsigned)(nch * 9) * 1024u;
     const unsigned voffW = (unsigned)lane * 16u;
     i32x4 rsrcW[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) {
-        const int frag = min(f0 + NF * wc + j, a.n16 - 1);  // fragments beyond the matrix: any valid rows (never stored)
-        rsrcW[j] = make_rsrc3(reinterpret_cast<const char*>(a.wr) + (long long)frag * fragb);
-    }
     hr_i32x4 w[3][NF];
     unsigned s_kb = 0;                            // byte offset of the current chunk's first k-step inside a fragment
     // tap TT_ (0..10, relative to the current chunk: 9 and 10 are the next chunk's first two) into register set SET_; the reads of
@@ -165,18 +202,9 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
     // else of a read is an immediate (64 d, + the m plane).  The two patch buffers sit 32 KB apart, so that the chunk hand-over is
     // one XOR per address; a read costs no VALU at all (the first version recomputed ~8 VALU per read: the ky = 2 taps, four
     // reads, took 570 ticks instead of 410 — profiles/r6d_timeline_h2r_192.txt)
-    unsigned rbase[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int p0 = 4 * wr * kRPW + lr;
-        rbase[r] = (unsigned)(p0 * 64 + ((lq ^ ((((p0 + r) >> 2) & 1) << 1)) << 4));
-    }
+    unsigned rbase[8];                            // (set at every tile's start: not live through the epilogue)
 
     f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
-#pragma unroll
-    for (int f = 0; f < MF; ++f)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
     h16x8 ah[4], am[4];                           // input rows in 4 sliding slots (row r of the current kx in slot r & 3)
     // input row R_ (0..5 of the wave's window) at column shift KX_ of the buffer rbase points into, into slot R_ & 3
 #define PADEL_HR_READROW(R_, KX_)                                                                                 \
@@ -205,105 +233,166 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
     // tap step T_ = 3 kx + ky of the current chunk (weight set T_ % 3 — 9 % 3 == 0, so a tap uses the same set in every chunk).
-    // Queue of the wave behind W(T_) when it waits: [P, issued in tap 8] W(T_ + 1) [P] W(T_ + 2): 6 requests, 12 in taps 0 / 1.
-    // Tap 8 carries the chunk's bookkeeping between its MFMA rows, where the matrix pipe still holds the previous row's products:
-    // the chunk barrier, the buffer switch of the row addresses, the next chunk's first rows, the requests of the patch after
-    // next (a span per row) and the flush of the main sums (row k's behind row k + 1's products; the last one under tap 0).
+    // Queue of the wave behind W(T_) when it waits: [P, issued in tap 8 / at the tile's start] W(T_ + 1) [P] W(T_ + 2): 6 requests, 12
+    // in taps 0 / 1.  Tap 8 carries the chunk's bookkeeping between its MFMA rows, where the matrix pipe still holds the previous
+    // row's products: the chunk barrier, the buffer switch of the row addresses, the next chunk's first rows, the requests of the
+    // patch after next (a span per row; none in a tile's last chunk) and the flush of the main sums (row k's behind row k + 1's
+    // products; the last one under the next tap 0).
 #define PADEL_HR_STEP(T_)                                                                                         \
     do {                                                                                                          \
         constexpr int kx_ = h2_tap_kx(T_), ky_ = h2_tap_ky(T_), set_ = (T_) % 3;                                  \
         PADEL_HR_STAMP(T_, 0);                                                                                    \
         PADEL_HR_PRIO(0);                                                                                         \
-        if constexpr (PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                                           \
+        if constexpr (PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                                 \
         PADEL_HR_WAITW(set_, (T_) < 2 ? 12 : 6);                                                                  \
         PADEL_HR_STAMP(T_, 1);                                                                                    \
         if constexpr ((T_) != 8) PADEL_HR_STAMP(T_, 2);                                                           \
         PADEL_HR_PRIO(1);                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         if constexpr (ky_ == 0) {                                                                                 \
-            PADEL_HR_MFMA_ROW(0, 0, set_, (T_) == 0 && !(ABL & 32));                                                             \
+            PADEL_HR_MFMA_ROW(0, 0, set_, (T_) == 0 && !(ABL & 32));                                              \
             PADEL_HR_STAMP(T_, 3);                                                                                \
-            if constexpr ((T_) == 0 && !(ABL & 32)) PADEL_HR_FLUSH(1);/* the previous chunk's last row (chunk 0: + 0) */      \
-            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(4, kx_);   /* slot 0, first used by row 3 of ky = 1 */            \
+            if constexpr ((T_) == 0 && !(ABL & 32)) PADEL_HR_FLUSH(1);   /* the previous chunk's last row (chunk 0: + 0) */ \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(4, kx_);   /* slot 0, first used by row 3 of ky = 1 */ \
             PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
-            PADEL_HR_MFMA_ROW(1, 0, set_, (T_) == 0 && !(ABL & 32)); PADEL_HR_PRIO(3); PADEL_HR_MFMA_ROW(2, 0, set_, (T_) == 0 && !(ABL & 32)); PADEL_HR_MFMA_ROW(3, 0, set_, (T_) == 0 && !(ABL & 32)); \
+            PADEL_HR_MFMA_ROW(1, 0, set_, (T_) == 0 && !(ABL & 32)); PADEL_HR_PRIO(3);                            \
+            PADEL_HR_MFMA_ROW(2, 0, set_, (T_) == 0 && !(ABL & 32)); PADEL_HR_MFMA_ROW(3, 0, set_, (T_) == 0 && !(ABL & 32)); \
         } else if constexpr (ky_ == 1) {                                                                          \
             PADEL_HR_MFMA_ROW(0, 1, set_, false);                                                                 \
             PADEL_HR_STAMP(T_, 3);                                                                                \
-            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(5, kx_);   /* slot 1, first used by row 3 of ky = 2 */            \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(5, kx_);   /* slot 1, first used by row 3 of ky = 2 */ \
             PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             PADEL_HR_MFMA_ROW(1, 1, set_, false); PADEL_HR_PRIO(3); PADEL_HR_MFMA_ROW(2, 1, set_, false); PADEL_HR_MFMA_ROW(3, 1, set_, false); \
         } else if constexpr (kx_ < 2) {                    /* ky = 2: rows 2, 3, 0, 1 free slots 0, 1, 2, 3 for the next column */ \
             PADEL_HR_MFMA_ROW(2, 2, set_, false);                                                                 \
             PADEL_HR_STAMP(T_, 3);                                                                                \
-            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(0, kx_ + 1);                                                                         \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(0, kx_ + 1);                                         \
             PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             PADEL_HR_MFMA_ROW(3, 2, set_, false);                                                                 \
-            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(1, kx_ + 1);                                                                         \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(1, kx_ + 1);                                         \
             PADEL_HR_PRIO(3);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             PADEL_HR_MFMA_ROW(0, 2, set_, false);                                                                 \
-            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(2, kx_ + 1);                                                                         \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(2, kx_ + 1);                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             PADEL_HR_MFMA_ROW(1, 2, set_, false);                                                                 \
-            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(3, kx_ + 1);                                                                         \
+            if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(3, kx_ + 1);                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
         } else {                                           /* tap 8: the chunk barrier sits behind the first row's products */ \
             PADEL_HR_MFMA_ROW(2, 2, set_, false);                                                                 \
             /* every read of this chunk's patch has returned (row 5 was read under tap 7; lgkmcnt(0) costs nothing here), */ \
             /* and the wave's own requests of the next chunk's patch landed long ago (in order in front of W(8)) */ \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
-            if constexpr (PADEL_HR_ON(64)) __builtin_amdgcn_s_barrier();                                                    \
+            if constexpr (PADEL_HR_ON(64)) __builtin_amdgcn_s_barrier();                                          \
             asm volatile("" ::: "memory");                                                                        \
             PADEL_HR_STAMP(T_, 2); PADEL_HR_STAMP(T_, 3);                                                         \
+            unsigned vo8[3];                               /* the three lane offsets: read here, used a row of MFMAs later */ \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) vo8[k] = pvo[(set8 * 3 + k) * 256];                     \
             _Pragma("unroll") for (int r = 0; r < 8; ++r) rbase[r] ^= (unsigned)kRBufStride;                      \
-            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(0, 0);                                                         \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(0, 0);                                               \
             PADEL_HR_PRIO(2);                                                                                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             PADEL_HR_MFMA_ROW(3, 2, set_, false);                                                                 \
-            PADEL_HR_PRIO(3);                                                                 \
-            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(2);                                                               \
-            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(1, 0);                                                         \
-            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN(0, c + 2, c & 1);   /* into the buffer this chunk read */         \
+            PADEL_HR_PRIO(3);                                                                                     \
+            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(2);                                                     \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(1, 0);                                               \
+            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN8(0);   /* into the buffer this chunk read */ \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             PADEL_HR_MFMA_ROW(0, 2, set_, false);                                                                 \
-            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(3);                                                               \
-            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(2, 0);                                                         \
-            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN(1, c + 2, c & 1);                                                 \
+            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(3);                                                     \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(2, 0);                                               \
+            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN8(1);                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
             PADEL_HR_MFMA_ROW(1, 2, set_, false);                                                                 \
-            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(0);                                                               \
-            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(3, 0);                                                         \
-            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN(2, c + 2, c & 1);                                                 \
+            if constexpr (PADEL_HR_ON(32)) PADEL_HR_FLUSH(0);                                                     \
+            if constexpr (PADEL_HR_ON(128)) PADEL_HR_READROW(3, 0);                                               \
+            if constexpr (PADEL_HR_ON(16)) PADEL_HR_PSPAN8(2);                     \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
         }                                                                                                         \
         PADEL_HR_STAMP(T_, 4);                                                                                    \
     } while (0)
 
-    // prologue: P(0), W(0), W(1), P(1) — the order the steady state leaves behind tap 8
-    PADEL_HR_PATCH(0, 0);
-    PADEL_HR_LOADW(0, 0);
-    PADEL_HR_LOADW(1, 1);
-    PADEL_HR_PATCH(1, 1);
-    if constexpr ((ABL & 256) != 0) { wait_vm3<0>(); for (int j = 0; j < NF; ++j) w[2][j] = w[0][j]; }      // (probe: no weight requests inside the loop)
-    wait_vm3<12>();                               // P(0) landed (W(0), W(1), P(1) may be in flight)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    PADEL_HR_READROW(0, 0); PADEL_HR_READROW(1, 0); PADEL_HR_READROW(2, 0); PADEL_HR_READROW(3, 0);
-    __builtin_amdgcn_sched_barrier(0);
+    int gpar = 0;                                 // parity of the running chunk count = the buffer the current chunk reads
+    bool first = true;
+    int tpar = 0;                                 // parity of the tile count = the parameter set of the current tile
+    PADEL_HR_PARAMS(cur, rsrcPn, 0);
+    PADEL_HR_PATCH(0, 0, rsrcPn, 0);
+    for (;;) {                                    // ---- tiles
+        if constexpr (DBG) { t_begin = __builtin_amdgcn_s_memtime(); dbg_k = 0; }
+        // this tile's patch parameters are the ones the previous tile computed as "next"
+        rsrcP = rsrcPn;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            const int frag = min(cur.f0 + NF * wc + j, a.n16 - 1);   // fragments beyond the matrix: any valid rows (never stored)
+            rsrcW[j] = make_rsrc3(reinterpret_cast<const char*>(a.wr) + (long long)frag * fragb);
+        }
+        s_kb = 0;
+        // W(0), W(1), P(1): the order the steady state leaves behind tap 8 (P(0): before the loop / tap 8 of the previous tile's
+        // second-last chunk)
+        PADEL_HR_LOADW(0, 0);
+        PADEL_HR_LOADW(1, 1);
+        PADEL_HR_PATCH(1, gpar ^ 1, rsrcP, tpar);
+        const HrTile nxt = hr_tile(a, v + G, vmax);        // (the tile arithmetic runs under the latency of the requests above)
+        PADEL_HR_PARAMS(nxt, rsrcPn, tpar ^ 1);
+        if constexpr ((ABL & 256) != 0) { wait_vm3<0>(); for (int j = 0; j < NF; ++j) w[2][j] = w[0][j]; }      // (probe: no weight requests inside the loop)
+        if (first) {
+            wait_vm3<12>();                       // P(0) landed (W(0), W(1), P(1) may be in flight)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        {
+            int lr_ = lr;
+            asm volatile("" : "+v"(lr_));
+            const int p0 = 4 * wr * kRPW + lr_;
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                rbase[r] = (unsigned)(p0 * 64 + ((lq ^ ((((p0 + r) >> 2) & 1) << 1)) << 4)) ^ (gpar ? (unsigned)kRBufStride : 0u);
+        }
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
+        PADEL_HR_READROW(0, 0); PADEL_HR_READROW(1, 0); PADEL_HR_READROW(2, 0); PADEL_HR_READROW(3, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
-        PADEL_HR_STEP(0); PADEL_HR_STEP(1); PADEL_HR_STEP(2); PADEL_HR_STEP(3); PADEL_HR_STEP(4);
-        PADEL_HR_STEP(5); PADEL_HR_STEP(6); PADEL_HR_STEP(7); PADEL_HR_STEP(8);
-        s_kb += 9u * 1024u;
-        dbg_k += 9;
+        for (int c = 0; c < nch; ++c) {
+            const bool own8 = c + 2 < nch;
+            i32x4 rs8 = own8 ? rsrcP : rsrcPn;
+            if (c + 1 >= nch) rs8[2] = 0;
+            const unsigned so8 = own8 ? (unsigned)(c + 2) * 128u : 0u;
+            const int set8 = own8 ? tpar : tpar ^ 1;
+            PADEL_HR_STEP(0); PADEL_HR_STEP(1); PADEL_HR_STEP(2); PADEL_HR_STEP(3); PADEL_HR_STEP(4);
+            PADEL_HR_STEP(5); PADEL_HR_STEP(6); PADEL_HR_STEP(7); PADEL_HR_STEP(8);
+            s_kb += 9u * 1024u;
+            gpar ^= 1;
+            dbg_k += 9;
+        }
+        PADEL_HR_PRIO(0);
+        // the look-ahead requests of the last chunk (taps 9 / 10: weights nobody uses, issued to keep the counted waits static) target
+        // register sets 0 and 1: they must have landed before the epilogue may reuse those registers
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]) :: "memory");
+        PADEL_HR_FLUSH(1);
+        if constexpr ((ABL & 32) != 0) { PADEL_HR_FLUSH(0); PADEL_HR_FLUSH(2); PADEL_HR_FLUSH(3); }      // (probe: one main chain, flushed once)
+
+        int mpix[MF];
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const int oy = cur.y0 + 4 * wr + f, ox = cur.x0 + lr;
+            mpix[f] = (oy < a.Ho && ox < a.Wo) ? (cur.n * a.Ho + oy) * a.Wo + ox : -1;
+        }
+        const int fw = cur.f0 + NF * wc;
+        const bool fast = cur.y0 + 8 <= a.Ho && cur.x0 + 16 <= a.Wo && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
+                          (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
+        if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
+        if (!nxt.valid) break;
+        cur = nxt;
+        v += G;
+        tpar ^= 1;
+        first = false;
     }
-    PADEL_HR_PRIO(0);
-    PADEL_HR_FLUSH(1);
-    if constexpr ((ABL & 32) != 0) { PADEL_HR_FLUSH(0); PADEL_HR_FLUSH(2); PADEL_HR_FLUSH(3); }      // (probe: one main chain, flushed once)
     wait_vm3<0>();                                // the tail's requests (zeros into a free buffer, weights nobody uses) before the LDS is released
 #undef PADEL_HR_STEP
 #undef PADEL_HR_MFMA_ROW
@@ -312,18 +401,9 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
 #undef PADEL_HR_LOADW
 #undef PADEL_HR_PATCH
 #undef PADEL_HR_PSPAN
+#undef PADEL_HR_PSPAN8
+#undef PADEL_HR_PARAMS
 #undef PADEL_HR_FLUSH
-
-    int mpix[MF];
-#pragma unroll
-    for (int f = 0; f < MF; ++f) {
-        const int oy = y0 + 4 * wr + f, ox = x0 + lr;
-        mpix[f] = (oy < a.Ho && ox < a.Wo) ? (n * a.Ho + oy) * a.Wo + ox : -1;
-    }
-    const int fw = f0 + NF * wc;
-    const bool fast = y0 + 8 <= a.Ho && x0 + 16 <= a.Wo && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
-                      (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
-    if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
     if constexpr (DBG) {
         if (a.dbg) {
             const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -334,7 +414,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a) {
                 const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
                 const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
                 d[wave] = ((unsigned long long)xcc << 32) | hw;
-                if (wave == 0) { d[4] = t_begin; d[5] = t_end; d[6] = (unsigned long long)(nch * 9); d[7] = (unsigned long long)bid; }
+                if (wave == 0) { d[4] = t_begin; d[5] = t_end; d[6] = (unsigned long long)(nch * 9); d[7] = (unsigned long long)blockIdx.x; }      // the LAST tile's life
             }
         }
     }
@@ -366,7 +446,7 @@ hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStre
 }
 
 bool conv_h2r_supported(const ConvArgs& a) {
-    return a.w_single && a.wr && a.ksize == 3 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 32 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr && !a.in2;
+    return a.w_single && a.wr && a.ksize == 3 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 64 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr && !a.in2;
 }
 
 hipError_t launch_conv_h2r(const ConvArgs& a_in, hipStream_t s) {
@@ -375,21 +455,24 @@ hipError_t launch_conv_h2r(const ConvArgs& a_in, hipStream_t s) {
     const int batch = a.M / (a.Ho * a.Wo);
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
     a.n_ntiles = (a.n16 + 5) / 6;
-    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    const int vmax = 8 * ((a.n_mtiles + 7) / 8) * a.n_ntiles;          // virtual block ids
+    static int n_cu = 0;
+    if (!n_cu) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
+    const int per = (a.tune & 4) ? vmax : 2 * n_cu;                     // tuning bit 2: one workgroup per tile (the non-persistent form)
+    dim3 grid((unsigned)(vmax < per ? vmax : per), 1, 1);               // 2 workgroups per CU (registers); both multiples of 8
 #ifdef PADEL_H2P_PROBES
     if (a.dbg) {
-        hipLaunchKernelGGL((conv_h2r_kernel<3, 2, true>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((conv_h2r_kernel<3, 2, true>), grid, dim3(256), 0, s, a, vmax);
         return hipGetLastError();
     }
-#define PADEL_HR_ABL(N_) case N_: hipLaunchKernelGGL((conv_h2r_kernel<3, 2, false, N_>), grid, dim3(256), 0, s, a); return hipGetLastError();
+#define PADEL_HR_ABL(N_) case N_: hipLaunchKernelGGL((conv_h2r_kernel<3, 2, false, N_>), grid, dim3(256), 0, s, a, vmax); return hipGetLastError();
     switch (a.tune & ~15) {
-        PADEL_HR_ABL(16) PADEL_HR_ABL(32) PADEL_HR_ABL(48) PADEL_HR_ABL(64) PADEL_HR_ABL(128) PADEL_HR_ABL(256) PADEL_HR_ABL(240) PADEL_HR_ABL(496) PADEL_HR_ABL(512) PADEL_HR_ABL(1008)
+        PADEL_HR_ABL(16) PADEL_HR_ABL(240) PADEL_HR_ABL(1008)
         default: break;
     }
 #undef PADEL_HR_ABL
 #endif
-    if (a.tune & 2) hipLaunchKernelGGL((conv_h2r_kernel<3, 2, false, 0, 0>), grid, dim3(256), 0, s, a);      // tuning only: no priority ladder
-    else hipLaunchKernelGGL((conv_h2r_kernel<3, 2>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_h2r_kernel<3, 2>), grid, dim3(256), 0, s, a, vmax);
     return hipGetLastError();
 }
 

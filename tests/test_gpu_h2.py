@@ -446,3 +446,57 @@ def test_fused_stem_layer1_matches_unfused(gpu_engine, scale, hw, imgsz):
         assert rel <= 3e-5, f"head {l}: relative difference {rel:.3e}"
     assert np.array_equal(c0, c1) and int(c0.sum()) > 0
     assert np.array_equal(b0[..., 5], b1[..., 5]) and float(np.abs(b0[..., :4] - b1[..., :4]).max()) <= 2e-2 and float(np.abs(b0[..., 4] - b1[..., 4]).max()) <= 1e-4
+
+
+@pytest.mark.parametrize("shape", [(10, 50, 70, 64, 192, True), (13, 41, 100, 96, 96, False), (4, 64, 96, 192, 288, True)], ids=["2-chunks", "3-chunks", "6-chunks"])
+def test_h2r_persistent_workgroups_walk_many_tiles(gpu_engine, shape):
+    """Round 6: the register-weights quad kernel (conv_patch_h2r.hip, tile 324) runs 2 PERSISTENT workgroups per CU; a workgroup
+    requests its next tile's first patch chunk during the current tile's second-last chunk.  The tile tests above have fewer
+    tiles than workgroups; here every workgroup walks several tiles (partial patches in y and x, several channel tiles, residual):
+    bitwise the quad kernel (323), the 48-channel patch tile (303) and its own one-workgroup-per-tile form (tuning bit 2), twice."""
+    B, H, W, cin, cout, use_res = shape
+    rng = np.random.default_rng(cin + cout + H)
+    x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32)
+    w = rng.normal(0, (2.0 / (cin * 9)) ** 0.5, (cout, cin, 3, 3)).astype(np.float16).astype(np.float32)
+    scale = rng.uniform(0.5, 2.0, cout).astype(np.float32)
+    b = rng.normal(0, 0.5, cout).astype(np.float32)
+    wr = rng.normal(0, (1.0 / cin) ** 0.5, (cout, cin, 1, 1)).astype(np.float32)
+    tiles = B * ((H + 7) // 8) * ((W + 15) // 16) * ((cout + 95) // 96)
+    assert tiles > 512, "the point of the test: more tiles than persistent workgroups"
+
+    def run():
+        g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2)
+        b0 = g.buf(0, cin)
+        res = None
+        if use_res:
+            b2 = g.buf(0, G.pad16(cout))
+            g.conv((b0, 0, cin), (b2, 0), wr, np.zeros(cout, np.float32), 1, 1, G.ACT_NONE)
+            res = (b2, 0)
+        b1 = g.buf(0, G.pad16(cout))
+        g.conv((b0, 0, cin), (b1, 0), w, b, 3, 1, G.ACT_SILU, res=res, out_scale=scale)
+        assert g.ops[-1]["flags"] & G.FLAG_W_SINGLE
+        g.head_buf = (b1, -1, -1)
+        m = E.Model(gpu_engine, g)
+        m.set_max_batch(B)
+        y = m.tracknet_infer(x)[..., :cout]
+        assert not m.take_overflow()
+        m.close()
+        return y
+
+    outs = {}
+    try:
+        for name, kw in (("303", dict(variant=303)), ("323", dict(variant=323)), ("324", dict(variant=324)), ("324 again", dict(variant=324)),
+                         ("324 one workgroup per tile", dict(variant=324, tune=5))):
+            gpu_engine.set_tuning(**{"tune": 1, **kw})
+            outs[name] = run()
+    finally:
+        gpu_engine.set_tuning(variant=-1, tune=1)
+    xt = torch.from_numpy(x).permute(0, 3, 1, 2).double()
+    want = F.silu(F.conv2d(xt, torch.from_numpy(w).double() * torch.from_numpy(scale).double()[:, None, None, None], torch.from_numpy(b).double(), padding=1))
+    if use_res:
+        want = want + F.conv2d(xt, torch.from_numpy(wr).double())
+    want = want.permute(0, 2, 3, 1).numpy()
+    ref = outs["303"]
+    assert float(np.abs(ref - want).max()) / max(1.0, float(np.abs(want).max())) < 3e-6
+    for name, y in outs.items():
+        assert np.array_equal(y, ref), f"{name} differs from the 48-channel patch tile (max {np.abs(y - ref).max():.3e}, {int((y != ref).sum())} values)"
