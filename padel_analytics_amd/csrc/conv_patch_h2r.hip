@@ -51,6 +51,7 @@ typedef int hr_i32x4 __attribute__((ext_vector_type(4)));
 // row's six products issued (its operands were in registers) / 4 last product issued
 constexpr int kRDbgSteps = 32;
 constexpr int kRDbgWords = 8 + 4 * kRDbgSteps * 5;
+constexpr int kRDbgTile = 3;                     // the tile of a persistent workgroup whose steps the ring keeps
 
 }  // namespace
 
@@ -85,6 +86,10 @@ __device__ __forceinline__ HrTile hr_tile(const ConvArgs& a, int v, int vmax) {
 // non-persistent form requested zeros to keep its counted waits static) and lands during the last chunk and the epilogue; chunk 1
 // follows at the next tile's start behind its first weights — the request order a fresh workgroup's prologue has, so every
 // counted wait is the same in every chunk of every tile.
+// Measured on top and NOT kept (profiles/r6*): a priority ladder over the rows of a tap (-2 .. 0 %); half a tile of sleep for the
+// workgroup in the CU's odd thread-group slot — the tile log of the probe build shows the two workgroups of a CU are not in phase
+// anyway (the older one gets the pipe first: 64.5 k vs 83 k ticks per tile, epilogues 0.9 beside the partner's main loop), no
+// change; `nt` on the patch requests (-6 .. -8 %), `sc0` on the weight loads (0).
 template <int NF, int NBUF, bool DBG = false, int ABL = 0, int PRIO = 0>
 __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, const int vmax) {
     constexpr int MF = 4;
@@ -96,9 +101,9 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
     __shared__ __attribute__((aligned(16))) float lds[(PATCH_B + PVO_B + DBG_B) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
     unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(ldsb + PATCH_B + PVO_B);
-    unsigned long long t_begin = 0;
-    int dbg_k = 0;
-    (void)stamps; (void)t_begin; (void)dbg_k;
+    unsigned long long t_begin = 0, t_end_rec = 0;
+    int dbg_k = 0, dbg_tile = 0;
+    (void)stamps; (void)t_begin; (void)t_end_rec; (void)dbg_k; (void)dbg_tile;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,11 +116,11 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
 #define PADEL_HR_PRIO(N_) do { if constexpr (PRIO == 1) __builtin_amdgcn_s_setprio(N_); } while (0)
 #define PADEL_HR_STAMP(J, slot)                                                                                   \
     do {                                                                                                          \
-        if constexpr (DBG) {                                                                                      \
+        if constexpr (DBG) {                               /* the ring records ONE tile in the middle of the launch (the fourth) */ \
             const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                           \
             const int real_ = (wave * kRDbgSteps + ((dbg_k + (J)) & (kRDbgSteps - 1))) * 5 + (slot);              \
             const int dummy_ = 4 * kRDbgSteps * 5 + wave * 64 + lane;                                             \
-            stamps[lane == 0 ? real_ : dummy_] = t_;                                                              \
+            stamps[(lane == 0 && dbg_tile == kRDbgTile) ? real_ : dummy_] = t_;                                   \
         }                                                                                                         \
     } while (0)
     const int wr = wave & 1, wc = wave >> 1;      // pixel half (rows 4 wr ..), channel half (fragments 3 wc ..)
@@ -125,7 +130,6 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
     int v = (int)blockIdx.x;
     HrTile cur = hr_tile(a, v, vmax);
     if (!cur.valid) return;
-
     // ---- the patch: span s of a plane = 16 pixels x 64 bytes, lane i -> pixel 16 s + i / 4, physical 16-byte slot i & 3 =
     // logical chunk q of that pixel (hr_off), which is piece (q & 1) of group (q >> 1) of the pixel's 128 bytes [h0 m0 h1 m1]
     // in HBM; the plane's 32 bytes go in through the scalar offset.  Wave w requests spans 3 w .. 3 w + 2 of both planes.
@@ -321,7 +325,13 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
     PADEL_HR_PARAMS(cur, rsrcPn, 0);
     PADEL_HR_PATCH(0, 0, rsrcPn, 0);
     for (;;) {                                    // ---- tiles
-        if constexpr (DBG) { t_begin = __builtin_amdgcn_s_memtime(); dbg_k = 0; }
+        if constexpr (DBG) {
+            const unsigned long long tb_ = __builtin_amdgcn_s_memtime(); dbg_k = 0;
+            if (dbg_tile <= kRDbgTile) t_begin = tb_;
+            if (dbg_tile == kRDbgTile + 1) t_end_rec = tb_;
+            // the tile log (records gridDim.x + blockIdx.x of the dump, behind the per-workgroup records): tile start / epilogue start
+            if (a.dbg && tid == 0 && dbg_tile < kRDbgWords / 2) a.dbg[((long long)G + blockIdx.x) * kRDbgWords + 2 * dbg_tile] = tb_;
+        }
         // this tile's patch parameters are the ones the previous tile computed as "next"
         rsrcP = rsrcPn;
 #pragma unroll
@@ -361,7 +371,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         for (int c = 0; c < nch; ++c) {
             const bool own8 = c + 2 < nch;
             i32x4 rs8 = own8 ? rsrcP : rsrcPn;
-            if (c + 1 >= nch) rs8[2] = 0;
+            if (c + 1 >= nch || (ABL & 2048)) rs8[2] = 0;      // (probe 2048: every tap-8 request through the zero-record descriptor)
             const unsigned so8 = own8 ? (unsigned)(c + 2) * 128u : 0u;
             const int set8 = own8 ? tpar : tpar ^ 1;
             PADEL_HR_STEP(0); PADEL_HR_STEP(1); PADEL_HR_STEP(2); PADEL_HR_STEP(3); PADEL_HR_STEP(4);
@@ -377,6 +387,10 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         PADEL_HR_FLUSH(1);
         if constexpr ((ABL & 32) != 0) { PADEL_HR_FLUSH(0); PADEL_HR_FLUSH(2); PADEL_HR_FLUSH(3); }      // (probe: one main chain, flushed once)
 
+        if constexpr (DBG) {
+            if (a.dbg && tid == 0 && dbg_tile < kRDbgWords / 2) a.dbg[((long long)G + blockIdx.x) * kRDbgWords + 2 * dbg_tile + 1] = __builtin_amdgcn_s_memtime();
+            ++dbg_tile;
+        }
         int mpix[MF];
 #pragma unroll
         for (int f = 0; f < MF; ++f) {
@@ -406,7 +420,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
 #undef PADEL_HR_FLUSH
     if constexpr (DBG) {
         if (a.dbg) {
-            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            const unsigned long long t_end = t_end_rec ? t_end_rec : __builtin_amdgcn_s_memtime();      // the recorded tile's end = the next tile's start
             __syncthreads();
             unsigned long long* d = a.dbg + (long long)blockIdx.x * kRDbgWords;
             for (int i = tid; i < 4 * kRDbgSteps * 5; i += 256) d[8 + i] = stamps[i];
@@ -466,8 +480,8 @@ hipError_t launch_conv_h2r(const ConvArgs& a_in, hipStream_t s) {
         return hipGetLastError();
     }
 #define PADEL_HR_ABL(N_) case N_: hipLaunchKernelGGL((conv_h2r_kernel<3, 2, false, N_>), grid, dim3(256), 0, s, a, vmax); return hipGetLastError();
-    switch (a.tune & ~15) {
-        PADEL_HR_ABL(16) PADEL_HR_ABL(240) PADEL_HR_ABL(1008)
+    switch ((a.tune >> 5) << 4) {      // tuning word bits 5.. = ABL >> 4
+        PADEL_HR_ABL(16) PADEL_HR_ABL(240) PADEL_HR_ABL(1008) PADEL_HR_ABL(2048)
         default: break;
     }
 #undef PADEL_HR_ABL

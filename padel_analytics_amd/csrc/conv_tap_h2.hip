@@ -300,7 +300,19 @@ int choose_conv_h2_variant(const ConvArgs& a) {
             const long long blocks = patches * ntiles;
             const long long per_cu = (blocks + 255) / 256;
             const float sc = 1.21f * fill * (float)blocks / (256.f * (float)per_cu);
-            if (sc > best) { best = sc; bv = a.w_single ? 324 : 323; }
+            if (sc > best) { best = sc; bv = 323; }
+        }
+        // two-product layers (PA_CONV_W_SINGLE) with at least two 32-channel chunks: the register-weights form of the quad tile
+        // (conv_patch_h2r.hip, round 6: weights global -> VGPR, one barrier per chunk, 2 persistent workgroups per CU) measured
+        // 1.15-1.18 x the quad kernel (96 -> 96: 440 -> 505, 192 -> 192: 520 -> 615 TFLOP/s; profiles/r6_sweep_h2r.txt) — fast enough to
+        // take channel counts that leave its last 96-channel tile part empty (192 -> 256: 553 vs 473 on the 64-channel tile)
+        if (conv_h2r_supported(a)) {
+            const int ntiles = (n16 + 5) / 6;
+            const float fill = (float)n16 / (float)(ntiles * 6) * (float)M / (float)(patches * 128);
+            // (no round-quantisation term: the persistent workgroups start their next tile's loads under the current tile, and
+            //  a 2.25-tiles-per-workgroup launch — the players graph's 192 -> 192 at 24 x 40 — still measured 461 vs 377 TFLOP/s)
+            const float sc = 1.40f * fill;
+            if (sc > best) { best = sc; bv = 324; }
         }
         // few input channels (16 / 32 / 48: 5-14 k-steps): the wide patch kernel keeps the whole K extent of a 16 x 16 pixel
         // tile in LDS (conv_patch_h2w.hip; measured against the 8 x 16 tiles in profiles/r3_sweep_h2w.txt)

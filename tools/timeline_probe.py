@@ -21,7 +21,7 @@ sys.path.insert(0, str(ROOT))
 STEPS, WORDS = 64, 8 + 4 * 64 * 5
 
 
-def run_conv(dump, kernel="lds", B=64, H=48, W=80, cin=192, cout=192):
+def run_conv(dump, kernel="lds", B=64, H=48, W=80, cin=192, cout=192, tune=1):
     w16 = kernel == "h2r"
     if kernel == "h2r":
         kernel = "h2q"
@@ -31,7 +31,7 @@ def run_conv(dump, kernel="lds", B=64, H=48, W=80, cin=192, cout=192):
     eng = E.default_engine(0)
     eng.set_profiling(True)
     h2 = kernel == "h2q"
-    eng.set_tuning(impl=0, variant=(324 if w16 else 323) if h2 else 7, timeline=1)
+    eng.set_tuning(impl=0, variant=(324 if w16 else 323) if h2 else 7, timeline=1, tune=tune)
     eng.lib.pa_engine_set_timeline_path(eng.handle, dump.encode())
     rng = np.random.default_rng(0)
     g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2 if h2 else G.DTYPE_F32)
@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--cin", type=int, default=192)
     ap.add_argument("--cout", type=int, default=192)
     ap.add_argument("--hw", default="48x80")
+    ap.add_argument("--tune", type=int, default=1, help="tuning word of the launch (h2r: 9 = no phase offset)")
     a = ap.parse_args()
     global STEPS, WORDS
     h2r = a.kernel == "h2r"
@@ -73,10 +74,15 @@ def main():
     if h2q:
         STEPS, WORDS = 32, 8 + 4 * 32 * 5            # conv_patch_h2q.hip:kQDbgSteps
     H_, W_ = (int(v) for v in a.hw.split("x"))
-    ms = run_conv(a.dump, a.kernel, H=H_, W=W_, cin=a.cin, cout=a.cout)
+    ms = run_conv(a.dump, a.kernel, H=H_, W=W_, cin=a.cin, cout=a.cout, tune=a.tune)
     raw = np.fromfile(a.dump, dtype=np.uint64)
     nblk = raw.size // WORDS
     raw = raw[: nblk * WORDS].reshape(nblk, WORDS)
+    tile_log = None
+    if h2r:                                             # persistent workgroups: records [G, 2G) hold the tile log (tile start, epilogue start)
+        G = min(512, nblk // 2)                         # 2 workgroups per CU (launch_conv_h2r)
+        tile_log = raw[G:2 * G].astype(np.int64)
+        raw = raw[:G]
     raw = raw[raw[:, 5] != 0]                           # grid padding: workgroups that returned at once wrote nothing
     nblk = raw.shape[0]
     hdr = raw[:, :8]
@@ -202,6 +208,43 @@ def main():
                      if a.kernel in ("tap", "h2q", "h2r") else
                      "l = prefetch issue + ds_read wait, M = MFMA burst being issued, w = vmcnt wait, b = ds_write + barrier")
       + f"; 1 column = {res} ticks")
+    if tile_log is not None:
+        # phase relation of the two workgroups of a CU over the launch: tile starts (S) and epilogue starts (E) of both, relative to the first
+        P("\nphase of the two workgroups of some CUs (ticks since the launch's first stamp; S tile start, E epilogue start):")
+        t00 = tile_log[tile_log > 0].min()
+        shown = 0
+        for kk in uniq:
+            bl = np.where(key == kk)[0]
+            if len(bl) != 2 or shown >= 4:
+                continue
+            shown += 1
+            for b in bl:
+                bid_ = int(hdr[b, 7])
+                row = tile_log[bid_]
+                row = row[row > 0] - t00
+                P(f"  CU {int(kk):4d} wg {bid_:4d} tg {(int(hdr[b, 0]) >> 16) & 15}: " + " ".join(f"{'S' if i % 2 == 0 else 'E'}{v}" for i, v in enumerate(row[:20])))
+        # overlap statistic: fraction of each workgroup's epilogue+prologue span (E_i .. S_{i+1} + first tap) that falls inside the partner's main loops
+        tot = ov = 0
+        for kk in uniq:
+            bl = np.where(key == kk)[0]
+            if len(bl) != 2:
+                continue
+            logs = []
+            for b in bl:
+                row = tile_log[int(hdr[b, 7])]
+                row = row[row > 0]
+                logs.append(row)
+            for me, other in ((0, 1), (1, 0)):
+                a_, o_ = logs[me], logs[other]
+                nt_ = len(a_) // 2
+                for i in range(nt_ - 1):
+                    e0, s1 = a_[2 * i + 1], a_[2 * i + 2]             # my epilogue .. my next tile start
+                    tot += s1 - e0
+                    for j in range(len(o_) // 2):
+                        m0, m1 = o_[2 * j], o_[2 * j + 1]              # partner's tile start .. its epilogue start (~ its main loop)
+                        ov += max(0, min(s1, m1) - max(e0, m0))
+        if tot:
+            P(f"  epilogue spans that ran beside the partner's main loop: {ov / tot:.2f} of their time (0 = in phase, 1 = anti-phase)")
     # compact copy of 16 CUs for offline analysis
     keep = np.where(np.isin(key, uniq[:16]))[0]
     np.savez_compressed(str(Path(a.out).with_suffix(".npz")), hdr=hdr[keep], st=(st[keep] - tb[keep, None, None, None]).astype(np.int32),
