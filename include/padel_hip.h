@@ -30,7 +30,7 @@ extern "C" {
 typedef struct pa_engine pa_engine;
 typedef struct pa_model pa_model;
 
-#define PA_ABI_VERSION 4
+#define PA_ABI_VERSION 5
 
 /* ---- graph description (built on the host from a state_dict; see padel_analytics_amd/graph.py) ---- */
 
@@ -262,6 +262,15 @@ int pa_engine_bcast_weights_from(pa_engine* eng, pa_model* src, pa_model* dst, i
 int pa_engine_bcast(pa_engine* eng, void* dev_ptr, size_t nbytes, int root);
 /* max over ranks of one double (bench: step time of the slowest rank) */
 int pa_engine_allreduce_max(pa_engine* eng, double* value);
+/* ABI v5 (round 6) — the sharded runner's result gather on the communicator the library owns, instead of torch.distributed
+ * (trackers/runner.py has no counterpart: the reference runs one process).  Every rank contributes `nbytes` bytes of HOST memory
+ * (its packed partial results; lengths differ per rank, 0 allowed).  Two calls, two collectives, no padding to the longest rank:
+ * pa_engine_gather_sizes — ncclAllGather of the lengths: sizes[r] = rank r's nbytes, on every rank;
+ * pa_engine_gather       — one ncclSend per rank / nranks - 1 ncclRecv on the root inside a group: on `root`, `recv` (capacity
+ *                          recv_cap >= sum of sizes) receives the buffers back to back in rank order; other ranks pass recv = NULL.
+ * `sizes` of the second call are the first call's.  nranks == 1 (or no communicator): host copies.                          */
+int pa_engine_gather_sizes(pa_engine* eng, size_t nbytes, uint64_t* sizes);
+int pa_engine_gather(pa_engine* eng, const void* send, size_t nbytes, void* recv, size_t recv_cap, const uint64_t* sizes, int root);
 
 /* ---- host-native ByteTrack: `self.byte_track.update_with_detections(detections)`,
  * trackers/players_tracker/players_tracker.py:367-369 (constructed at :311 with frame_rate = fps; supervision

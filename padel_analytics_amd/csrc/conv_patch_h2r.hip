@@ -449,6 +449,21 @@ __global__ void __launch_bounds__(256) h2r_repack_kernel(const char* __restrict_
     *reinterpret_cast<h2_u32x4*>(wr + i * 16) = v;
 }
 
+// PA_CONV_W_SINGLE is a promise of the CALLER's (public C-ABI): the m plane of the packed weights is all zero.  Checked once per
+// model on the device: any non-zero m bit of the conv's rows x k-steps raises *flag
+__global__ void __launch_bounds__(256) h2_mplane_check_kernel(const unsigned* __restrict__ w, long long n_steps, unsigned* flag) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;          // one thread per 16 bytes of an m half (64 B = 4 threads)
+    if (i >= n_steps * 4) return;
+    const h2_u32x4 v = *reinterpret_cast<const h2_u32x4*>(w + (i >> 2) * 32 + 16 + (i & 3) * 4);
+    if (((v[0] | v[1] | v[2] | v[3]) & 0x7FFF7FFFu) != 0u) atomicOr(flag, 1u);
+}
+
+hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsigned* flag, hipStream_t s) {
+    hipLaunchKernelGGL(h2_mplane_check_kernel, dim3((unsigned)((rows_x_ksteps * 4 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const unsigned*>(w), rows_x_ksteps, flag);
+    return hipGetLastError();
+}
+
 size_t conv_h2r_copy_bytes(int n16, int cin) { return (size_t)n16 * (size_t)((cin >> 5) * 9) * 1024; }
 
 hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s) {

@@ -162,7 +162,10 @@ int pa_engine_create(int device_id, pa_engine** out) {
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "zero page: %s", hipGetErrorString(r)); }
     r = padel::init_misc_kernels();
     if (r != hipSuccess) { delete e; PA_FAIL((pa_engine*)nullptr, "kernel attributes: %s", hipGetErrorString(r)); }
-    if (const char* v = getenv("PADEL_CONV_IMPL")) e->t.impl = (v[0] == 'b') ? 2 : 0;   // tap | bx3
+    if (const char* v = getenv("PADEL_CONV_IMPL")) {       // tap | bx3 ("lds", the kernel retired in round 5, is refused — it used to select tap silently)
+        if (v[0] == 'l') { delete e; PA_FAIL((pa_engine*)nullptr, "PADEL_CONV_IMPL=%s: the LDS kernel was retired in round 5; tap or bx3", v); }
+        e->t.impl = (v[0] == 'b') ? 2 : 0;
+    }
     e->t.variant = env_int("PADEL_CONV_VARIANT", -1);
     e->t.tune = env_int("PADEL_CONV_TUNE", 1);
     e->t.tap_pd = env_int("PADEL_CONV_TAP_PD", 2) == 3 ? 3 : 2;
@@ -178,7 +181,10 @@ int pa_engine_create(int device_id, pa_engine** out) {
 int pa_engine_set_tuning(pa_engine* e, const char* key, int value) {
     if (!e || !key) return 1;
     const std::string k = key;
-    if (k == "impl") e->t.impl = (value == 0) ? 0 : 2;      // 0: fp32-input MFMA tap kernels, 2: bf16x3 (1 was the LDS kernel: tools/legacy_conv)
+    if (k == "impl") {                                      // 0: fp32-input MFMA tap kernels, 2: bf16x3
+        if (value != 0 && value != 2) PA_FAIL(e, "tuning impl = %d: 0 (fp32-input MFMA tap kernels) or 2 (bf16x3); 1 was the LDS kernel, retired in round 5 (tools/legacy_conv)", value);
+        e->t.impl = value;
+    }
     else if (k == "variant") e->t.variant = value;
     else if (k == "tune") e->t.tune = value;
     else if (k == "tap_pd") e->t.tap_pd = (value == 3) ? 3 : 2;
@@ -862,6 +868,26 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
 static int ensure_operand_copies(pa_model* m) {
     if (m->wr_valid || m->d.dtype != PA_DTYPE_H2) return 0;
     pa_engine* e = m->e;
+    // PA_CONV_W_SINGLE is the caller's promise that a conv's packed m plane is all zero; the two-product kernels skip the wm x ah
+    // product on the strength of it.  Checked against the blob once per model (and again after a weight broadcast): a conv whose
+    // promise does not hold fails the call instead of computing silently wrong results
+    {
+        bool any = false;
+        PA_HIP(e, hipMemsetAsync(m->d_ovf + 32, 0, sizeof(unsigned) * 8, e->stream));        // scratch words of the 256-byte flag block
+        for (size_t i = 0; i < m->ops.size(); ++i) {
+            const pa_op_desc& o = m->ops[i];
+            if (o.kind != PA_OP_CONV || !(o.flags & PA_CONV_W_SINGLE)) continue;
+            const long long ksteps = o.ksize == 3 ? (long long)(o.cin / 32) * 9 + ((o.cin & 16) ? 5 : 0) : (long long)(o.cin + 31) / 32 * o.ksize * o.ksize;
+            PA_HIP(e, launch_h2_mplane_check(m->d_w + o.w_off, (long long)o.npad * ksteps, m->d_ovf + 32, e->stream));
+            any = true;
+        }
+        if (any) {
+            unsigned bad = 0;
+            PA_HIP(e, hipMemcpyAsync(&bad, m->d_ovf + 32, sizeof(bad), hipMemcpyDeviceToHost, e->stream));
+            PA_HIP(e, hipStreamSynchronize(e->stream));
+            if (bad) PA_FAIL(e, "a conv flagged PA_CONV_W_SINGLE has a non-zero m plane in the weight blob (pack it without the flag, or with fp16-number weights)");
+        }
+    }
     if (m->wr_off.empty()) {
         m->wr_off.assign(m->ops.size(), -1);
         size_t total = 0;
@@ -1578,6 +1604,11 @@ struct pa_comm {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -1614,7 +1645,13 @@ int pa_engine_comm_init(pa_engine* e, const void* unique_id, size_t id_bytes, in
     c->Broadcast = (decltype(c->Broadcast))dlsym(lib, "ncclBroadcast");
     c->AllReduce = (decltype(c->AllReduce))dlsym(lib, "ncclAllReduce");
     c->GetErrorString = (decltype(c->GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!c->CommInitRank || !c->CommDestroy || !c->Broadcast || !c->AllReduce || !c->GetErrorString) {
+    c->AllGather = (decltype(c->AllGather))dlsym(lib, "ncclAllGather");
+    c->Send = (decltype(c->Send))dlsym(lib, "ncclSend");
+    c->Recv = (decltype(c->Recv))dlsym(lib, "ncclRecv");
+    c->GroupStart = (decltype(c->GroupStart))dlsym(lib, "ncclGroupStart");
+    c->GroupEnd = (decltype(c->GroupEnd))dlsym(lib, "ncclGroupEnd");
+    if (!c->CommInitRank || !c->CommDestroy || !c->Broadcast || !c->AllReduce || !c->GetErrorString || !c->AllGather || !c->Send || !c->Recv ||
+        !c->GroupStart || !c->GroupEnd) {
         delete c;
         PA_FAIL(e, "librccl: missing symbols");
     }
@@ -1672,6 +1709,88 @@ int pa_engine_bcast_weights_from(pa_engine* e, pa_model* src, pa_model* dst, int
     const ncclResult_t r = e->comm->Broadcast(send, dst->d_w, dst->n_w * sizeof(float), ncclUint8, root, e->comm->comm, e->stream);
     if (r != ncclSuccess) PA_FAIL(e, "ncclBroadcast: %s", e->comm->GetErrorString(r));
     PA_HIP(e, hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+// The sharded runner's gather (include/padel_hip.h, ABI v5): variable-length host buffers of every rank to the root, over the
+// communicator the library owns.  Lengths by ncclAllGather (pa_engine_gather_sizes), payload by one ncclSend per rank and
+// nranks - 1 ncclRecv on the root inside one group (the root's own part is a host copy); device staging buffers live for the call.
+int pa_engine_gather_sizes(pa_engine* e, size_t nbytes, uint64_t* sizes) {
+    if (!e || !sizes) PA_FAIL(e, "pa_engine_gather_sizes: NULL argument");
+    const int nranks = e->comm ? e->comm->nranks : 1;
+    if (nranks == 1) { sizes[0] = nbytes; return 0; }
+    PA_HIP(e, hipSetDevice(e->dev));
+    pa_comm* c = e->comm;
+    unsigned long long* d_sizes = nullptr;
+    PA_HIP(e, hipMalloc((void**)&d_sizes, (size_t)(nranks + 1) * sizeof(unsigned long long)));
+    const unsigned long long mine = nbytes;
+    hipError_t h = hipMemcpyAsync(d_sizes + nranks, &mine, sizeof(mine), hipMemcpyHostToDevice, e->stream);
+    ncclResult_t r = ncclSuccess;
+    if (h == hipSuccess) r = c->AllGather(d_sizes + nranks, d_sizes, 1, ncclUint64, c->comm, e->stream);
+    std::vector<unsigned long long> hs((size_t)nranks);
+    if (h == hipSuccess && r == ncclSuccess) h = hipMemcpyAsync(hs.data(), d_sizes, (size_t)nranks * sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream);
+    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    hipFree(d_sizes);
+    if (r != ncclSuccess) PA_FAIL(e, "ncclAllGather: %s", c->GetErrorString(r));
+    if (h != hipSuccess) PA_FAIL(e, "pa_engine_gather_sizes: %s", hipGetErrorString(h));
+    for (int k = 0; k < nranks; ++k) sizes[k] = hs[(size_t)k];
+    return 0;
+}
+
+int pa_engine_gather(pa_engine* e, const void* send, size_t nbytes, void* recv, size_t recv_cap, const uint64_t* sizes, int root) {
+    if (!e || !sizes || (nbytes && !send)) PA_FAIL(e, "pa_engine_gather: NULL argument");
+    const int nranks = e->comm ? e->comm->nranks : 1, me = e->comm ? e->comm->rank : 0;
+    if (root < 0 || root >= nranks) PA_FAIL(e, "pa_engine_gather: root %d of %d", root, nranks);
+    if (sizes[me] != nbytes) PA_FAIL(e, "pa_engine_gather: sizes[%d] = %llu, nbytes = %zu", me, (unsigned long long)sizes[me], nbytes);
+    size_t total = 0;
+    for (int k = 0; k < nranks; ++k) total += (size_t)sizes[k];
+    // the capacity check comes BEFORE the exchange and depends only on what every rank knows: a root that bails out alone would
+    // leave the others inside their sends
+    if (me == root && (recv_cap < total || (total && !recv))) PA_FAIL(e, "pa_engine_gather: recv capacity %zu < %zu", recv_cap, total);
+    if (nranks == 1) {
+        if (nbytes) memcpy(recv, send, nbytes);
+        return 0;
+    }
+    PA_HIP(e, hipSetDevice(e->dev));
+    pa_comm* c = e->comm;
+    char* d_send = nullptr;
+    char* d_recv = nullptr;
+    hipError_t h = hipSuccess;
+    ncclResult_t r = ncclSuccess;
+    if (me != root && nbytes) {
+        h = hipMalloc((void**)&d_send, nbytes);
+        if (h == hipSuccess) h = hipMemcpyAsync(d_send, send, nbytes, hipMemcpyHostToDevice, e->stream);
+    }
+    if (me == root && total) h = hipMalloc((void**)&d_recv, total);
+    // (an allocation failure still enters the group with nothing posted: the peers' sends then fail inside RCCL instead of hanging)
+    r = c->GroupStart();
+    if (h == hipSuccess && r == ncclSuccess) {
+        if (me == root) {
+            size_t off = 0;
+            for (int k = 0; k < nranks && r == ncclSuccess; ++k) {
+                if (k != root && sizes[k]) r = c->Recv(d_recv + off, (size_t)sizes[k], ncclUint8, k, c->comm, e->stream);
+                off += (size_t)sizes[k];
+            }
+        } else if (nbytes) {
+            r = c->Send(d_send, nbytes, ncclUint8, root, c->comm, e->stream);
+        }
+    }
+    const ncclResult_t r2 = c->GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (h == hipSuccess && r == ncclSuccess && me == root) {
+        size_t off = 0;
+        for (int k = 0; k < nranks && h == hipSuccess; ++k) {
+            const size_t nb = (size_t)sizes[k];
+            if (k == root) { if (nb) memcpy((char*)recv + off, send, nb); }
+            else if (nb) h = hipMemcpyAsync((char*)recv + off, d_recv + off, nb, hipMemcpyDeviceToHost, e->stream);
+            off += nb;
+        }
+    }
+    if (h == hipSuccess) h = hipStreamSynchronize(e->stream);
+    if (d_send) hipFree(d_send);
+    if (d_recv) hipFree(d_recv);
+    if (r != ncclSuccess) PA_FAIL(e, "ncclSend/Recv: %s", c->GetErrorString(r));
+    if (h != hipSuccess) PA_FAIL(e, "pa_engine_gather: %s", hipGetErrorString(h));
     return 0;
 }
 

@@ -87,6 +87,8 @@ bool conv_h2r_supported(const ConvArgs& a);            // conv_patch_h2r.hip (ro
 hipError_t launch_conv_h2r(const ConvArgs& a, hipStream_t s);
 size_t conv_h2r_copy_bytes(int n16, int cin);          // bytes of the operand-order copy of one conv's h plane
 hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s);
+// *flag |= 1 when any m-plane bit of `rows_x_ksteps` packed 128-byte k-step records is set (the PA_CONV_W_SINGLE promise, checked once per model)
+hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsigned* flag, hipStream_t s);
 hipError_t launch_conv_h2_deep(const ConvArgs& a, int variant, hipStream_t s);     // conv_tap_h2p.hip: tap tiles with a 3-stage activation ring (239, 243); hipErrorNotSupported where they do not apply
 bool conv_h2w_supported(const ConvArgs& a);            // conv_patch_h2w.hip: stride-1 3x3 with 16 / 32 / 48 input channels
 hipError_t launch_conv_h2w(const ConvArgs& a, int nf, hipStream_t s);

@@ -38,7 +38,9 @@ __device__ __forceinline__ int fs_entry(int srow, int scol) { return (srow * 2 +
 }  // namespace
 
 // NF = c / 16 = stem channel fragments = layer-1 fragments per wave (layer 1 has 2c channels: 2 NF fragments per channel half pair)
-// WS: layer 1's packed weights have an all-zero m plane (ConvArgs::w_single): no wm x ah product, no m-plane requests / reads
+// WS: layer 1's packed weights have an all-zero m plane (ConvArgs::w_single): no wm x ah product and no m-plane operand reads.  (The
+// weight ring's requests still carry the all-zero plane — PADEL_FS_DMAB covers both planes of a k-step with one set of spans; the
+// zeros land in LDS and are never read.  ADVICE r5.)
 template <int NF, bool WS = false>
 __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, const ConvArgs a) {
     constexpr bool CHUNK = NF >= 2, TAIL = (NF & 1) != 0;

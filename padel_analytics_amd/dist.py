@@ -124,9 +124,29 @@ def _unpack_arrays(buf: np.ndarray) -> list:
     return out
 
 
+_comm_engine = None       # the Engine whose library-owned RCCL communicator carries the gathers (set by Engine.comm_init)
+
+
+def use_engine_comm(engine) -> None:
+    """Round 6: route ``gather_bytes`` (and with it gather_arrays / gather_results) through the communicator ``libpadel_hip.so`` owns
+    (``pa_engine_gather``: ncclAllGather of the lengths + ncclSend / ncclRecv, no padding) instead of torch.distributed.  Called by
+    ``Engine.comm_init`` for nranks > 1; ``None`` switches back (CPU tests: gloo)."""
+    global _comm_engine
+    _comm_engine = engine
+
+
 def gather_bytes(buf: np.ndarray, dst: int = 0) -> Optional[list]:
-    """One uint8 buffer per rank -> on `dst` the list of all ranks' buffers (rank order), None elsewhere.  Two collectives
-    whatever the content: an all-gather of the lengths and ONE gather of the buffers padded to the longest."""
+    """One uint8 buffer per rank -> on `dst` the list of all ranks' buffers (rank order), None elsewhere.  On the GPU box: the
+    library's own RCCL communicator (``use_engine_comm``).  Without one (the gloo CPU tests): torch.distributed."""
+    eng = _comm_engine
+    if eng is not None and getattr(eng, "nranks", 1) == world_size() and world_size() > 1:
+        return eng.gather_bytes(np.ascontiguousarray(buf, np.uint8).reshape(-1), dst)
+    return _gather_bytes_torch(buf, dst)
+
+
+def _gather_bytes_torch(buf: np.ndarray, dst: int = 0) -> Optional[list]:
+    """The torch.distributed form (gloo in the CPU tests): an all-gather of the lengths and ONE gather of the buffers padded to
+    the longest."""
     import torch
     import torch.distributed as dist
     world, me = dist.get_world_size(), dist.get_rank()

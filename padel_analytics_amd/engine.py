@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "pa_upload", "pa_engine_set_tuning", "pa_engine_set_timeline_path", "pa_model_plan_bytes",
     "pa_yolo_netin_shape", "pa_yolo_read_netin",
     "pa_comm_unique_id", "pa_engine_comm_init", "pa_engine_comm_destroy", "pa_engine_bcast_weights",
-    "pa_engine_bcast", "pa_engine_allreduce_max",
+    "pa_engine_bcast", "pa_engine_allreduce_max", "pa_engine_gather_sizes", "pa_engine_gather",
     "pa_bytetrack_create", "pa_bytetrack_destroy", "pa_bytetrack_reset", "pa_bytetrack_update_batch",
     "pa_model_take_overflow", "pa_yolo_postprocess", "pa_host_register", "pa_host_unregister",
     "pa_engine_bcast_weights_from", "pa_model_fill_arena", "pa_yolo_submit", "pa_yolo_wait",
@@ -151,6 +151,8 @@ def load_library():
     lib.pa_engine_bcast.argtypes = [vp, vp, sz, i32]
     lib.pa_engine_bcast_weights_from.argtypes = [vp, vp, vp, i32]
     lib.pa_engine_allreduce_max.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.pa_engine_gather_sizes.argtypes = [vp, sz, C.POINTER(C.c_uint64)]
+    lib.pa_engine_gather.argtypes = [vp, vp, sz, vp, sz, C.POINTER(C.c_uint64), i32]
     lib.pa_bytetrack_create.argtypes = [C.c_double, i32, C.c_double, i32, C.POINTER(vp)]
     lib.pa_bytetrack_destroy.argtypes = [vp]
     lib.pa_bytetrack_destroy.restype = None
@@ -162,7 +164,7 @@ def load_library():
     lib.pa_host_unregister.argtypes = [vp, vp]
     lib.pa_model_take_overflow.argtypes = [vp, C.POINTER(i32)]
     lib.pa_yolo_postprocess.argtypes = [vp, C.POINTER(vp), i32, i32, i32, C.POINTER(pa_yolo_params), vp, vp, vp]
-    if lib.pa_abi_version() != 4:
+    if lib.pa_abi_version() != 5:
         raise EngineUnavailable("libpadel_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -246,7 +248,7 @@ class Engine:
         self._check(self.lib.pa_host_unregister(self.handle, arr.ctypes.data))
 
     def set_tuning(self, **kv):
-        """Tests / tools only: impl (2 bx3, 0 tap, 1 lds), variant (tile id, -1 auto), tune, tap_pd, graph, alias, fold_up, timeline."""
+        """Tests / tools only: impl (2 bx3, 0 tap; 1 — the retired LDS kernel — is refused), variant (tile id, -1 auto), tune, tap_pd, graph, alias, fold_up, timeline."""
         for k, v in kv.items():
             self._check(self.lib.pa_engine_set_tuning(self.handle, k.encode(), int(v)))
             if k == "timeline":
@@ -257,6 +259,9 @@ class Engine:
         buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
         self._check(self.lib.pa_engine_comm_init(self.handle, buf, len(unique_id), nranks, rank))
         self.nranks, self.rank = nranks, rank
+        if nranks > 1:                     # the sharded runner's gathers travel over this communicator from now on (dist.gather_bytes)
+            from . import dist as _dist
+            _dist.use_engine_comm(self)
 
     def bcast_weights(self, model: "Model", root: int = 0):
         self._check(self.lib.pa_engine_bcast_weights(self.handle, model.handle, root))
@@ -268,6 +273,27 @@ class Engine:
     def bcast(self, buf: DeviceBuffer, nbytes: int, root: int = 0):
         self._check(self.lib.pa_engine_bcast(self.handle, buf.ptr, nbytes, root))
 
+    def gather_bytes(self, buf: np.ndarray, root: int = 0):
+        """Variable-length uint8 buffers of every rank -> on `root` the list of them in rank order (None elsewhere), over the
+        library's RCCL communicator (``pa_engine_gather_sizes`` + ``pa_engine_gather``: lengths by all-gather, payload by send /
+        recv, no padding; torch.distributed is not in this path)."""
+        buf = np.ascontiguousarray(buf, np.uint8).reshape(-1)
+        n = max(getattr(self, "nranks", 1), 1)
+        me = getattr(self, "rank", 0)
+        sizes = (C.c_uint64 * n)()
+        self._check(self.lib.pa_engine_gather_sizes(self.handle, int(buf.size), sizes))
+        total = int(sum(sizes))
+        recv = np.empty(max(total, 1), np.uint8) if me == root else None
+        self._check(self.lib.pa_engine_gather(self.handle, buf.ctypes.data if buf.size else None, int(buf.size),
+                                              recv.ctypes.data if recv is not None else None, total if recv is not None else 0, sizes, root))
+        if me != root:
+            return None
+        out, off = [], 0
+        for k in range(n):
+            out.append(recv[off:off + int(sizes[k])])
+            off += int(sizes[k])
+        return out
+
     def allreduce_max(self, value: float) -> float:
         v = C.c_double(value)
         self._check(self.lib.pa_engine_allreduce_max(self.handle, C.byref(v)))
@@ -275,6 +301,9 @@ class Engine:
 
     def close(self):
         if self.handle:
+            from . import dist as _dist
+            if _dist._comm_engine is self:
+                _dist.use_engine_comm(None)
             self.lib.pa_engine_destroy(self.handle)
             self.handle = None
 
@@ -324,7 +353,9 @@ class _PinnedBlock:
         # registered, unregistered and then handed to an unrelated array made a later pageable hipMemcpy from that array fault
         # on the GPU (round 5, tests/test_gpu_pipeline.py::test_close_with_a_ticket_in_flight_then_reuse_the_pages).  A private
         # mapping is page-aligned, zero-filled, and its addresses go back to the kernel — not to malloc — when the views die
-        self._mm = mmap.mmap(-1, size)
+        # MAP_PRIVATE | MAP_ANONYMOUS explicitly: Python's default for fileno -1 is MAP_SHARED — shmem-backed pages that a forked child
+        # (multiprocessing, the gloo test workers) would share with the parent's result arrays
+        self._mm = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, prot=mmap.PROT_READ | mmap.PROT_WRITE)
         self.block = np.frombuffer(self._mm, np.uint8)
         self.engine = engine
         engine.pin(self.block)

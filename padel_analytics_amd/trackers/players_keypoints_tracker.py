@@ -230,9 +230,30 @@ class PlayerKeypointsTracker(Tracker):
         return out
 
     def merge_partials(self, partials: list, **kwargs) -> list:
+        """Partials: ``predict_partial``'s (n + 1, 2 K) float64 arrays, or — after the wire — (float32 (n, 2 K) view, (rx, ry))."""
         K, _ = self.model.kpt_shape
-        return [PlayersKeypoints(xy=p[:-1].reshape(-1, K, 2).astype(np.float32), ratio=(float(p[-1, 0]), float(p[-1, 1])))
+        return [PlayersKeypoints(xy=p[0].reshape(-1, K, 2), ratio=p[1]) if isinstance(p, tuple) else
+                PlayersKeypoints(xy=p[:-1].reshape(-1, K, 2).astype(np.float32), ratio=(float(p[-1, 0]), float(p[-1, 1])))
                 for p in partials]
+
+    # on the wire (round 6): the keypoint coordinates are float32 VALUES carried in float64 rows (the ratio row needs doubles) — they
+    # travel as float32 (lossless: half the bytes of the default ragged pack, 1.9 MB instead of 3.8 MB per rank and 64-frame batch at
+    # the bench's 283 persons per frame), the ratio rows as one (frames, 2) float64 array beside them
+    def pack_partials(self, partials: list):
+        K, _ = self.model.kpt_shape
+        counts = np.array([len(p) - 1 for p in partials], np.int64)
+        rows = np.empty((int(counts.sum()), 2 * K), np.float32)
+        pos = 0
+        for p, c in zip(partials, counts):             # one conversion per frame straight into the send buffer
+            rows[pos:pos + c] = p[:-1]
+            pos += int(c)
+        ratios = np.array([p[-1, :2] for p in partials], np.float64).reshape(len(partials), 2)
+        return [counts, rows, ratios]
+
+    def unpack_partials(self, arrays: list) -> list:
+        counts, rows, ratios = arrays                  # views into the received buffer: no per-frame copies on rank 0
+        ends = np.cumsum(counts)
+        return [(rows[int(e) - int(c):int(e)], (float(ratios[i, 0]), float(ratios[i, 1]))) for i, (c, e) in enumerate(zip(counts, ends))]
 
     def predict_frames(self, frame_generator, **kwargs):
         raise NoPredictFrames()

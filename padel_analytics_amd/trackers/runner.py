@@ -72,32 +72,36 @@ class TrackingRunner:
     def run(self) -> None:
         print(f"runner: Running {self.total_frames} frames")
         self._merges = []                  # sharded mode, rank 0: sequential stages still running behind the next tracker's shard
-        if self.fanout:
-            self._run_fanout()
-        else:
-            for tracker in self.trackers.values():
-                # results (and the prediction caches) live on rank 0 only: its decision to skip a tracker is the one
-                # every rank follows, or the others would wait in the sharded path's collectives for ever
-                stored = D.broadcast_flag(len(tracker) != 0) if self.distributed else len(tracker) != 0
-                if stored:
-                    print(f"{tracker.__str__()}: {len(tracker)} predictions stored")
-                    continue
-                tracker.to(tracker.DEVICE)
-                print(f"{str(tracker)}: Running on {tracker.DEVICE} ...")
-                t0 = timeit.default_timer()
-                if self.distributed:
-                    self._predict_sharded(tracker)
-                else:
-                    self._predict(tracker)
-                t1 = timeit.default_timer()
-                tracker.to("cpu")
-                if self._merges and self._merges[-1][0] is tracker:
-                    self._merges[-1] += (t0,)          # reported (with the merge inside the time) when the merge is done
-                    continue
-                self._report(tracker, t0, t1)
-                if not self.distributed or D.rank() == 0:
-                    tracker.save_predictions()
-        self._join_merges()
+        try:
+            if self.fanout:
+                self._run_fanout()
+            else:
+                for tracker in self.trackers.values():
+                    # results (and the prediction caches) live on rank 0 only: its decision to skip a tracker is the one
+                    # every rank follows, or the others would wait in the sharded path's collectives for ever
+                    stored = D.broadcast_flag(len(tracker) != 0) if self.distributed else len(tracker) != 0
+                    if stored:
+                        print(f"{tracker.__str__()}: {len(tracker)} predictions stored")
+                        continue
+                    tracker.to(tracker.DEVICE)
+                    print(f"{str(tracker)}: Running on {tracker.DEVICE} ...")
+                    t0 = timeit.default_timer()
+                    if self.distributed:
+                        self._predict_sharded(tracker)
+                    else:
+                        self._predict(tracker)
+                    t1 = timeit.default_timer()
+                    tracker.to("cpu")
+                    if self._merges and self._merges[-1][0] is tracker:
+                        self._merges[-1] += (t0, t1)      # reported when the merge is done: shard time and the merge's own span apart
+                        continue
+                    self._report(tracker, t0, t1)
+                    if not self.distributed or D.rank() == 0:
+                        tracker.save_predictions()
+        finally:
+            #  a tracker that raises must not leave finished merges unsaved or the worker pool alive; a merge's own
+            # exception surfaces here, after the merges before it were saved
+            self._join_merges()
         self.draw_and_collect_data()
 
     def _predict(self, tracker: Tracker) -> None:
@@ -164,10 +168,11 @@ class TrackingRunner:
         if rank == 0:
             def merge():
                 from .tracker import relaxed_gc
+                ts = timeit.default_timer()
                 with relaxed_gc():
                     tracker.results.predictions = tracker.merge_partials(allp)
                 print(f"{tracker.__str__()}: {len(tracker.results)} predictions.")
-                return timeit.default_timer()
+                return ts, timeit.default_timer()
             # The sequential stage (ByteTrack ids over ALL frames in global order: ~60 us per frame of host C++) is rank 0's
             # alone.  Where it touches no GPU it runs on a worker thread while rank 0's GPU starts on the next tracker's shard —
             # otherwise the other ranks would wait for it at the next gather; run() joins before it returns
@@ -180,14 +185,31 @@ class TrackingRunner:
                 merge()
 
     def _join_merges(self) -> None:
-        for tracker, fut, t0 in getattr(self, "_merges", []):
-            t1 = fut.result()
-            self._report(tracker, t0, t1)
-            tracker.save_predictions()
-        self._merges = []
+        """Collect rank 0's deferred sequential stages.  ``timings``: "seconds" is the tracker's own shard (device stage + gather),
+        "merge_seconds" the merge's own span, which ran BESIDE the next tracker's shard ("merge_overlapped") — the two are not
+        added: the next tracker's "seconds" already covers that wall time (no double counting)."""
+        merges, self._merges = getattr(self, "_merges", []), []
         pool, self._merge_pool = getattr(self, "_merge_pool", None), None
-        if pool is not None:
-            pool.shutdown()
+        first_error = None
+        try:
+            for item in merges:
+                tracker, fut = item[0], item[1]
+                try:
+                    ts, te = fut.result()
+                except BaseException as exc:       # keep collecting: the merges behind this one are finished work
+                    first_error = first_error or exc
+                    continue
+                if len(item) >= 4:
+                    self._report(tracker, item[2], item[3])
+                    self.timings[str(tracker)].update(merge_seconds=te - ts, merge_overlapped=True)
+                else:                               # the tracker loop was left before its bookkeeping: report the merge alone
+                    self._report(tracker, ts, te)
+                tracker.save_predictions()
+        finally:
+            if pool is not None:
+                pool.shutdown()
+        if first_error is not None:
+            raise first_error
 
     def _share_background(self, tracker) -> None:
         """TrackNet's background median (iterable.py:59-81) is a property of the clip's first frames: rank 0

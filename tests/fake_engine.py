@@ -55,7 +55,17 @@ class FakeEngine:
     def comm_init(self, unique_id, nranks, rank):
         assert isinstance(unique_id, (bytes, bytearray)) and len(unique_id) == 128
         self.comm = (bytes(unique_id), nranks, rank)
+        self.nranks, self.rank = nranks, rank
         LOG.append(f"comm_init nranks={nranks} rank={rank}")
+        if nranks > 1:                     # like Engine.comm_init: the runner's gathers go through the engine's communicator
+            from padel_analytics_amd import dist as D
+            D.use_engine_comm(self)
+
+    def gather_bytes(self, buf, root=0):
+        """Stands in for pa_engine_gather (RCCL on the GPU box): same contract, carried by gloo here."""
+        from padel_analytics_amd import dist as D
+        LOG.append(f"gather_bytes via the engine's communicator: {int(np.asarray(buf).size)} bytes")
+        return D._gather_bytes_torch(buf, root)
 
     def bcast_weights(self, model, root=0):
         """The one-time weight broadcast (pa_engine_bcast_weights): rank `root`'s blob reaches every rank's model."""

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} missing from libpadel_hip.so"
     assert sorted(E.ABI_SYMBOLS) == names
     lib.pa_abi_version.restype = ctypes.c_int
-    assert lib.pa_abi_version() == 4
+    assert lib.pa_abi_version() == 5
 
 
 def test_no_gpu_fails_loudly():

@@ -500,3 +500,33 @@ def test_h2r_persistent_workgroups_walk_many_tiles(gpu_engine, shape):
     assert float(np.abs(ref - want).max()) / max(1.0, float(np.abs(want).max())) < 3e-6
     for name, y in outs.items():
         assert np.array_equal(y, ref), f"{name} differs from the 48-channel patch tile (max {np.abs(y - ref).max():.3e}, {int((y != ref).sum())} values)"
+
+
+def test_w_single_promise_is_checked_against_the_blob(gpu_engine):
+    """PA_CONV_W_SINGLE is the caller's promise (public C-ABI) that a conv's packed m plane is all zero.  A blob that
+    breaks it must fail the call — the two-product kernels would otherwise skip a non-zero product silently."""
+    cin, cout = 64, 96
+    rng = np.random.default_rng(5)
+    w = rng.normal(0, 0.05, (cout, cin, 3, 3)).astype(np.float32)                 # not fp16 numbers: the m plane is populated
+    g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2)
+    b0, b1 = g.buf(0, cin), g.buf(0, cout)
+    g.conv((b0, 0, cin), (b1, 0), w, np.zeros(cout, np.float32), 3, 1, G.ACT_SILU)
+    g.head_buf = (b1, -1, -1)
+    assert not (g.ops[-1]["flags"] & G.FLAG_W_SINGLE)
+    g.ops[-1]["flags"] |= G.FLAG_W_SINGLE                                          # the lie
+    m = E.Model(gpu_engine, g)
+    m.set_max_batch(1)
+    try:
+        with pytest.raises(E.EngineError, match="PA_CONV_W_SINGLE"):
+            m.tracknet_infer(rng.normal(0, 1, (1, 16, 16, cin)).astype(np.float32))
+    finally:
+        m.close()
+
+
+def test_engine_gather_bytes_single_rank(gpu_engine):
+    """ABI v5: pa_engine_gather_sizes / pa_engine_gather — with one rank (all a 1-GPU box has) the host-copy form; the N > 1 form
+    is covered by the gloo stand-in (tests/test_bench_gloo.py) and by the driver's multi-GPU bench."""
+    buf = np.arange(1000, dtype=np.uint8)
+    got = gpu_engine.gather_bytes(buf, 0)
+    assert len(got) == 1 and np.array_equal(got[0], buf)
+    assert gpu_engine.gather_bytes(np.zeros(0, np.uint8), 0)[0].size == 0

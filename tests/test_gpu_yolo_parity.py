@@ -32,6 +32,43 @@ pytestmark = pytest.mark.gpu
 TOL_PX = 1e-3
 REPORT = {}
 
+# The fp32 / fp64 CPU-oracle evaluations are the suite's cost (round 5: 699 s of the driver's 1 200 s limit): several tests look at
+# the same (checkpoint, clip) from different sides — both arithmetics of a tight test, the multi-seed statement's first seed, the ulp
+# study.  One evaluation per distinct (weights, frames, thresholds, dtype) and process.
+_ORACLE_CACHE = {}
+
+
+def _content_key(sd, srcs, *rest):
+    import zlib
+    h = 0
+    for k in sorted(sd):
+        a = np.ascontiguousarray(sd[k])
+        h = zlib.crc32(a.reshape(-1)[:: max(1, a.size // 4096)].tobytes(), h)       # a strided sample of every tensor
+        h = zlib.crc32(str((k, a.shape, a.dtype)).encode(), h)
+    for f in srcs:
+        a = np.ascontiguousarray(f)
+        h = zlib.crc32(a.reshape(-1)[::97].tobytes(), h)
+        h = zlib.crc32(str(a.shape).encode(), h)
+    return (h,) + tuple(rest)
+
+
+def _oracle_predict(sd, nc, kpt, srcs, conf, iou, imgsz, dtype=torch.float32):
+    key = _content_key(sd, srcs, nc, kpt, conf, iou, imgsz, str(dtype), "predict")
+    if key not in _ORACLE_CACHE:
+        model = ref.YoloV8Ref(sd, nc, kpt) if dtype == torch.float32 else ref.YoloV8Ref(sd, nc, kpt, dtype=dtype)
+        _ORACLE_CACHE[key] = ref.predict(model, srcs, conf, iou, imgsz, classes=[0])
+    return _ORACLE_CACHE[key]
+
+
+def _oracle_heads(sd, nc, kpt, srcs, S, dtype):
+    key = _content_key(sd, srcs, nc, kpt, S, str(dtype), "heads")
+    if key not in _ORACLE_CACHE:
+        o = ref.YoloV8Ref(sd, nc, kpt) if dtype == torch.float32 else ref.YoloV8Ref(sd, nc, kpt, dtype=dtype)
+        x = ref.preprocess(list(srcs), S)
+        with torch.no_grad():
+            _ORACLE_CACHE[key] = o.head_raw(o.features(x.double() if dtype == torch.float64 else x))
+    return _ORACLE_CACHE[key]
+
 
 def _calib(scale, nc, kpt, srcs, imgsz, conf, seed, dfl_scale=1.0, kpt_scale=1.0):
     im = ref.preprocess(list(srcs), imgsz)
@@ -50,12 +87,8 @@ def _check_heads(tag, m, sd, nc, kpt, srcs, S, n):
     fp64 — the evidence for the CONV STACK that the attenuated-head coordinate tests cannot give (VERDICT r4 #6b).  Errors
     relative to the largest value of the map; the fp32 CPU oracle's own distance from its fp64 evaluation is the yardstick:
     L-inf <= max(2e-5, 1.5 x the oracle's), RMS <= max(2e-6, 1.25 x the oracle's) per level."""
-    o64 = ref.YoloV8Ref(sd, nc, kpt, dtype=torch.float64)
-    o32 = ref.YoloV8Ref(sd, nc, kpt)
-    x = ref.preprocess(list(srcs), S)
-    with torch.no_grad():
-        det, kp = o64.head_raw(o64.features(x.double()))
-        det32, kp32 = o32.head_raw(o32.features(x))
+    det, kp = _oracle_heads(sd, nc, kpt, srcs, S, torch.float64)
+    det32, kp32 = _oracle_heads(sd, nc, kpt, srcs, S, torch.float32)
     rep = {"linf_engine": [], "linf_oracle_fp32": [], "rms_engine": [], "rms_oracle_fp32": []}
     for l in range(3):
         want = (det[l] if not kp else torch.cat((det[l], kp[l]), 1)).permute(0, 2, 3, 1).numpy()
@@ -98,8 +131,8 @@ def _as_arrays(res, nk=0):
 
 def _check(tag, sd, nc, kpt, srcs, got, conf, iou, imgsz, tight=False):
     boxes, kpts, counts = got
-    r32 = ref.predict(ref.YoloV8Ref(sd, nc, kpt), srcs, conf, iou, imgsz, classes=[0])
-    r64 = ref.predict(ref.YoloV8Ref(sd, nc, kpt, dtype=torch.float64), srcs, conf, iou, imgsz, classes=[0])
+    r32 = _oracle_predict(sd, nc, kpt, srcs, conf, iou, imgsz)
+    r64 = _oracle_predict(sd, nc, kpt, srcs, conf, iou, imgsz, torch.float64)
     assert sum(len(r["boxes"]) for r in r32) > 0, "calibration produced no detections"
     nk = 0 if kpt is None else kpt[0] * kpt[1]
     b64, k64, c64 = _as_arrays(r64, nk)
@@ -306,9 +339,8 @@ def test_detect_m_tight_outlier_in_grid_ulps(gpu_engine):
     frames = synth.synthetic_frames(3, 720, 1280, seed=13)
     srcs = [f[..., ::-1] for f in frames]
     sd = _calib("m", 80, None, srcs, 640, 0.5, seed=17, dfl_scale=0.02)
-    o64 = ref.YoloV8Ref(sd, 80, None, dtype=torch.float64)
-    r64 = ref.predict(o64, srcs, 0.5, 0.7, 640, classes=[0])
-    r32 = ref.predict(ref.YoloV8Ref(sd, 80, None), srcs, 0.5, 0.7, 640, classes=[0])
+    r64 = _oracle_predict(sd, 80, None, srcs, 0.5, 0.7, 640, torch.float64)
+    r32 = _oracle_predict(sd, 80, None, srcs, 0.5, 0.7, 640)
     b64, _, c64 = _as_arrays(r64)
     b32, _, c32 = _as_arrays(r32)
     assert np.array_equal(c32, c64)
@@ -322,8 +354,7 @@ def test_detect_m_tight_outlier_in_grid_ulps(gpu_engine):
         dist[mode] = in_ulps(got[0])
         _check(f"detect-m-tight seeds 13/17 (ulp study) [{mode}]", sd, 80, None, srcs, got, 0.5, 0.7, 640, tight=True)
         if mode == MODES[0]:
-            with torch.no_grad():
-                det, _ = o64.head_raw(o64.features(ref.preprocess(srcs, 640).double()))
+            det, _ = _oracle_heads(sd, 80, None, srcs, 640, torch.float64)
             cs = m.head_shapes(720, 1280, 640)[0][2]
             heads = []
             for l in range(3):
