@@ -59,7 +59,7 @@ constexpr int kRDbgTile = 3;                     // the tile of a persistent wor
 // (conv_patch_h2q.hip).  Invalid ids (grid padding) sit at the end of every XCD's range: once a workgroup's id is invalid, all its
 // later ones are
 struct HrTile { int n, y0, x0, f0; bool valid; };
-__device__ __forceinline__ HrTile hr_tile(const ConvArgs& a, int v, int vmax) {
+__device__ __forceinline__ HrTile hr_tile(const ConvArgs& a, int v, int vmax, int frags_per_tile) {
     HrTile t;
     const int nmt = a.n_mtiles, nnt = a.n_ntiles;
     const int q8 = nmt >> 3, r8 = nmt & 7, xcd = v & 7, idx = v >> 3;
@@ -72,7 +72,7 @@ __device__ __forceinline__ HrTile hr_tile(const ConvArgs& a, int v, int vmax) {
     const int rt = mt - t.n * tpi;
     const int ty = rt / txN, tx = rt - ty * txN;
     t.y0 = ty * 8; t.x0 = tx * 16;
-    t.f0 = nt * 6;
+    t.f0 = nt * frags_per_tile;
     return t;
 }
 
@@ -90,11 +90,16 @@ __device__ __forceinline__ HrTile hr_tile(const ConvArgs& a, int v, int vmax) {
 // workgroup in the CU's odd thread-group slot — the tile log of the probe build shows the two workgroups of a CU are not in phase
 // anyway (the older one gets the pipe first: 64.5 k vs 83 k ticks per tile, epilogues 0.9 beside the partner's main loop), no
 // change; `nt` on the patch requests (-6 .. -8 %), `sc0` on the weight loads (0).
-template <int NF, int NBUF, bool DBG = false, int ABL = 0, int PRIO = 0>
+template <int NF, bool WS, bool DBG = false, int ABL = 0, int PRIO = 0>
 __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, const int vmax) {
     constexpr int MF = 4;
-    static_assert(NF == 3, "a wave owns 3 channel fragments; 12 patch spans = 3 per wave");
-    static_assert(NBUF == 2, "double-buffered patch");
+    // NF channel fragments per wave (a workgroup: 2 NF x 16 channels); WS: two products (the m plane of the weights is all zero and
+    // is neither fetched nor multiplied), else three — which fits the registers with NF = 2 only: 64-channel tiles, the shape of
+    // every TrackNetV3 layer (fp32 checkpoint: three products) and of the 64- / 256-channel layers of the YOLO graphs
+    static_assert((NF == 3 && WS) || NF == 2, "NF = 3 with three products needs 72 weight registers: over the budget of 2 waves per SIMD");
+    constexpr int NBUF = 2;                       // double-buffered patch
+    constexpr int NPL = WS ? 1 : 2;               // weight planes fetched per fragment
+    constexpr int NW = NF * NPL;                  // weight requests per tap and wave
     constexpr int DBG_B = DBG ? (4 * kRDbgSteps * 5 + 4 * 64) * 8 : 0;
     constexpr int PATCH_B = (NBUF - 1) * kRBufStride + kRPatchB;
     constexpr int PVO_B = 2 * 3 * 256 * 4;       // the lane offsets of the patch requests, two tiles' worth
@@ -128,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
     const int nch = a.cin >> 5;                   // >= 2 (launch_conv_h2r)
     const int G = (int)gridDim.x;
     int v = (int)blockIdx.x;
-    HrTile cur = hr_tile(a, v, vmax);
+    HrTile cur = hr_tile(a, v, vmax, 2 * NF);
     if (!cur.valid) return;
     // ---- the patch: span s of a plane = 16 pixels x 64 bytes, lane i -> pixel 16 s + i / 4, physical 16-byte slot i & 3 =
     // logical chunk q of that pixel (hr_off), which is piece (q & 1) of group (q >> 1) of the pixel's 128 bytes [h0 m0 h1 m1]
@@ -181,25 +186,39 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         dma3<(K_) * 1024>(vo8[K_], rs8, so8, lb_); dma3<kRPlaneB + (K_) * 1024>(vo8[K_], rs8, so8 + 32u, lb_);    \
     } while (0)
 
-    // ---- weights: a.wr = [fragment][k-step][lane][16 bytes] (h plane only): lane l of fragment j reads bytes [16 l, 16 l + 16)
-    // of the k-step's 1 KB — its MFMA A operand (row l & 15 at k = 8 (l >> 4)).  One descriptor per fragment, one lane offset
-    const unsigned fragb = (unsigned)(nch * 9) * 1024u;
+    // ---- weights: a.wr = [fragment][k-step][h | m][lane][16 bytes]: lane l of fragment j reads bytes [16 l, 16 l + 16) of the
+    // k-step's h KB (and, with three products, of its m KB) — its MFMA A operand (row l & 15 at k = 8 (l >> 4)).  One descriptor per
+    // fragment, one lane offset
+    const unsigned fragb = (unsigned)(nch * 9) * 2048u;
     const unsigned voffW = (unsigned)lane * 16u;
     i32x4 rsrcW[NF];
-    hr_i32x4 w[3][NF];
+    hr_i32x4 w[3][NF], wm[3][WS ? 1 : NF];        // (wm: the correction plane's operands; unused with WS)
     unsigned s_kb = 0;                            // byte offset of the current chunk's first k-step inside a fragment
     // tap TT_ (0..10, relative to the current chunk: 9 and 10 are the next chunk's first two) into register set SET_; the reads of
-    // the last chunk's 9 / 10 run up to 2 KB past a fragment (into the next fragment, or the slack behind the copy)
+    // the last chunk's 9 / 10 run up to 4 KB past a fragment (into the next fragment, or the slack behind the copy)
 #define PADEL_HR_LOADW(SET_, TT_)                                                                                 \
     do {                                                                                                          \
-        const unsigned so_ = s_kb + (unsigned)((TT_) * 1024);                                                     \
-        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+        const unsigned so_ = s_kb + (unsigned)((TT_) * 2048);                                                     \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j) {                                                          \
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"                                               \
                          : "=v"(w[SET_][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory");                    \
+            if constexpr (!WS)                                                                                    \
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:1024"                               \
+                             : "=v"(wm[SET_][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory");               \
+        }                                                                                                         \
     } while (0)
-    // the counted wait that publishes set SET_ to the compiler: the registers pass through it
-#define PADEL_HR_WAITW(SET_, N_)                                                                                  \
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(N_) : "memory")
+    // the counted wait that publishes set SET_ to the compiler: the registers pass through it.  BASE_: requests of the wave that may
+    // stay in flight besides the two younger taps' (0, or 6 patch requests)
+#define PADEL_HR_WAITW(SET_, BASE_)                                                                               \
+    do {                                                                                                          \
+        if constexpr (NF == 3)                                                                                    \
+            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"((BASE_) + 2 * NW) : "memory"); \
+        else if constexpr (WS)                                                                                    \
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]) : "n"((BASE_) + 2 * NW) : "memory"); \
+        else                                                                                                      \
+            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(wm[SET_][0]), "+v"(wm[SET_][WS ? 0 : 1]) \
+                         : "n"((BASE_) + 2 * NW) : "memory");                                                     \
+    } while (0)
 
     // ---- row reads: patch pixel p = p0 + d with p0 = 72 wr + lr (the wave's row 0 at kx = 0) and d = 18 R + KX; hr_off's swizzle
     // term depends on bit 2 of p only, i.e. on d & 7 (adding a multiple of 8 leaves bit 2 alone): eight lane addresses, everything
@@ -225,6 +244,10 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         constexpr int s_ = ((F_) + (KY_)) & 3;                                                                    \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), am[s_], cross[F_][j], 0, 0, 0); \
+        if constexpr (!WS) {                                                                                      \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                        \
+                cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wm[SET_][WS ? 0 : j]), ah[s_], cross[F_][j], 0, 0, 0); \
+        }                                                                                                         \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), ah[s_],   \
                                                                  (FIRST_) ? (f32x4){0.f, 0.f, 0.f, 0.f} : part[F_][j], 0, 0, 0); \
@@ -248,7 +271,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         PADEL_HR_STAMP(T_, 0);                                                                                    \
         PADEL_HR_PRIO(0);                                                                                         \
         if constexpr (PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                                 \
-        PADEL_HR_WAITW(set_, (T_) < 2 ? 12 : 6);                                                                  \
+        PADEL_HR_WAITW(set_, (T_) < 2 ? 6 : 0);                                                                   \
         PADEL_HR_STAMP(T_, 1);                                                                                    \
         if constexpr ((T_) != 8) PADEL_HR_STAMP(T_, 2);                                                           \
         PADEL_HR_PRIO(1);                                                                                         \
@@ -345,11 +368,11 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         PADEL_HR_LOADW(0, 0);
         PADEL_HR_LOADW(1, 1);
         PADEL_HR_PATCH(1, gpar ^ 1, rsrcP, tpar);
-        const HrTile nxt = hr_tile(a, v + G, vmax);        // (the tile arithmetic runs under the latency of the requests above)
+        const HrTile nxt = hr_tile(a, v + G, vmax, 2 * NF);        // (the tile arithmetic runs under the latency of the requests above)
         PADEL_HR_PARAMS(nxt, rsrcPn, tpar ^ 1);
-        if constexpr ((ABL & 256) != 0) { wait_vm3<0>(); for (int j = 0; j < NF; ++j) w[2][j] = w[0][j]; }      // (probe: no weight requests inside the loop)
+        if constexpr ((ABL & 256) != 0) { wait_vm3<0>(); for (int j = 0; j < NF; ++j) { w[2][j] = w[0][j]; if constexpr (!WS) wm[2][j] = wm[0][j]; } }      // (probe: no weight requests inside the loop)
         if (first) {
-            wait_vm3<12>();                       // P(0) landed (W(0), W(1), P(1) may be in flight)
+            wait_vm3<2 * NW + 6>();               // P(0) landed (W(0), W(1), P(1) may be in flight)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
@@ -376,14 +399,14 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
             const int set8 = own8 ? tpar : tpar ^ 1;
             PADEL_HR_STEP(0); PADEL_HR_STEP(1); PADEL_HR_STEP(2); PADEL_HR_STEP(3); PADEL_HR_STEP(4);
             PADEL_HR_STEP(5); PADEL_HR_STEP(6); PADEL_HR_STEP(7); PADEL_HR_STEP(8);
-            s_kb += 9u * 1024u;
+            s_kb += 9u * 2048u;
             gpar ^= 1;
             dbg_k += 9;
         }
         PADEL_HR_PRIO(0);
         // the look-ahead requests of the last chunk (taps 9 / 10: weights nobody uses, issued to keep the counted waits static) target
         // register sets 0 and 1: they must have landed before the epilogue may reuse those registers
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[0][2]), "+v"(w[1][0]), "+v"(w[1][1]), "+v"(w[1][2]) :: "memory");
+        PADEL_HR_WAITW(0, -2 * NW); PADEL_HR_WAITW(1, -2 * NW);           // vmcnt(0), both sets' registers through it
         PADEL_HR_FLUSH(1);
         if constexpr ((ABL & 32) != 0) { PADEL_HR_FLUSH(0); PADEL_HR_FLUSH(2); PADEL_HR_FLUSH(3); }      // (probe: one main chain, flushed once)
 
@@ -437,15 +460,15 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
 #undef PADEL_HR_ON
 }
 
-// one thread per 16 bytes of the copy: [fragment f][k-step t][lane l] <- bytes [16 (l >> 4), +16) of the h half of k-step t of row
-// 16 f + (l & 15) of the packed blob ([row][k-step][h x 32 | m x 32] fp16)
+// one thread per 16 bytes of the copy: [fragment f][k-step t][plane p][lane l] <- bytes [16 (l >> 4), +16) of plane p (h | m) of k-step t
+// of row 16 f + (l & 15) of the packed blob ([row][k-step][h x 32 | m x 32] fp16)
 __global__ void __launch_bounds__(256) h2r_repack_kernel(const char* __restrict__ w, char* __restrict__ wr, int n16, int ksteps) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)n16 * ksteps * 64) return;
-    const int l = (int)(i & 63);
-    const long long ft = i >> 6;
+    if (i >= (long long)n16 * ksteps * 128) return;
+    const int l = (int)(i & 63), pl = (int)((i >> 6) & 1);
+    const long long ft = i >> 7;
     const int t = (int)(ft % ksteps), f = (int)(ft / ksteps);
-    const h2_u32x4 v = *reinterpret_cast<const h2_u32x4*>(w + ((long long)(f * 16 + (l & 15)) * ksteps + t) * 128 + (l >> 4) * 16);
+    const h2_u32x4 v = *reinterpret_cast<const h2_u32x4*>(w + ((long long)(f * 16 + (l & 15)) * ksteps + t) * 128 + pl * 64 + (l >> 4) * 16);
     *reinterpret_cast<h2_u32x4*>(wr + i * 16) = v;
 }
 
@@ -464,44 +487,49 @@ hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsig
     return hipGetLastError();
 }
 
-size_t conv_h2r_copy_bytes(int n16, int cin) { return (size_t)n16 * (size_t)((cin >> 5) * 9) * 1024; }
+size_t conv_h2r_copy_bytes(int n16, int cin) { return (size_t)n16 * (size_t)((cin >> 5) * 9) * 2048; }
 
 hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s) {
     const int ksteps = (cin >> 5) * 9;
-    const long long n = (long long)n16 * ksteps * 64;
+    const long long n = (long long)n16 * ksteps * 128;
     hipLaunchKernelGGL(h2r_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const char*>(w),
                        reinterpret_cast<char*>(wr), n16, ksteps);
     return hipGetLastError();
 }
 
 bool conv_h2r_supported(const ConvArgs& a) {
-    return a.w_single && a.wr && a.ksize == 3 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 64 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr && !a.in2;
+    return a.wr && a.ksize == 3 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 64 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr && !a.in2;
 }
 
-hipError_t launch_conv_h2r(const ConvArgs& a_in, hipStream_t s) {
-    if (!conv_h2r_supported(a_in)) return hipErrorNotSupported;
+// nf = channel fragments per wave: 3 (96-channel tiles; two-product layers only) or 2 (64-channel tiles; two or three products)
+hipError_t launch_conv_h2r(const ConvArgs& a_in, int nf, hipStream_t s) {
+    if (!conv_h2r_supported(a_in) || (nf != 2 && nf != 3) || (nf == 3 && !a_in.w_single)) return hipErrorNotSupported;
     ConvArgs a = a_in;
     const int batch = a.M / (a.Ho * a.Wo);
     a.n_mtiles = batch * ((a.Ho + 7) / 8) * ((a.Wo + 15) / 16);
-    a.n_ntiles = (a.n16 + 5) / 6;
+    a.n_ntiles = (a.n16 + 2 * nf - 1) / (2 * nf);
     const int vmax = 8 * ((a.n_mtiles + 7) / 8) * a.n_ntiles;          // virtual block ids
     static int n_cu = 0;
     if (!n_cu) { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n_cu = p.multiProcessorCount; if (n_cu <= 0) n_cu = 256; }
     const int per = (a.tune & 4) ? vmax : 2 * n_cu;                     // tuning bit 2: one workgroup per tile (the non-persistent form)
     dim3 grid((unsigned)(vmax < per ? vmax : per), 1, 1);               // 2 workgroups per CU (registers); both multiples of 8
 #ifdef PADEL_H2P_PROBES
-    if (a.dbg) {
-        hipLaunchKernelGGL((conv_h2r_kernel<3, 2, true>), grid, dim3(256), 0, s, a, vmax);
-        return hipGetLastError();
-    }
-#define PADEL_HR_ABL(N_) case N_: hipLaunchKernelGGL((conv_h2r_kernel<3, 2, false, N_>), grid, dim3(256), 0, s, a, vmax); return hipGetLastError();
-    switch ((a.tune >> 5) << 4) {      // tuning word bits 5.. = ABL >> 4
-        PADEL_HR_ABL(16) PADEL_HR_ABL(240) PADEL_HR_ABL(1008) PADEL_HR_ABL(2048)
-        default: break;
-    }
+    if (nf == 3) {
+        if (a.dbg) {
+            hipLaunchKernelGGL((conv_h2r_kernel<3, true, true>), grid, dim3(256), 0, s, a, vmax);
+            return hipGetLastError();
+        }
+#define PADEL_HR_ABL(N_) case N_: hipLaunchKernelGGL((conv_h2r_kernel<3, true, false, N_>), grid, dim3(256), 0, s, a, vmax); return hipGetLastError();
+        switch ((a.tune >> 5) << 4) {      // tuning word bits 5.. = ABL >> 4
+            PADEL_HR_ABL(16) PADEL_HR_ABL(240) PADEL_HR_ABL(1008) PADEL_HR_ABL(2048)
+            default: break;
+        }
 #undef PADEL_HR_ABL
+    }
 #endif
-    hipLaunchKernelGGL((conv_h2r_kernel<3, 2>), grid, dim3(256), 0, s, a, vmax);
+    if (nf == 3) hipLaunchKernelGGL((conv_h2r_kernel<3, true>), grid, dim3(256), 0, s, a, vmax);
+    else if (a.w_single) hipLaunchKernelGGL((conv_h2r_kernel<2, true>), grid, dim3(256), 0, s, a, vmax);
+    else hipLaunchKernelGGL((conv_h2r_kernel<2, false>), grid, dim3(256), 0, s, a, vmax);
     return hipGetLastError();
 }
 

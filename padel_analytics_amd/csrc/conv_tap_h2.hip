@@ -219,9 +219,12 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         if (conv_h2w_supported(a)) return launch_conv_h2w(a, variant - 340, s);
         variant = 303;
     }
-    if (variant == 324) {                  // the register-weights quad kernel (conv_patch_h2r.hip: two-product layers); elsewhere the quad kernel
-        if (conv_h2r_supported(a)) return launch_conv_h2r(a, s);
-        variant = 323;
+    if (variant == 324 || variant == 325) {   // the register-weights quad kernels (conv_patch_h2r.hip): 324 = 96-channel tiles (two-product layers),
+        if (conv_h2r_supported(a)) {           // 325 = 64-channel tiles (two or three products); elsewhere the quad kernel / the 64-channel patch tile
+            const hipError_t e = launch_conv_h2r(a, variant == 324 ? 3 : 2, s);
+            if (e != hipErrorNotSupported) return e;
+        }
+        variant = variant == 324 ? 323 : 304;
     }
     if (variant == 323) {                  // the quad patch kernel (conv_patch_h2q.hip); where it does not apply, the 48-channel patch tile
         if (conv_h2q_supported(a)) return launch_conv_h2q(a, s);
@@ -306,13 +309,23 @@ int choose_conv_h2_variant(const ConvArgs& a) {
         // (conv_patch_h2r.hip, round 6: weights global -> VGPR, one barrier per chunk, 2 persistent workgroups per CU) measured
         // 1.15-1.18 x the quad kernel (96 -> 96: 440 -> 505, 192 -> 192: 520 -> 615 TFLOP/s; profiles/r6_sweep_h2r.txt) — fast enough to
         // take channel counts that leave its last 96-channel tile part empty (192 -> 256: 553 vs 473 on the 64-channel tile)
-        if (conv_h2r_supported(a)) {
+        if (conv_h2r_supported(a) && a.w_single) {
             const int ntiles = (n16 + 5) / 6;
             const float fill = (float)n16 / (float)(ntiles * 6) * (float)M / (float)(patches * 128);
             // (no round-quantisation term: the persistent workgroups start their next tile's loads under the current tile, and
             //  a 2.25-tiles-per-workgroup launch — the players graph's 192 -> 192 at 24 x 40 — still measured 461 vs 377 TFLOP/s)
             const float sc = 1.40f * fill;
             if (sc > best) { best = sc; bv = 324; }
+        }
+        // the same kernel on 64-channel tiles (tile 325: a wave 4 rows x 2 fragments): two-product layers whose channels are not a
+        // multiple of 96 (192 -> 256: 600 vs 544 on tile 324 vs 472 on the 64-channel patch tile; 192 -> 64: 569 vs 451; 64 -> 64:
+        // 401 vs 325) and every THREE-product layer with whole chunks — TrackNetV3's fp32 checkpoints (64 -> 64 .. 512 -> 512: 314-438
+        // vs 294-393 TFLOP/s) — profiles/r6u_sweep_h2r_nf2.txt
+        if (conv_h2r_supported(a)) {
+            const int ntiles = (n16 + 3) / 4;
+            const float fill = (float)n16 / (float)(ntiles * 4) * (float)M / (float)(patches * 128);
+            const float sc = (a.w_single ? 1.33f : 1.22f) * fill;
+            if (sc > best) { best = sc; bv = 325; }
         }
         // few input channels (16 / 32 / 48: 5-14 k-steps): the wide patch kernel keeps the whole K extent of a 16 x 16 pixel
         // tile in LDS (conv_patch_h2w.hip; measured against the 8 x 16 tiles in profiles/r3_sweep_h2w.txt)

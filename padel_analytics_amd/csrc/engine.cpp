@@ -781,6 +781,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             const bool use_bx3 = a.w3 != nullptr;
             int bm = 0, bn = 0;
             if (h2 && (lv == 323 || lv == 324)) { bm = 128; bn = 96; }
+            else if (h2 && lv == 325) { bm = 128; bn = 64; }
             else if (h2 && lv >= 341 && lv <= 343) { bm = 256; bn = (lv - 340) * 16; }      // wide patch kernel: 16 x 16 pixels                       // quad patch kernel: 8 x 16 pixels x 96 channels
             else if (h2 && (lv == 243 || lv == 239)) conv_variant_shape(lv - 230, &bm, &bn);      // deep-ring tap tiles: the shape of 213 / 209
             else if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
@@ -893,13 +894,13 @@ static int ensure_operand_copies(pa_model* m) {
         size_t total = 0;
         for (size_t i = 0; i < m->ops.size(); ++i) {
             const pa_op_desc& o = m->ops[i];
-            if (o.kind != PA_OP_CONV || !(o.flags & PA_CONV_W_SINGLE) || o.ksize != 3 || o.stride != 1 || (o.cin & 31) || o.cin < 32) continue;
+            if (o.kind != PA_OP_CONV || o.ksize != 3 || o.stride != 1 || (o.cin & 31) || o.cin < 64) continue;
             m->wr_off[i] = (long long)total;
             total += conv_h2r_copy_bytes(o.npad / 16, o.cin);
         }
         if (total) {
-            PA_HIP(e, hipMalloc((void**)&m->d_wr, total + 4096));          // the last chunk's look-ahead reads run 2 KB past a fragment
-            PA_HIP(e, hipMemsetAsync(m->d_wr + total, 0, 4096, e->stream));
+            PA_HIP(e, hipMalloc((void**)&m->d_wr, total + 8192));          // the last chunk's look-ahead reads run 4 KB past a fragment
+            PA_HIP(e, hipMemsetAsync(m->d_wr + total, 0, 8192, e->stream));
         }
     }
     for (size_t i = 0; i < m->ops.size(); ++i) {

@@ -41,7 +41,7 @@ struct ConvArgs {
     unsigned* ovf_flag;   // h2 kernels: set to 1 when an output value does not fit the fp16 range (h2_common.h)
     int w_single;         // h2 kernels: 1 = the m plane of the packed weights is all zero (PA_CONV_W_SINGLE): the wm x ah product, its
                           // weight requests and operand reads are skipped — two MFMAs per operand pair (same results: the product is 0)
-    const void* wr;       // h2 two-product stride-1 3x3 layers: the h plane once more in MFMA operand order [fragment][k-step][lane][16 B]
+    const void* wr;       // h2 stride-1 3x3 layers with whole chunks: the weights once more in MFMA operand order [fragment][k-step][h | m][lane][16 B]
                           // (conv_patch_h2r.hip; nullptr: no such copy)
     unsigned long long* dbg;   // tuning only (PADEL_CONV_DBG): per-workgroup s_memtime timeline, see conv_tap.hip
     // m / (Ho*Wo) and rem / Wo without an integer-division sequence (conv_tap.hip prologue): q = (umulhi(n, magic) + n) >> shift,
@@ -84,7 +84,7 @@ hipError_t launch_conv_h2p(const ConvArgs& a, int nf, hipStream_t s);
 bool conv_h2q_supported(const ConvArgs& a);            // conv_patch_h2q.hip: stride-1 3x3, cin % 32 == 0, no absorbed upsample
 hipError_t launch_conv_h2q(const ConvArgs& a, hipStream_t s);
 bool conv_h2r_supported(const ConvArgs& a);            // conv_patch_h2r.hip (round 6): the quad tile with the weights global -> registers, one barrier per chunk; PA_CONV_W_SINGLE layers only
-hipError_t launch_conv_h2r(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv_h2r(const ConvArgs& a, int nf, hipStream_t s);      // nf 3: tile 324 (96 channels, two products), nf 2: tile 325 (64 channels, two or three products)
 size_t conv_h2r_copy_bytes(int n16, int cin);          // bytes of the operand-order copy of one conv's h plane
 hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s);
 // *flag |= 1 when any m-plane bit of `rows_x_ksteps` packed 128-byte k-step records is set (the PA_CONV_W_SINGLE promise, checked once per model)

@@ -18,7 +18,7 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 303, 304, 313, 323, 324, 341, 342, 343)      # 324: the register-weights quad kernel (round 6; two-product layers, elsewhere = 323); 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
+H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 303, 304, 313, 323, 324, 325, 341, 342, 343)      # 324 / 325: the register-weights quad kernels (round 6; 96-channel tiles, two-product layers only / 64-channel tiles, two or three products); 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
 H2_SINGLE_LEVEL = ()            # (the 6-fragment patch tile 306 — main product accumulated in ONE level — was removed in round 5)
 
 def _graph(case, w, b, wr, dtype):
@@ -486,11 +486,12 @@ def test_h2r_persistent_workgroups_walk_many_tiles(gpu_engine, shape):
     outs = {}
     try:
         for name, kw in (("303", dict(variant=303)), ("323", dict(variant=323)), ("324", dict(variant=324)), ("324 again", dict(variant=324)),
-                         ("324 one workgroup per tile", dict(variant=324, tune=5))):
+                         ("324 one workgroup per tile", dict(variant=324, tune=5)), ("325", dict(variant=325)), ("325 again", dict(variant=325)),
+                         ("325 three products", dict(variant=325, w_single=0)), ("325 one workgroup per tile", dict(variant=325, tune=5))):
             gpu_engine.set_tuning(**{"tune": 1, **kw})
             outs[name] = run()
     finally:
-        gpu_engine.set_tuning(variant=-1, tune=1)
+        gpu_engine.set_tuning(variant=-1, tune=1, w_single=1)
     xt = torch.from_numpy(x).permute(0, 3, 1, 2).double()
     want = F.silu(F.conv2d(xt, torch.from_numpy(w).double() * torch.from_numpy(scale).double()[:, None, None, None], torch.from_numpy(b).double(), padding=1))
     if use_res:

@@ -44,6 +44,13 @@ SHAPES = [
     ("players.P4 192->192 24x40", 64, 24, 40, 192, 192, 3, 1),
     ("players.P5 288->288 12x20", 64, 12, 20, 288, 288, 3, 1),
     ("players.head 192->256 48x80", 64, 48, 80, 192, 256, 3, 1),
+    # TrackNetV3 (fp32 checkpoint: three products) at 288 x 512 and the 64-channel layers of the pose heads
+    ("tn 64->64 288x512", 16, 288, 512, 64, 64, 3, 1),
+    ("tn 128->128 144x256", 32, 144, 256, 128, 128, 3, 1),
+    ("tn 256->256 72x128", 64, 72, 128, 256, 256, 3, 1),
+    ("tn 512->512 36x64", 64, 36, 64, 512, 512, 3, 1),
+    ("pose.head 192->64 P3", 64, 160, 160, 192, 64, 3, 1),
+    ("pose.head 64->64 P3", 64, 160, 160, 64, 64, 3, 1),
 ]
 
 

@@ -15,6 +15,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=72)
     ap.add_argument("--feed", type=int, default=8)
+    ap.add_argument("--dump-ops", default="", help="per-op CSV of one profiled pass (kind, ksize, M, cout, cin, stride, tile, ms, flops)")
     a = ap.parse_args()
     from oracle import tracknet_ref as tr          # seeded synthetic TrackNet weights (setup only)
     from padel_analytics_amd import engine as E, graph as G
@@ -44,9 +45,16 @@ if __name__ == "__main__":
     n, _ = run()
     dt = time.perf_counter() - t0
     _, recs = run(profile=True)
+    if a.dump_ops:
+        with open(a.dump_ops, "w") as f:
+            f.write("kind,ksize,M,cout,cin,stride,bm,bn,ms,flops\n")
+            for r in recs:
+                f.write(f"{r['kind']},{r['ksize']},{r['M']},{r['cout']},{r['cin']},{r['stride']},{r['mf']},{r['nf']},{r['ms']:.5f},{r['flops']:.0f}\n")
     conv = [r for r in recs if r["kind"] == 2]
     ms = sum(r["ms"] for r in conv); fl = sum(r["flops"] for r in conv)
     print(json.dumps({"tracker": "ball_tracker (TrackNetV3 27->8 @288x512, one window per frame)", "frames": n,
                       "frames_per_s": round(n / dt, 1), "ms_per_frame": round(1e3 * dt / n, 3),
                       "conv_tflops": round(fl / ms / 1e9, 1), "conv_ms_per_frame": round(ms / (a.frames - 7), 3),
+                      "all_kernels_ms_per_frame": round(sum(r["ms"] for r in recs) / (a.frames - 7), 3),
+                      "non_conv_ms_per_frame": {str(k): round(sum(r["ms"] for r in recs if r["kind"] == k) / (a.frames - 7), 4) for k in sorted({r["kind"] for r in recs}) if k != 2},
                       "input": "host frames (H2D inside the timed region), masks D2H", "arithmetic": E.fp32_mode()}))
