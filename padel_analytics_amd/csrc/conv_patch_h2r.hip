@@ -487,10 +487,12 @@ hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsig
     return hipGetLastError();
 }
 
-size_t conv_h2r_copy_bytes(int n16, int cin) { return (size_t)n16 * (size_t)((cin >> 5) * 9) * 2048; }
+// k-steps of a stride-1 3x3 layer in the packed blob: 9 taps per whole 32-channel chunk + 5 tap pairs for a 16-channel tail
+static int h2_ksteps3(int cin) { return (cin >> 5) * 9 + ((cin & 16) ? 5 : 0); }
+size_t conv_h2r_copy_bytes(int n16, int cin) { return (size_t)n16 * (size_t)h2_ksteps3(cin) * 2048; }
 
 hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s) {
-    const int ksteps = (cin >> 5) * 9;
+    const int ksteps = h2_ksteps3(cin);
     const long long n = (long long)n16 * ksteps * 128;
     hipLaunchKernelGGL(h2r_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const char*>(w),
                        reinterpret_cast<char*>(wr), n16, ksteps);

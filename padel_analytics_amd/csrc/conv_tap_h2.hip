@@ -216,6 +216,10 @@ static hipError_t launch_h2t(const ConvArgs& a_in, hipStream_t s) {
 hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
     if ((a.ksize != 3 && a.ksize != 1) || (a.cin & 15) || a.cin < 16 || !a.w || !a.oscale || !a.ovf_flag) return hipErrorNotSupported;
     if (variant >= 341 && variant <= 343) {  // the wide patch kernel for 16 / 32 / 48 input channels (conv_patch_h2w.hip), 1..3 channel fragments
+        if (!(a.tune & 8) && conv_h2v_supported(a)) {      // its register-weights form (conv_patch_h2v.hip; tuning bit 3: the round-3 kernel)
+            const hipError_t e = launch_conv_h2v(a, variant - 340, s);
+            if (e != hipErrorNotSupported) return e;
+        }
         if (conv_h2w_supported(a)) return launch_conv_h2w(a, variant - 340, s);
         variant = 303;
     }

@@ -92,6 +92,8 @@ hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsig
 hipError_t launch_conv_h2_deep(const ConvArgs& a, int variant, hipStream_t s);     // conv_tap_h2p.hip: tap tiles with a 3-stage activation ring (239, 243); hipErrorNotSupported where they do not apply
 bool conv_h2w_supported(const ConvArgs& a);            // conv_patch_h2w.hip: stride-1 3x3 with 16 / 32 / 48 input channels
 hipError_t launch_conv_h2w(const ConvArgs& a, int nf, hipStream_t s);
+bool conv_h2v_supported(const ConvArgs& a);            // conv_patch_h2v.hip (round 6): the wide patch tile with the weights global -> registers, one barrier per workgroup
+hipError_t launch_conv_h2v(const ConvArgs& a, int nf, hipStream_t s);
 // fp16 path (conv_tap16.hip): in / w / res / out are _Float16 arrays behind the float pointers of ConvArgs (cs and
 // choff count elements); cin % 32 == 0; weights packed [Npad][Ktot] with K order (64-channel chunk, tap, 32-channel half)
 hipError_t launch_conv_tap16(const ConvArgs& a, int variant, hipStream_t s);

@@ -531,3 +531,48 @@ def test_engine_gather_bytes_single_rank(gpu_engine):
     got = gpu_engine.gather_bytes(buf, 0)
     assert len(got) == 1 and np.array_equal(got[0], buf)
     assert gpu_engine.gather_bytes(np.zeros(0, np.uint8), 0)[0].size == 0
+
+
+@pytest.mark.parametrize("cin,cout,w16", [(48, 48, True), (32, 64, False), (16, 32, True), (48, 96, False)], ids=["48-48-two", "32-64-three", "16-32-two", "48-96-three"])
+def test_h2v_register_weight_wide_kernel_equals_the_wide_kernel(gpu_engine, cin, cout, w16):
+    """Round 6: conv_patch_h2v.hip (the wide patch tile with the weights global -> VGPR, no per-step barrier) against
+    conv_patch_h2w.hip (tuning bit 3) and the 48-channel patch tile, bitwise, on partial tiles with a residual, twice."""
+    B, H, W = 3, 37, 50
+    rng = np.random.default_rng(cin * 7 + cout)
+    x = rng.normal(0, 1, (B, H, W, cin)).astype(np.float32)
+    w = rng.normal(0, (2.0 / (cin * 9)) ** 0.5, (cout, cin, 3, 3)).astype(np.float32)
+    scale = None
+    if w16:
+        w = w.astype(np.float16).astype(np.float32)
+        scale = rng.uniform(0.5, 2.0, cout).astype(np.float32)
+    b = rng.normal(0, 0.5, cout).astype(np.float32)
+    wr = rng.normal(0, (1.0 / cin) ** 0.5, (cout, cin, 1, 1)).astype(np.float32)
+
+    def run():
+        g = G.Graph(task=G.TASK_TRACKNET, dtype=G.DTYPE_H2)
+        b0 = g.buf(0, cin)
+        b2 = g.buf(0, G.pad16(cout))
+        g.conv((b0, 0, cin), (b2, 0), wr, np.zeros(cout, np.float32), 1, 1, G.ACT_NONE)
+        b1 = g.buf(0, G.pad16(cout))
+        g.conv((b0, 0, cin), (b1, 0), w, b, 3, 1, G.ACT_SILU, res=(b2, 0), out_scale=scale)
+        assert bool(g.ops[-1]["flags"] & G.FLAG_W_SINGLE) == w16
+        g.head_buf = (b1, -1, -1)
+        m = E.Model(gpu_engine, g)
+        m.set_max_batch(B)
+        y = m.tracknet_infer(x)[..., :cout]
+        m.close()
+        return y
+
+    outs = {}
+    try:
+        for nf in (1, 2, 3):
+            for name, tune in ((f"h2v nf {nf}", 1), (f"h2v nf {nf} again", 1), (f"h2w nf {nf}", 9)):
+                gpu_engine.set_tuning(variant=340 + nf, tune=tune)
+                outs[name] = run()
+        gpu_engine.set_tuning(variant=303, tune=1)
+        outs["303"] = run()
+    finally:
+        gpu_engine.set_tuning(variant=-1, tune=1)
+    ref = outs["303"]
+    for name, y in outs.items():
+        assert np.array_equal(y, ref), f"{name} differs from the 48-channel patch tile (max {np.abs(y - ref).max():.3e}, {int((y != ref).sum())} values)"
