@@ -894,9 +894,11 @@ static int ensure_operand_copies(pa_model* m) {
         size_t total = 0;
         for (size_t i = 0; i < m->ops.size(); ++i) {
             const pa_op_desc& o = m->ops[i];
-            // conv_patch_h2r.hip: whole chunks, at least two; conv_patch_h2v.hip: 16 / 32 / 48 input channels
-            if (o.kind != PA_OP_CONV || o.ksize != 3 || o.stride != 1) continue;
-            if (!(((o.cin & 31) == 0 && o.cin >= 64) || o.cin == 16 || o.cin == 32 || o.cin == 48)) continue;
+            // conv_patch_h2r.hip: stride 1, whole chunks, at least two; conv_patch_h2v.hip: stride 1, 16 / 32 / 48 input channels;
+            // stem_l1_h2.hip: the stride-2 layer behind the stem (16 / 32 / 48 input channels)
+            if (o.kind != PA_OP_CONV || o.ksize != 3) continue;
+            const bool few = o.cin == 16 || o.cin == 32 || o.cin == 48;
+            if (!((o.stride == 1 && (o.cin & 31) == 0 && o.cin >= 64) || few)) continue;
             m->wr_off[i] = (long long)total;
             total += conv_h2r_copy_bytes(o.npad / 16, o.cin);
         }

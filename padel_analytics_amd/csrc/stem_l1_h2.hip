@@ -41,8 +41,14 @@ __device__ __forceinline__ int fs_entry(int srow, int scol) { return (srow * 2 +
 // WS: layer 1's packed weights have an all-zero m plane (ConvArgs::w_single): no wm x ah product and no m-plane operand reads.  (The
 // weight ring's requests still carry the all-zero plane — PADEL_FS_DMAB covers both planes of a k-step with one set of spans; the
 // zeros land in LDS and are never read.  ADVICE r5.)
-template <int NF, bool WS = false>
+// WR (round 6, with WS): layer 1's weights come global -> VGPR from the operand-order copy (ConvArgs::wr, conv_patch_h2r.hip), two
+// steps ahead through three register sets with counted waits, and its operands are read one step ahead into a second register set:
+// phase 2 has NO per-step barrier and no weight stages in LDS (a step is 2 x NF x 2 = 12 MFMAs per wave at c = 48 — 192 pipe
+// cycles that used to sit behind a barrier, a ring wait and NF weight reads each).  The barriers that remain publish the stem's
+// planes (one, two more around the c = 48 tail planes).
+template <int NF, bool WS = false, bool WR = false>
 __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, const ConvArgs a) {
+    static_assert(!WR || WS, "register weights: two-product layers");
     constexpr bool CHUNK = NF >= 2, TAIL = (NF & 1) != 0;
     constexpr int NCF = CHUNK ? 2 : 0;               // stem fragments that form the 32-channel chunk
     constexpr int MF = 2;
@@ -53,9 +59,10 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
     constexpr int NSTG = 3;                          // weight ring: step T + 2 is requested while step T computes (a layer-1 step
                                                      // is 18 MFMAs per wave: with a 2-stage ring every step waited out a DMA round trip)
     static_assert(S_B + NSTG * BSTAGE_B + 1024 <= 80 * 1024, "2 workgroups per CU");
-    __shared__ __attribute__((aligned(16))) float lds[(S_B + NSTG * BSTAGE_B + 1024) / 4];
+    constexpr int WSTG_B = WR ? 0 : NSTG * BSTAGE_B;               // (register weights: no weight stages)
+    __shared__ __attribute__((aligned(16))) float lds[(S_B + WSTG_B + 1024) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
-    float* const s_osc = lds + (S_B + NSTG * BSTAGE_B) / 4;        // 1 / row scale of the stem's weight rows (NF x 16 floats)
+    float* const s_osc = lds + (S_B + WSTG_B) / 4;                  // 1 / row scale of the stem's weight rows (NF x 16 floats)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,8 +106,37 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
         if constexpr (NF >= 2) dma3<4096>(voffB[NF >= 2 ? 1 : 0], rsrcB, (unsigned)(ST_) * 128u, lw_);            \
         if constexpr (NF >= 3) dma3<8192>(voffB[NF >= 3 ? 2 : 0], rsrcB, (unsigned)(ST_) * 128u, lw_);            \
     } while (0)
-    PADEL_FS_DMAB(0);
-    PADEL_FS_DMAB(1);
+    // register weights: fragment wc NF + j of layer 1 (its 2 NF fragments, NSTEPS k-steps of 2 KB each: [h | m][lane][16 B])
+    typedef int fs_i32x4 __attribute__((ext_vector_type(4)));
+    const unsigned voffW = (unsigned)lane * 16u;
+    i32x4 rsrcW[NF];
+    fs_i32x4 wreg[3][NF];
+    (void)voffW; (void)rsrcW; (void)wreg;
+    if constexpr (WR) {
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+            rsrcW[j] = make_rsrc3(reinterpret_cast<const char*>(a.wr) + (long long)(wc * NF + j) * (NSTEPS * 2048));
+    }
+#define PADEL_FS_LOADW(ST_)                                                                                       \
+    do {                                                                                                          \
+        const unsigned so_ = (unsigned)((ST_) * 2048);                                                            \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen"                                               \
+                         : "=v"(wreg[(ST_) % 3][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory");            \
+    } while (0)
+#define PADEL_FS_WAITW(ST_, N_)                                                                                   \
+    do {                                                                                                          \
+        if constexpr (NF == 3) asm volatile("s_waitcnt vmcnt(%3)" : "+v"(wreg[(ST_) % 3][0]), "+v"(wreg[(ST_) % 3][1]), "+v"(wreg[(ST_) % 3][NF - 1]) : "n"(N_) : "memory"); \
+        else if constexpr (NF == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wreg[(ST_) % 3][0]), "+v"(wreg[(ST_) % 3][NF - 1]) : "n"(N_) : "memory"); \
+        else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(wreg[(ST_) % 3][0]) : "n"(N_) : "memory");                \
+    } while (0)
+    if constexpr (WR) {
+        PADEL_FS_LOADW(0);
+        if constexpr (NSTEPS > 1) PADEL_FS_LOADW(1);
+    } else {
+        PADEL_FS_DMAB(0);
+        PADEL_FS_DMAB(1);
+    }
 
     // ---- phase 1 operands.  K slot kk of lane group lq is k = 8 lq + kk -> tap (dy, dx) = (k / 9, k / 3 % 3), colour byte k % 3
     // (k >= 27: zero weights AND zero data).  Weights of row lr = channel 16 j + lr: w / 255, scaled by the power of two that
@@ -223,6 +259,8 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
 #pragma unroll
         for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
     h16x8 ah[MF], am[MF], wh[NF], wm[NF];
+    h16x8 ah2[2][MF], am2[2][MF];                  // (WR: the operands of step T in set T & 1, read one step ahead)
+    (void)ah2; (void)am2;
     // entry of output row (2 wr + F_) of this wave at tap T_ (column-major: (ky, kx) = (T_ % 3, T_ / 3)), column lr
 #define PADEL_FS_ENT(F_, T_) fs_entry(2 * (2 * wr + (F_)) + h2_tap_ky(T_), 2 * lr + h2_tap_kx(T_))
 #define PADEL_FS_READB(ST_)                                                                                       \
@@ -301,6 +339,74 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
             _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
     } while (0)
 
+    // ---- register-weight steps (WR)
+#define PADEL_FS_READA2(SET_, T_)                                                                                 \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
+            const char* p_ = ldsb + fs_off(PADEL_FS_ENT(f, T_), lq);                                              \
+            ah2[SET_][f] = *reinterpret_cast<const h16x8*>(p_);                                                   \
+            am2[SET_][f] = *reinterpret_cast<const h16x8*>(p_ + kFPlaneB);                                        \
+        }                                                                                                         \
+    } while (0)
+#define PADEL_FS_TREADA2(SET_, JT_)                                                                               \
+    do {                                                                                                          \
+        constexpr int ta_ = 2 * (JT_), tb_ = 2 * (JT_) + 1 < 9 ? 2 * (JT_) + 1 : 8;                               \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                          \
+            const int ea_ = PADEL_FS_ENT(f, ta_), eb_ = PADEL_FS_ENT(f, tb_);                                     \
+            const char* p_ = ldsb + fs_tail_off((lq >> 1) ? eb_ : ea_, lq & 1);                                   \
+            ah2[SET_][f] = *reinterpret_cast<const h16x8*>(p_);                                                   \
+            am2[SET_][f] = *reinterpret_cast<const h16x8*>(p_ + kFTPlaneB);                                       \
+        }                                                                                                         \
+    } while (0)
+#define PADEL_FS_MFMA2(SET_, ST_)                                                                                 \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            cross[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wreg[(ST_) % 3][j]), am2[SET_][f], cross[f][j], 0, 0, 0); \
+        _Pragma("unroll") for (int f = 0; f < MF; ++f) _Pragma("unroll") for (int j = 0; j < NF; ++j)             \
+            part[f][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wreg[(ST_) % 3][j]), ah2[SET_][f], part[f][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    // step ST_ of the walk: request step ST_ + 2's weights, read the NEXT step's operands (NEXT_: the read macro call, or nothing at
+    // the end of a plane set), wait for this step's weights (younger: ST_ + 1, ST_ + 2 where they exist), multiply
+#define PADEL_FS_STEP2(ST_, NEXT_)                                                                                \
+    do {                                                                                                          \
+        if constexpr ((ST_) + 2 < NSTEPS) PADEL_FS_LOADW((ST_) + 2);                                              \
+        NEXT_;                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_FS_WAITW(ST_, NF * (((ST_) + 1 < NSTEPS ? 1 : 0) + ((ST_) + 2 < NSTEPS ? 1 : 0)));                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_FS_MFMA2((ST_) & 1, ST_);                                                                           \
+    } while (0)
+    if constexpr (WR) {
+        if constexpr (CHUNK) {
+            PADEL_FS_STEM(0, 2, false);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's plane writes have reached the LDS
+            __builtin_amdgcn_s_barrier();                        // ... and every wave's: the planes are published
+            asm volatile("" ::: "memory");
+            PADEL_FS_READA2(0, 0);
+            PADEL_FS_STEP2(0, PADEL_FS_READA2(1, 1)); PADEL_FS_STEP2(1, PADEL_FS_READA2(0, 2)); PADEL_FS_STEP2(2, PADEL_FS_READA2(1, 3));
+            PADEL_FS_STEP2(3, PADEL_FS_READA2(0, 4)); PADEL_FS_STEP2(4, PADEL_FS_READA2(1, 5)); PADEL_FS_STEP2(5, PADEL_FS_READA2(0, 6));
+            PADEL_FS_STEP2(6, PADEL_FS_READA2(1, 7)); PADEL_FS_STEP2(7, PADEL_FS_READA2(0, 8)); PADEL_FS_STEP2(8, (void)0);
+            PADEL_FS_FLUSH();
+        }
+        if constexpr (TAIL) {
+            constexpr int S0 = CHUNK ? 9 : 0;
+            if constexpr (CHUNK) {                   // every wave is done with the chunk planes: the tail planes take their place
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+            PADEL_FS_STEM(NCF, 1, true);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            PADEL_FS_TREADA2(S0 & 1, 0);
+            PADEL_FS_STEP2(S0, PADEL_FS_TREADA2((S0 + 1) & 1, 1)); PADEL_FS_STEP2(S0 + 1, PADEL_FS_TREADA2((S0 + 2) & 1, 2));
+            PADEL_FS_STEP2(S0 + 2, PADEL_FS_TREADA2((S0 + 3) & 1, 3)); PADEL_FS_STEP2(S0 + 3, PADEL_FS_TREADA2((S0 + 4) & 1, 4));
+            PADEL_FS_STEP2(S0 + 4, (void)0);
+            PADEL_FS_FLUSH();
+        }
+    } else {
     if constexpr (CHUNK) {
         PADEL_FS_STEM(0, 2, false);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this wave's plane writes have reached the LDS
@@ -320,7 +426,14 @@ __global__ void __launch_bounds__(256, 2) stem_l1_h2_kernel(const StemArgs st, c
         PADEL_FS_TSTEP(0, S0); PADEL_FS_TSTEP(1, S0 + 1); PADEL_FS_TSTEP(2, S0 + 2); PADEL_FS_TSTEP(3, S0 + 3); PADEL_FS_TSTEP(4, S0 + 4);
         PADEL_FS_FLUSH();
     }
+    }
     wait_vm3<0>();
+#undef PADEL_FS_STEP2
+#undef PADEL_FS_MFMA2
+#undef PADEL_FS_TREADA2
+#undef PADEL_FS_READA2
+#undef PADEL_FS_WAITW
+#undef PADEL_FS_LOADW
 #undef PADEL_FS_FLUSH
 #undef PADEL_FS_TSTEP
 #undef PADEL_FS_TREADA
@@ -367,6 +480,15 @@ hipError_t launch_stem_l1_h2(const StemArgs& st, const ConvArgs& a_in, hipStream
     a.n_mtiles = batch * ((a.Ho + 3) / 4) * ((a.Wo + 15) / 16);
     a.n_ntiles = 1;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8), 1, 1);
+    if (a.w_single && a.wr && !(a.tune & 8)) {           // register weights (tuning bit 3: the round-5 weight ring)
+        switch (st.cout / 16) {
+            case 1: hipLaunchKernelGGL((stem_l1_h2_kernel<1, true, true>), grid, dim3(256), 0, s, st, a); return hipGetLastError();
+            case 2: hipLaunchKernelGGL((stem_l1_h2_kernel<2, true, true>), grid, dim3(256), 0, s, st, a); return hipGetLastError();
+            // (3 workgroups per CU — the LDS would allow them now — need 168 VGPRs: 11 spilled, 3.42 instead of 3.32 ms on the pose graph)
+            case 3: hipLaunchKernelGGL((stem_l1_h2_kernel<3, true, true>), grid, dim3(256), 0, s, st, a); return hipGetLastError();
+            default: return hipErrorNotSupported;
+        }
+    }
     switch (st.cout / 16) {
         case 1: if (a.w_single) hipLaunchKernelGGL((stem_l1_h2_kernel<1, true>), grid, dim3(256), 0, s, st, a);
                 else hipLaunchKernelGGL((stem_l1_h2_kernel<1>), grid, dim3(256), 0, s, st, a);
