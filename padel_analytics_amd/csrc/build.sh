@@ -12,7 +12,7 @@ OUT="${PADEL_OUT:-../libpadel_hip.so}"
 mkdir -p "$BUILD"
 pids=()
 # PADEL_ONLY="a.hip b.hip": recompile only these translation units and relink with the objects already in $BUILD (iteration)
-ALL="conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_tap_h2.hip conv_tap_h2p.hip conv_patch_h2.hip conv_patch_h2q.hip conv_patch_h2r.hip conv_patch_h2v.hip conv_patch_h2w.hip conv_patch16.hip kernels_misc.hip stem_l1_h2.hip postproc.hip tracknet_post.hip"
+ALL="conv_tap.hip conv_tap16.hip conv_tap_bx3.hip conv_patch_bx3.hip conv_tap_h2.hip conv_tap_h2p.hip conv_1x1_h2s.hip conv_patch_h2.hip conv_patch_h2q.hip conv_patch_h2r.hip conv_patch_h2v.hip conv_patch_h2w.hip conv_patch16.hip kernels_misc.hip stem_l1_h2.hip postproc.hip tracknet_post.hip"
 for f in ${PADEL_ONLY:-$ALL}; do
   [ -f "$f" ] || continue
   [ "$f" = engine.cpp ] && continue

@@ -1,0 +1,213 @@
+// K4s "h2 1x1, register weights" (round 6) — the 1x1 convolutions of h2 graphs, two-product layers (PA_CONV_W_SINGLE) with
+// cin % 32 == 0 and no absorbed upsample: the C2f cv1 / cv2, SPPF and head 1x1 layers, 17 ms of the bench's step at 120-375 TFLOP/s
+// fp32-equivalent and 2.5-4.9 TB/s — neither at the matrix roof nor at the HBM roof.
+//
+// A 1x1 layer streams its activation tile once per k-step (no tap reuse): what it needs is requests far enough ahead and nothing
+// else between its products.  The tap kernels (conv_tap_h2p.hip: 128 x 96 tile, 4 waves of 2 x 6 fragments) keep two activation
+// steps in flight and spend a ring wait, six weight reads and a barrier per 24-MFMA k-step.  Here
+//   * a workgroup owns 128 pixels x 96 channels as 2 x 2 waves of 4 x 3 fragments (64 pixels x 48 channels: 3 KB of weights per
+//     wave and k-step instead of 6 — the two waves of a channel half share them in the L1);
+//   * the WEIGHTS never touch LDS: global -> VGPR from the operand-order copy ([fragment][k-step][h | m][lane][16 B],
+//     conv_patch_h2r.hip), two k-steps ahead through three register sets;
+//   * the LDS that frees (80 KB per workgroup, two per CU) is a FIVE-stage activation ring of single k-steps (128 pixels x 32
+//     channels x 4 B = 16 KB per stage): the request of step J + 4 goes out behind the barrier of step J — four steps (64 KB per
+//     workgroup, 128 KB per CU) in flight; the per-step barrier stays (it publishes the stage), but all that sits in front of it is
+//     the wave's own counted wait.
+// (First version, measured: 32 KB double steps in a two-stage ring, one barrier per 48 MFMAs — 363 vs 363 and 266 vs 276 TFLOP/s on
+//  1152 -> 384 / 576 -> 192 against the tap tile: one double step in flight does not cover the memory latency; depth, not barrier
+//  count, is what these layers need.)
+// The M tail needs no lane masks: the tile's buffer descriptor ends at the tensor's end (out-of-range lanes read zeros); the lane
+// offsets are constants of the kernel.
+// Accumulation as in the tap kernels — cross: wh am per k-step; main: wh ah in blocks of 9 k-steps, flushed into acc — so results are
+// bitwise those of conv_h2_1_kernel / conv_h2_1p_kernel.
+#include "h2_common.h"
+
+namespace padel {
+
+namespace {
+
+constexpr int kSPlaneB = 128 * 64;              // one fp16 plane of a 32-channel chunk: 128 pixels x 64 B
+constexpr int kSStageB = 2 * kSPlaneB;          // h | m of one k-step
+constexpr int kSStages = 5;
+constexpr int kSAhead = 4;                      // request distance in k-steps
+
+__device__ __forceinline__ unsigned hs_off(int p, int q) { return (unsigned)(p * 64 + ((q ^ (((p >> 2) & 1) << 1)) << 4)); }
+
+typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace
+
+__global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
+    constexpr int MF = 4, NF = 3;
+    __shared__ __attribute__((aligned(16))) float lds[(kSStages * kSStageB) / 4];
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;      // pixel half (64 pixels), channel half (3 fragments)
+    const int lr = lane & 15, lq = lane >> 4;
+
+    // XCD-aware 1-D tile map: the channel tiles of one pixel tile are neighbours on one XCD (they share its activations in the L2)
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;
+    const int bid = blockIdx.x;
+    const int q8 = nmt >> 3, r8 = nmt & 7, xcd = bid & 7, idx = bid >> 3;
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;
+    if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
+    const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
+    const int m0 = mt * 128;
+    const int f0 = nt * 2 * NF;
+    const int nch = a.cin >> 5;                   // k-steps
+
+    // ---- activations: span s of a plane = 16 pixels x 64 bytes, lane i -> pixel 16 s + i / 4, physical 16-byte slot i & 3 = logical
+    // chunk q of that pixel, which is piece (q & 1) of group (q >> 1) of the pixel's 128 bytes [h0 m0 h1 m1] of the k-step in HBM; the
+    // m plane's 32 bytes go in through the scalar offset.  Wave w requests spans w and w + 4 of both planes of a stage.
+    // The descriptor starts at the tile's first pixel and ends with the tensor: the M tail reads zeros.
+    const long long pix_b = (long long)a.in_cs * 4;
+    const char* const in0 = reinterpret_cast<const char*>(a.in + a.in_choff) + (long long)m0 * pix_b;
+    i32x4 rsrcA = make_rsrc3(in0);
+    {
+        const long long left = ((long long)a.M - m0) * pix_b;
+        rsrcA[2] = (int)(left > 0x7FFFFFFFll ? 0x7FFFFFFFll : left);
+    }
+    const int p_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const unsigned p_piece = (unsigned)((p_q >> 1) * 64 + (p_q & 1) * 16);
+    unsigned voA[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) voA[k] = (unsigned)(((wave + 4 * k) * 16 + (lane >> 2)) * (unsigned)pix_b) + p_piece;
+    const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+    const unsigned lpw = __builtin_amdgcn_readfirstlane(lp0 + (unsigned)wave * 1024u);
+    // k-step K_ into the stage at byte offset SB_; k-steps beyond the last go through a descriptor of zero records (the request
+    // count per step — and with it every counted wait — is static)
+#define PADEL_HS_REQA(SB_, K_)                                                                                    \
+    do {                                                                                                          \
+        const unsigned so_ = (unsigned)(K_) * 128u;                                                               \
+        const unsigned lb_ = lpw + (unsigned)(SB_);                                                               \
+        i32x4 rs_ = rsrcA;                                                                                        \
+        if ((int)(K_) >= nch) rs_[2] = 0;                                                                         \
+        dma3<0>(voA[0], rs_, so_, lb_); dma3<4096>(voA[1], rs_, so_, lb_);                                        \
+        dma3<kSPlaneB>(voA[0], rs_, so_ + 32u, lb_); dma3<kSPlaneB + 4096>(voA[1], rs_, so_ + 32u, lb_);          \
+    } while (0)
+
+    // ---- weights: a.wr = [fragment][k-step][h | m][lane][16 bytes]; NF requests per wave and k-step
+    const unsigned fragb = (unsigned)nch * 2048u;
+    const unsigned voffW = (unsigned)lane * 16u;
+    i32x4 rsrcW[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int frag = min(f0 + NF * wc + j, a.n16 - 1);   // fragments beyond the matrix: any valid rows (never stored)
+        rsrcW[j] = make_rsrc3(reinterpret_cast<const char*>(a.wr) + (long long)frag * fragb);
+    }
+    hs_i32x4 w[3][NF];
+    // (k-steps beyond the last read the next fragment's first k-steps, or the slack behind the copy — never multiplied)
+#define PADEL_HS_LOADW(SET_, K_)                                                                                  \
+    do {                                                                                                          \
+        const unsigned so_ = (unsigned)(K_) * 2048u;                                                              \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[SET_][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory"); \
+    } while (0)
+#define PADEL_HS_WAITW(SET_, N_)                                                                                  \
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(N_) : "memory")
+
+    // ---- operand reads: pixel fragment f of the wave = pixels 64 wr + 16 f + lr: hs_off's swizzle depends on lr only, everything
+    // else is the stage's offset (scalar, walks the ring) and an immediate
+    const unsigned abase = hs_off(64 * wr + lr, lq);
+    f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
+    h16x8 ah[MF], am[MF];
+#define PADEL_HS_MFMA(F_, SET_)                                                                                   \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), am[F_], cross[F_][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), ah[F_], part[F_][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    // k-step K_ (weight set SET_ = K_ % 3, statically: the loop is unrolled by three; the stage walks the ring through s_rd / s_wr).
+    // Queue of the wave behind W(K_) when it waits: A(K_ + 2) x 4, W(K_ + 1) x 3, A(K_ + 3) x 4, W(K_ + 2) x 3 — 14 requests; in
+    // front of it, in order: A(K_), W(K_ - 1), A(K_ + 1).
+#define PADEL_HS_STEP(K_, SET_)                                                                                   \
+    do {                                                                                                          \
+        PADEL_HS_LOADW(((SET_) + 2) % 3, (K_) + 2);                                                               \
+        PADEL_HS_WAITW(SET_, 14);                                                                                 \
+        __builtin_amdgcn_s_barrier();             /* stage s_rd is published; the stage read in step K_ - 1 (= s_wr) is free */ \
+        asm volatile("" ::: "memory");                                                                            \
+        PADEL_HS_REQA(s_wr, (K_) + kSAhead);                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        {                                                                                                         \
+            const char* p_ = ldsb + abase + s_rd;                                                                 \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                      \
+                ah[f] = *reinterpret_cast<const h16x8*>(p_ + f * 1024);                                           \
+                am[f] = *reinterpret_cast<const h16x8*>(p_ + f * 1024 + kSPlaneB);                                \
+            }                                                                                                     \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        PADEL_HS_MFMA(0, SET_); PADEL_HS_MFMA(1, SET_); PADEL_HS_MFMA(2, SET_); PADEL_HS_MFMA(3, SET_);           \
+        if (++kblk == 9) {                        /* main sums in blocks of 9 k-steps (the tap kernels' accumulation blocks) */ \
+            kblk = 0;                                                                                             \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
+                _Pragma("unroll") for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
+        }                                                                                                         \
+        s_wr = s_rd;                                                                                              \
+        s_rd = s_rd + (unsigned)kSStageB == (unsigned)(kSStages * kSStageB) ? 0u : s_rd + (unsigned)kSStageB;     \
+    } while (0)
+
+    int kblk = 0;
+    unsigned s_rd = 0, s_wr = (unsigned)((kSStages - 1) * kSStageB);      // stage of the current step / the stage the previous step read
+    // prologue — the order the steady state leaves: A(0), A(1), W(0), A(2), W(1), A(3) (stages 0..3; stage 4 = "read by step -1")
+    PADEL_HS_REQA(0 * kSStageB, 0); PADEL_HS_REQA(1 * kSStageB, 1);
+    PADEL_HS_LOADW(0, 0);
+    PADEL_HS_REQA(2 * kSStageB, 2);
+    PADEL_HS_LOADW(1, 1);
+    PADEL_HS_REQA(3 * kSStageB, 3);
+#pragma unroll 1
+    for (int k = 0; k < nch; k += 3) {
+        PADEL_HS_STEP(k, 0);
+        if (k + 1 < nch) PADEL_HS_STEP(k + 1, 1);
+        if (k + 2 < nch) PADEL_HS_STEP(k + 2, 2);
+    }
+    if (kblk != 0) {
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) acc[f][j] += part[f][j];
+    }
+    // the look-ahead requests behind the last step (zero-record activations, weights nobody uses) before the LDS is released and
+    // before the epilogue may reuse the weight registers
+    PADEL_HS_WAITW(0, 0); PADEL_HS_WAITW(1, 0); PADEL_HS_WAITW(2, 0);
+#undef PADEL_HS_STEP
+#undef PADEL_HS_MFMA
+#undef PADEL_HS_WAITW
+#undef PADEL_HS_LOADW
+#undef PADEL_HS_REQA
+
+    int mpix[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int m = m0 + 64 * wr + 16 * f + lr;
+        mpix[f] = m < a.M ? m : -1;
+    }
+    const int fw = f0 + NF * wc;
+    const bool fast = m0 + 128 <= a.M && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
+                      (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
+    if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
+}
+
+bool conv_h2s_supported(const ConvArgs& a) {
+    return a.w_single && a.wr && a.ksize == 1 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 64 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr &&
+           !a.in2 && (long long)128 * a.in_cs * 4 < 0x7FFFFFFFll;
+}
+
+hipError_t launch_conv_h2s(const ConvArgs& a_in, hipStream_t s) {
+    if (!conv_h2s_supported(a_in)) return hipErrorNotSupported;
+    ConvArgs a = a_in;
+    a.n_mtiles = (a.M + 127) / 128;
+    a.n_ntiles = (a.n16 + 5) / 6;
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    hipLaunchKernelGGL(conv_h2s_kernel, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace padel

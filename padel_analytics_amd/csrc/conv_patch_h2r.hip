@@ -488,11 +488,12 @@ hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsig
 }
 
 // k-steps of a stride-1 3x3 layer in the packed blob: 9 taps per whole 32-channel chunk + 5 tap pairs for a 16-channel tail
-static int h2_ksteps3(int cin) { return (cin >> 5) * 9 + ((cin & 16) ? 5 : 0); }
-size_t conv_h2r_copy_bytes(int n16, int cin) { return (size_t)n16 * (size_t)h2_ksteps3(cin) * 2048; }
+// (1x1 layers: one k-step per 32 channels, a 16-channel tail half-filled)
+static int h2_ksteps(int cin, int ksize) { return ksize == 3 ? (cin >> 5) * 9 + ((cin & 16) ? 5 : 0) : (cin + 31) >> 5; }
+size_t conv_h2r_copy_bytes(int n16, int cin, int ksize) { return (size_t)n16 * (size_t)h2_ksteps(cin, ksize) * 2048; }
 
-hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s) {
-    const int ksteps = h2_ksteps3(cin);
+hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, int ksize, hipStream_t s) {
+    const int ksteps = h2_ksteps(cin, ksize);
     const long long n = (long long)n16 * ksteps * 128;
     hipLaunchKernelGGL(h2r_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const char*>(w),
                        reinterpret_cast<char*>(wr), n16, ksteps);

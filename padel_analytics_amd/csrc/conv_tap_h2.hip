@@ -241,6 +241,10 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         variant = (nf == 3 || nf == 13) ? 220 : (nf == 4 || nf == 14) ? 209 : 213;      // where the patch kernel does not apply: its tap sibling
     }
     if (a.in2 && a.ksize == 3) return hipErrorNotSupported;
+    if (variant == 244) {                  // 1x1 with register weights, one barrier per two k-steps (conv_1x1_h2s.hip); elsewhere the deep-ring tile
+        if (conv_h2s_supported(a)) return launch_conv_h2s(a, s);
+        variant = 243;
+    }
     if (variant == 243 || variant == 239) {   // 1x1 with the three-stage activation ring (conv_h2_1p_kernel); other kernel sizes: the plain tile
         const hipError_t e = launch_conv_h2_deep(a, variant, s);
         if (e != hipErrorNotSupported) return e;

@@ -782,6 +782,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             int bm = 0, bn = 0;
             if (h2 && (lv == 323 || lv == 324)) { bm = 128; bn = 96; }
             else if (h2 && lv == 325) { bm = 128; bn = 64; }
+            else if (h2 && lv == 244) { bm = 128; bn = 96; }
             else if (h2 && lv >= 341 && lv <= 343) { bm = 256; bn = (lv - 340) * 16; }      // wide patch kernel: 16 x 16 pixels                       // quad patch kernel: 8 x 16 pixels x 96 channels
             else if (h2 && (lv == 243 || lv == 239)) conv_variant_shape(lv - 230, &bm, &bn);      // deep-ring tap tiles: the shape of 213 / 209
             else if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
@@ -896,11 +897,13 @@ static int ensure_operand_copies(pa_model* m) {
             const pa_op_desc& o = m->ops[i];
             // conv_patch_h2r.hip: stride 1, whole chunks, at least two; conv_patch_h2v.hip: stride 1, 16 / 32 / 48 input channels;
             // stem_l1_h2.hip: the stride-2 layer behind the stem (16 / 32 / 48 input channels)
-            if (o.kind != PA_OP_CONV || o.ksize != 3) continue;
+            // conv_1x1_h2s.hip: 1x1, stride 1, whole chunks, at least two
+            if (o.kind != PA_OP_CONV) continue;
             const bool few = o.cin == 16 || o.cin == 32 || o.cin == 48;
-            if (!((o.stride == 1 && (o.cin & 31) == 0 && o.cin >= 64) || few)) continue;
+            const bool whole = o.stride == 1 && (o.cin & 31) == 0 && o.cin >= 64;
+            if (!((o.ksize == 3 && (whole || few)) || (o.ksize == 1 && whole && (o.flags & PA_CONV_W_SINGLE)))) continue;
             m->wr_off[i] = (long long)total;
-            total += conv_h2r_copy_bytes(o.npad / 16, o.cin);
+            total += conv_h2r_copy_bytes(o.npad / 16, o.cin, o.ksize);
         }
         if (total) {
             PA_HIP(e, hipMalloc((void**)&m->d_wr, total + 8192));          // the last chunk's look-ahead reads run 4 KB past a fragment
@@ -910,7 +913,7 @@ static int ensure_operand_copies(pa_model* m) {
     for (size_t i = 0; i < m->ops.size(); ++i) {
         if (m->wr_off[i] < 0) continue;
         const pa_op_desc& o = m->ops[i];
-        PA_HIP(e, launch_h2r_repack(m->d_w + o.w_off, m->d_wr + m->wr_off[i], o.npad / 16, o.cin, e->stream));
+        PA_HIP(e, launch_h2r_repack(m->d_w + o.w_off, m->d_wr + m->wr_off[i], o.npad / 16, o.cin, o.ksize, e->stream));
     }
     m->wr_valid = true;
     return 0;

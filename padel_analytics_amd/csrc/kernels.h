@@ -85,8 +85,10 @@ bool conv_h2q_supported(const ConvArgs& a);            // conv_patch_h2q.hip: st
 hipError_t launch_conv_h2q(const ConvArgs& a, hipStream_t s);
 bool conv_h2r_supported(const ConvArgs& a);            // conv_patch_h2r.hip (round 6): the quad tile with the weights global -> registers, one barrier per chunk; PA_CONV_W_SINGLE layers only
 hipError_t launch_conv_h2r(const ConvArgs& a, int nf, hipStream_t s);      // nf 3: tile 324 (96 channels, two products), nf 2: tile 325 (64 channels, two or three products)
-size_t conv_h2r_copy_bytes(int n16, int cin);          // bytes of the operand-order copy of one conv's h plane
-hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, hipStream_t s);
+size_t conv_h2r_copy_bytes(int n16, int cin, int ksize);          // bytes of the operand-order copy of one conv's weights (both planes)
+hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, int ksize, hipStream_t s);
+bool conv_h2s_supported(const ConvArgs& a);            // conv_1x1_h2s.hip (round 6): 1x1, two products, register weights, one barrier per two k-steps
+hipError_t launch_conv_h2s(const ConvArgs& a, hipStream_t s);
 // *flag |= 1 when any m-plane bit of `rows_x_ksteps` packed 128-byte k-step records is set (the PA_CONV_W_SINGLE promise, checked once per model)
 hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsigned* flag, hipStream_t s);
 hipError_t launch_conv_h2_deep(const ConvArgs& a, int variant, hipStream_t s);     // conv_tap_h2p.hip: tap tiles with a 3-stage activation ring (239, 243); hipErrorNotSupported where they do not apply
