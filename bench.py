@@ -257,9 +257,7 @@ def measure_traffic(a, ops_rows, tmp):
             "algorithmic_bytes_per_launch": round(alg / n_ops), "ratio_to_algorithmic": round((fetch + write) / (alg / n_ops), 3),
             "launches_counted": {"FETCH_SIZE": tot["FETCH_SIZE"][1], "WRITE_SIZE": tot["WRITE_SIZE"][1], "ops_per_step": n_ops},
             "static": False,
-            "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over "
-                      "`bench.py --engine-only --steps 1` of the same workload; FETCH_SIZE KiB x 1024 x 2 (gfx950 correction), "
-                      "WRITE_SIZE KiB x 1024"}
+            "source": "this run: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) of one engine-only step; FETCH x 2 (gfx950)"}
 
 
 def parity_low_noise_heads(eng, names, frames, sample, H, W, ref, parity):
@@ -778,7 +776,7 @@ def main():
                            "write_bytes_per_launch": tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                            "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"), "static": True,
-                           "source": "profiles/r5_traffic.json: " + tj["source"]}
+                           "source": ("profiles/r5_traffic.json: " + tj["source"])[:118]}
         out["roofline"] = {
             "kernel": ("conv_p16 / conv_p16q (stride-1 3x3 patch kernels) + conv_tap16 (stride 2); v_mfma_f32_16x16x32_f16" if a.dtype == "f16" else
                        "conv_h2r / h2q / h2p / h2w (stride-1 3x3 patch kernels) + conv_h2 (stride 2); 2-3 x v_mfma_f32_16x16x32_f16 per block" if a.impl == "h2" else
