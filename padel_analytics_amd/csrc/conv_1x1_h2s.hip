@@ -28,8 +28,6 @@ namespace {
 
 constexpr int kSPlaneB = 128 * 64;              // one fp16 plane of a 32-channel chunk: 128 pixels x 64 B
 constexpr int kSStageB = 2 * kSPlaneB;          // h | m of one k-step
-constexpr int kSStages = 5;
-constexpr int kSAhead = 4;                      // request distance in k-steps
 
 __device__ __forceinline__ unsigned hs_off(int p, int q) { return (unsigned)(p * 64 + ((q ^ (((p >> 2) & 1) << 1)) << 4)); }
 
@@ -37,8 +35,18 @@ typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
 
 }  // namespace
 
-__global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
+// WC = waves along the channels: 2 (128 x 96 tile, 4 waves, 2 workgroups per CU, 5-stage ring) or 4 (128 x 192 tile, 8 waves, ONE
+// workgroup per CU, 9-stage ring): what bounds a 1x1 layer is the LDS-DMA fill stream of its activation tile — every 96-channel
+// tile of a pixel tile requests the same 16 KB per k-step again (7.4 TB/s of requests on 1152 -> 384: the chip's LDS-DMA fill
+// rate) —, and with all MFMAs compiled out (PROBE) the kernel is exactly as fast: 265 vs 264 / 309 vs 331 TFLOP/s
+// (profiles/r6B_1x1_probe.txt).  Twice the channels per workgroup is half the requests.
+// PROBE (tuning word bit 6, wrong results): 1 = no MFMAs and no operand reads — what the request stream alone sustains
+template <int WC, int PROBE = 0>
+__global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a) {
     constexpr int MF = 4, NF = 3;
+    constexpr int kSStages = WC == 2 ? 5 : 9;
+    constexpr int kSAhead = kSStages - 1;          // request distance in k-steps
+    constexpr int NA = 8 / (2 * WC) * 2;           // activation requests per wave and k-step: 16 spans x planes over 2 WC waves
     __shared__ __attribute__((aligned(16))) float lds[(kSStages * kSStageB) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x;
@@ -55,7 +63,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
     if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
     const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
     const int m0 = mt * 128;
-    const int f0 = nt * 2 * NF;
+    const int f0 = nt * WC * NF;
     const int nch = a.cin >> 5;                   // k-steps
 
     // ---- activations: span s of a plane = 16 pixels x 64 bytes, lane i -> pixel 16 s + i / 4, physical 16-byte slot i & 3 = logical
@@ -73,7 +81,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
     const unsigned p_piece = (unsigned)((p_q >> 1) * 64 + (p_q & 1) * 16);
     unsigned voA[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) voA[k] = (unsigned)(((wave + 4 * k) * 16 + (lane >> 2)) * (unsigned)pix_b) + p_piece;
+    for (int k = 0; k < 2; ++k) voA[k] = (unsigned)(((wave + 4 * k) * 16 + (lane >> 2)) * (unsigned)pix_b) + p_piece;     // (WC = 4: one span per wave)
     const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
     const unsigned lpw = __builtin_amdgcn_readfirstlane(lp0 + (unsigned)wave * 1024u);
     // k-step K_ into the stage at byte offset SB_; k-steps beyond the last go through a descriptor of zero records (the request
@@ -84,8 +92,8 @@ __global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
         const unsigned lb_ = lpw + (unsigned)(SB_);                                                               \
         i32x4 rs_ = rsrcA;                                                                                        \
         if ((int)(K_) >= nch) rs_[2] = 0;                                                                         \
-        dma3<0>(voA[0], rs_, so_, lb_); dma3<4096>(voA[1], rs_, so_, lb_);                                        \
-        dma3<kSPlaneB>(voA[0], rs_, so_ + 32u, lb_); dma3<kSPlaneB + 4096>(voA[1], rs_, so_ + 32u, lb_);          \
+        dma3<0>(voA[0], rs_, so_, lb_); if constexpr (WC == 2) dma3<4096>(voA[1], rs_, so_, lb_);                 \
+        dma3<kSPlaneB>(voA[0], rs_, so_ + 32u, lb_); if constexpr (WC == 2) dma3<kSPlaneB + 4096>(voA[1], rs_, so_ + 32u, lb_); \
     } while (0)
 
     // ---- weights: a.wr = [fragment][k-step][h | m][lane][16 bytes]; NF requests per wave and k-step
@@ -131,12 +139,12 @@ __global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
 #define PADEL_HS_STEP(K_, SET_)                                                                                   \
     do {                                                                                                          \
         PADEL_HS_LOADW(((SET_) + 2) % 3, (K_) + 2);                                                               \
-        PADEL_HS_WAITW(SET_, 14);                                                                                 \
+        PADEL_HS_WAITW(SET_, 2 * NF + 2 * NA);                                                                    \
         __builtin_amdgcn_s_barrier();             /* stage s_rd is published; the stage read in step K_ - 1 (= s_wr) is free */ \
         asm volatile("" ::: "memory");                                                                            \
         PADEL_HS_REQA(s_wr, (K_) + kSAhead);                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        {                                                                                                         \
+        if constexpr (PROBE == 0) {                                                                               \
             const char* p_ = ldsb + abase + s_rd;                                                                 \
             _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                      \
                 ah[f] = *reinterpret_cast<const h16x8*>(p_ + f * 1024);                                           \
@@ -144,7 +152,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
             }                                                                                                     \
         }                                                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
-        PADEL_HS_MFMA(0, SET_); PADEL_HS_MFMA(1, SET_); PADEL_HS_MFMA(2, SET_); PADEL_HS_MFMA(3, SET_);           \
+        if constexpr (PROBE == 0) { PADEL_HS_MFMA(0, SET_); PADEL_HS_MFMA(1, SET_); PADEL_HS_MFMA(2, SET_); PADEL_HS_MFMA(3, SET_); } \
         if (++kblk == 9) {                        /* main sums in blocks of 9 k-steps (the tap kernels' accumulation blocks) */ \
             kblk = 0;                                                                                             \
             _Pragma("unroll") for (int f = 0; f < MF; ++f)                                                        \
@@ -156,8 +164,11 @@ __global__ void __launch_bounds__(256, 2) conv_h2s_kernel(const ConvArgs a) {
 
     int kblk = 0;
     unsigned s_rd = 0, s_wr = (unsigned)((kSStages - 1) * kSStageB);      // stage of the current step / the stage the previous step read
-    // prologue — the order the steady state leaves: A(0), A(1), W(0), A(2), W(1), A(3) (stages 0..3; stage 4 = "read by step -1")
+    // prologue — the order the steady state leaves behind W(0): A(2), W(1), A(3) (14 / 10 requests); everything further ahead
+    // (A(4) .. A(kSAhead - 1), WC = 4) goes in front of it, with A(0), A(1)
     PADEL_HS_REQA(0 * kSStageB, 0); PADEL_HS_REQA(1 * kSStageB, 1);
+#pragma unroll
+    for (int k = 4; k < kSAhead; ++k) PADEL_HS_REQA(k * kSStageB, k);
     PADEL_HS_LOADW(0, 0);
     PADEL_HS_REQA(2 * kSStageB, 2);
     PADEL_HS_LOADW(1, 1);
@@ -200,13 +211,23 @@ bool conv_h2s_supported(const ConvArgs& a) {
            !a.in2 && (long long)128 * a.in_cs * 4 < 0x7FFFFFFFll;
 }
 
-hipError_t launch_conv_h2s(const ConvArgs& a_in, hipStream_t s) {
+hipError_t launch_conv_h2s(const ConvArgs& a_in, bool nf12, hipStream_t s) {
     if (!conv_h2s_supported(a_in)) return hipErrorNotSupported;
     ConvArgs a = a_in;
     a.n_mtiles = (a.M + 127) / 128;
-    a.n_ntiles = (a.n16 + 5) / 6;
+    const bool wide = nf12;                     // 128 x 192 tiles: 8 waves, one workgroup per CU
+    a.n_ntiles = wide ? (a.n16 + 11) / 12 : (a.n16 + 5) / 6;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
-    hipLaunchKernelGGL(conv_h2s_kernel, grid, dim3(256), 0, s, a);
+    if (wide) {
+        static bool attr = false;
+        if (!attr) {                                // 144 KB of static LDS
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+            attr = true;
+        }
+        if (a.tune & 64) hipLaunchKernelGGL((conv_h2s_kernel<4, 1>), grid, dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2s_kernel<4, 0>), grid, dim3(512), 0, s, a);
+    } else if (a.tune & 64) hipLaunchKernelGGL((conv_h2s_kernel<2, 1>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_h2s_kernel<2, 0>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

@@ -241,8 +241,8 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         variant = (nf == 3 || nf == 13) ? 220 : (nf == 4 || nf == 14) ? 209 : 213;      // where the patch kernel does not apply: its tap sibling
     }
     if (a.in2 && a.ksize == 3) return hipErrorNotSupported;
-    if (variant == 244) {                  // 1x1 with register weights, one barrier per two k-steps (conv_1x1_h2s.hip); elsewhere the deep-ring tile
-        if (conv_h2s_supported(a)) return launch_conv_h2s(a, s);
+    if (variant == 244 || variant == 245) {   // 1x1 with register weights and a deep activation ring (conv_1x1_h2s.hip): 128 x 96 / 128 x 192; elsewhere the deep-ring tile
+        if (conv_h2s_supported(a)) return launch_conv_h2s(a, variant == 245, s);
         variant = 243;
     }
     if (variant == 243 || variant == 239) {   // 1x1 with the three-stage activation ring (conv_h2_1p_kernel); other kernel sizes: the plain tile
@@ -289,6 +289,11 @@ int choose_conv_h2_variant(const ConvArgs& a) {
     // 1x1 layers with K >= 192 stream their activations from HBM: the three-stage activation ring (conv_tap_h2p.hip) measured
     // +2..3 % at K = 192, +7..8 % at K = 576 / 1152, -2.5 % at K = 96 (profiles/r5b_tiles_1x1_deep_ring.txt); same results
     if (ksize == 1 && a.cin >= 192 && (bv == 213 || bv == 209)) bv += 30;
+    // Round 6: what bounds a long-K 1x1 layer is the LDS-DMA stream of its activation tile, requested again by every 96-channel tile
+    // of a pixel tile (conv_1x1_h2s.hip: the kernel is as fast with its MFMAs compiled out).  128 x 192 tiles (8 waves, one workgroup
+    // per CU, register weights) halve the requests: +10..14 % on 768 / 960 / 1152 -> 384 / 576, +4..7 % on 384 / 576 -> 384, level or
+    // behind on 192-channel outputs (profiles/r6D_1x1_tile_245.txt); bitwise the same results
+    if (ksize == 1 && a.w_single && n16 >= 24 && a.cin >= 384 && conv_h2s_supported(a)) bv = 245;
     if (conv_h2p_supported(a)) {
         struct P { int nf; float sp; };
         // (the 6-fragment patch tile accumulates its main product in ONE level — registers — and measured no faster than the

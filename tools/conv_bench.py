@@ -44,6 +44,14 @@ SHAPES = [
     ("players.P4 192->192 24x40", 64, 24, 40, 192, 192, 3, 1),
     ("players.P5 288->288 12x20", 64, 12, 20, 288, 288, 3, 1),
     ("players.head 192->256 48x80", 64, 48, 80, 192, 256, 3, 1),
+    # the pose graph's long-K 1x1 layers (C2f cv2 / SPPF / FPN joins at P3-P5, 1280^2)
+    ("pose 1x1 768->384 P4", 64, 80, 80, 768, 384, 1, 1),
+    ("pose 1x1 960->384 P4", 64, 80, 80, 960, 384, 1, 1),
+    ("pose 1x1 1152->576 P5", 64, 40, 40, 1152, 576, 1, 1),
+    ("pose 1x1 576->384 P4", 64, 80, 80, 576, 384, 1, 1),
+    ("pose 1x1 384->384 P4", 64, 80, 80, 384, 384, 1, 1),
+    ("pose 1x1 384->192 P3", 64, 160, 160, 384, 192, 1, 1),
+    ("pose 1x1 576->192 P3", 64, 160, 160, 576, 192, 1, 1),
     # TrackNetV3 (fp32 checkpoint: three products) at 288 x 512 and the 64-channel layers of the pose heads
     ("tn 64->64 288x512", 16, 288, 512, 64, 64, 3, 1),
     ("tn 128->128 144x256", 32, 144, 256, 128, 128, 3, 1),
