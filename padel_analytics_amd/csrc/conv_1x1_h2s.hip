@@ -206,6 +206,196 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
     if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
 }
 
+// ===================================================================================================== stride-2 3x3 (tile 246)
+// The stride-2 3x3 layers (L3 / L4 / L5 of the backbone, the PAN's downsampling convs: 6.1 ms of the bench's step on the tap kernel at
+// MfmaUtil 0.34) have the 1x1 layers' disease nine times over: the tap walk requests a 16 KB activation tile per TAP and 96-channel
+// tile — 7.4 TB/s of LDS-DMA requests on 96 -> 192, the chip's fill rate.  The same machine as conv_h2s_kernel<4>: 128 output pixels x
+// 192 channels per workgroup (8 waves, one workgroup per CU, nine 16 KB stages), register weights, k-step = (32-channel chunk, tap) with
+// the taps column-major like every h2 kernel and the main sums flushed per chunk (= the tap kernels' blocks of 9 k-steps): bitwise
+// conv_h2_kernel.  A lane's request offset is its pixel's top-left input pixel relative to the tile's; the tap enters through the
+// scalar offset, taps outside the image through a per-lane validity mask (3 row bits + 3 column bits).
+template <int PROBE = 0>
+__global__ void __launch_bounds__(512, 2) conv_h2s3_kernel(const ConvArgs a) {
+    constexpr int MF = 4, NF = 3, WC = 4;
+    constexpr int kSStages = 9, kSAhead = 8, NA = 2;
+    __shared__ __attribute__((aligned(16))) float lds[(kSStages * kSStageB) / 4];
+    char* const ldsb = reinterpret_cast<char*>(lds);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;
+    const int lr = lane & 15, lq = lane >> 4;
+
+    const int nmt = a.n_mtiles, nnt = a.n_ntiles;
+    const int bid = blockIdx.x;
+    const int q8 = nmt >> 3, r8 = nmt & 7, xcd = bid & 7, idx = bid >> 3;
+    const int mloc = idx / nnt, nt = idx - mloc * nnt;
+    if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
+    const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
+    const int m0 = mt * 128;
+    const int f0 = nt * WC * NF;
+    const int nch = a.cin >> 5;
+    const int HoWo = a.Ho * a.Wo;
+
+    // ---- activations.  Output pixel m -> (n, oy, ox); its window starts at input pixel (2 oy - 1, 2 ox - 1); linear input pixel
+    // relative to the tile's first one (monotone in m: >= 0).  Wave w requests span w (16 pixels) of both planes of a stage.
+    const long long pix_b = (long long)a.in_cs * 4;
+    long long lin0;
+    {
+        const int n = fastdiv3(m0, a.howo_magic, a.howo_shift);
+        const int rem = m0 - n * HoWo;
+        const int oy = fastdiv3(rem, a.wo_magic, a.wo_shift), ox = rem - oy * a.Wo;
+        lin0 = ((long long)n * a.H + (2 * oy - 1)) * a.W + (2 * ox - 1);
+    }
+    const i32x4 rsrcA = make_rsrc3(reinterpret_cast<const char*>(a.in + a.in_choff) + lin0 * pix_b);
+    const int p_q = (lane & 3) ^ (((lane >> 4) & 1) << 1);
+    const unsigned p_piece = (unsigned)((p_q >> 1) * 64 + (p_q & 1) * 16);
+    unsigned voA, vbits = 0;
+    {
+        const int m = m0 + wave * 16 + (lane >> 2);
+        const bool mv = m < a.M;
+        const int mc = mv ? m : m0;
+        const int n = fastdiv3(mc, a.howo_magic, a.howo_shift);
+        const int rem = mc - n * HoWo;
+        const int oy = fastdiv3(rem, a.wo_magic, a.wo_shift), ox = rem - oy * a.Wo;
+        const int iy0 = 2 * oy - 1, ix0 = 2 * ox - 1;
+        const long long lin = ((long long)n * a.H + iy0) * a.W + ix0;
+        voA = (unsigned)((lin - lin0) * pix_b) + p_piece;
+        if (mv) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                vbits |= ((unsigned)(iy0 + k) < (unsigned)a.H ? 1u : 0u) << k;
+                vbits |= ((unsigned)(ix0 + k) < (unsigned)a.W ? 8u : 0u) << k;
+            }
+        }
+    }
+    const unsigned rowb = (unsigned)a.W * (unsigned)pix_b;
+    const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
+    const unsigned lpw = __builtin_amdgcn_readfirstlane(lp0 + (unsigned)wave * 1024u);
+    // tap TAP_ (column-major: ky = TAP_ % 3, kx = TAP_ / 3) of chunk CH_ into the stage at byte offset SB_; chunks beyond the last go
+    // through a descriptor of zero records
+#define PADEL_HS3_REQA(SB_, CH_, TAP_)                                                                            \
+    do {                                                                                                          \
+        constexpr int ky_ = (TAP_) % 3, kx_ = (TAP_) / 3;                                                         \
+        constexpr unsigned need_ = (1u << ky_) | (8u << kx_);                                                     \
+        const unsigned so_ = (unsigned)(CH_) * 128u + (unsigned)ky_ * rowb + (unsigned)kx_ * (unsigned)pix_b;     \
+        const unsigned lb_ = lpw + (unsigned)(SB_);                                                               \
+        i32x4 rs_ = rsrcA;                                                                                        \
+        if ((int)(CH_) >= nch) rs_[2] = 0;                                                                        \
+        const unsigned vo_ = (vbits & need_) == need_ ? voA : kOOR3;                                              \
+        dma3<0>(vo_, rs_, so_, lb_); dma3<kSPlaneB>(vo_, rs_, so_ + 32u, lb_);                                    \
+    } while (0)
+
+    // ---- weights: a.wr = [fragment][k-step][h | m][lane][16 bytes], k-step = chunk * 9 + tap
+    const unsigned fragb = (unsigned)(nch * 9) * 2048u;
+    const unsigned voffW = (unsigned)lane * 16u;
+    i32x4 rsrcW[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int frag = min(f0 + NF * wc + j, a.n16 - 1);
+        rsrcW[j] = make_rsrc3(reinterpret_cast<const char*>(a.wr) + (long long)frag * fragb);
+    }
+    hs_i32x4 w[3][NF];
+    unsigned s_kw = 0;                            // byte offset of the current chunk's first k-step inside a fragment
+#define PADEL_HS3_LOADW(SET_, TT_)                                                                                \
+    do {                                                                                                          \
+        const unsigned so_ = s_kw + (unsigned)((TT_) * 2048);                                                     \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[SET_][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory"); \
+    } while (0)
+#define PADEL_HS3_WAITW(SET_, N_)                                                                                 \
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(N_) : "memory")
+
+    const unsigned abase = hs_off(64 * wr + lr, lq);
+    f32x4 acc[MF][NF], part[MF][NF], cross[MF][NF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) { acc[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; part[f][j] = acc[f][j]; cross[f][j] = acc[f][j]; }
+    h16x8 ah[MF], am[MF];
+#define PADEL_HS3_MFMA(F_, SET_)                                                                                  \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            cross[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), am[F_], cross[F_][j], 0, 0, 0); \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
+            part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), ah[F_], part[F_][j], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+    // tap T_ of chunk c (weight set T_ % 3; the request goes out for the step 8 ahead: tap T_ - 1 of chunk c + 1, or tap 8 of chunk c)
+#define PADEL_HS3_STEP(T_)                                                                                        \
+    do {                                                                                                          \
+        PADEL_HS3_LOADW(((T_) + 2) % 3, (T_) + 2);                                                                \
+        PADEL_HS3_WAITW((T_) % 3, 2 * NF + 2 * NA);                                                               \
+        __builtin_amdgcn_s_barrier();                                                                             \
+        asm volatile("" ::: "memory");                                                                            \
+        PADEL_HS3_REQA(s_wr, c + ((T_) >= 1 ? 1 : 0), ((T_) + 8) % 9);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if constexpr (PROBE == 0) {                                                                               \
+            const char* p_ = ldsb + abase + s_rd;                                                                 \
+            _Pragma("unroll") for (int f = 0; f < MF; ++f) {                                                      \
+                ah[f] = *reinterpret_cast<const h16x8*>(p_ + f * 1024);                                           \
+                am[f] = *reinterpret_cast<const h16x8*>(p_ + f * 1024 + kSPlaneB);                                \
+            }                                                                                                     \
+        }                                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if constexpr (PROBE == 0) { PADEL_HS3_MFMA(0, (T_) % 3); PADEL_HS3_MFMA(1, (T_) % 3); PADEL_HS3_MFMA(2, (T_) % 3); PADEL_HS3_MFMA(3, (T_) % 3); } \
+        s_wr = s_rd;                                                                                              \
+        s_rd = s_rd + (unsigned)kSStageB == (unsigned)(kSStages * kSStageB) ? 0u : s_rd + (unsigned)kSStageB;     \
+    } while (0)
+
+    unsigned s_rd = 0, s_wr = (unsigned)((kSStages - 1) * kSStageB);
+    // prologue: steps 0..7 = taps 0..7 of chunk 0; behind W(0): A(2), W(1), A(3)
+    PADEL_HS3_REQA(0 * kSStageB, 0, 0); PADEL_HS3_REQA(1 * kSStageB, 0, 1);
+    PADEL_HS3_REQA(4 * kSStageB, 0, 4); PADEL_HS3_REQA(5 * kSStageB, 0, 5); PADEL_HS3_REQA(6 * kSStageB, 0, 6); PADEL_HS3_REQA(7 * kSStageB, 0, 7);
+    PADEL_HS3_LOADW(0, 0);
+    PADEL_HS3_REQA(2 * kSStageB, 0, 2);
+    PADEL_HS3_LOADW(1, 1);
+    PADEL_HS3_REQA(3 * kSStageB, 0, 3);
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        PADEL_HS3_STEP(0); PADEL_HS3_STEP(1); PADEL_HS3_STEP(2); PADEL_HS3_STEP(3); PADEL_HS3_STEP(4);
+        PADEL_HS3_STEP(5); PADEL_HS3_STEP(6); PADEL_HS3_STEP(7); PADEL_HS3_STEP(8);
+#pragma unroll
+        for (int f = 0; f < MF; ++f)
+#pragma unroll
+            for (int j = 0; j < NF; ++j) { acc[f][j] += part[f][j]; part[f][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        s_kw += 9u * 2048u;
+    }
+    PADEL_HS3_WAITW(0, 0); PADEL_HS3_WAITW(1, 0); PADEL_HS3_WAITW(2, 0);
+#undef PADEL_HS3_STEP
+#undef PADEL_HS3_MFMA
+#undef PADEL_HS3_WAITW
+#undef PADEL_HS3_LOADW
+#undef PADEL_HS3_REQA
+
+    int mpix[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) {
+        const int m = m0 + 64 * wr + 16 * f + lr;
+        mpix[f] = m < a.M ? m : -1;
+    }
+    const int fw = f0 + NF * wc;
+    const bool fast = m0 + 128 <= a.M && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
+                      (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
+    if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
+}
+
+bool conv_h2s3_supported(const ConvArgs& a) {
+    return a.w_single && a.wr && a.ksize == 3 && a.stride == 2 && (a.cin & 31) == 0 && a.cin >= 32 && a.w != nullptr && !a.in2 &&
+           a.Ho <= (a.H + 1) / 2 && a.Wo <= (a.W + 1) / 2 && (long long)4 * a.W * a.in_cs * 4 < 0x3FFFFFFFll;
+}
+
+hipError_t launch_conv_h2s3(const ConvArgs& a_in, hipStream_t s) {
+    if (!conv_h2s3_supported(a_in)) return hipErrorNotSupported;
+    ConvArgs a = a_in;
+    a.n_mtiles = (a.M + 127) / 128;
+    a.n_ntiles = (a.n16 + 11) / 12;
+    dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    if (a.tune & 64) hipLaunchKernelGGL((conv_h2s3_kernel<1>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_h2s3_kernel<0>), grid, dim3(512), 0, s, a);
+    return hipGetLastError();
+}
+
 bool conv_h2s_supported(const ConvArgs& a) {
     return a.w_single && a.wr && a.ksize == 1 && a.stride == 1 && (a.cin & 31) == 0 && a.cin >= 64 && a.Ho == a.H && a.Wo == a.W && a.w != nullptr &&
            !a.in2 && (long long)128 * a.in_cs * 4 < 0x7FFFFFFFll;

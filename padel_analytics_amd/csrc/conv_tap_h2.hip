@@ -241,6 +241,10 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         variant = (nf == 3 || nf == 13) ? 220 : (nf == 4 || nf == 14) ? 209 : 213;      // where the patch kernel does not apply: its tap sibling
     }
     if (a.in2 && a.ksize == 3) return hipErrorNotSupported;
+    if (variant == 246) {                  // stride-2 3x3 on the register-weights ring machine (conv_1x1_h2s.hip: 128 x 192); elsewhere the 128 x 96 tap tile
+        if (conv_h2s3_supported(a)) return launch_conv_h2s3(a, s);
+        variant = 213;
+    }
     if (variant == 244 || variant == 245) {   // 1x1 with register weights and a deep activation ring (conv_1x1_h2s.hip): 128 x 96 / 128 x 192; elsewhere the deep-ring tile
         if (conv_h2s_supported(a)) return launch_conv_h2s(a, variant == 245, s);
         variant = 243;
@@ -294,6 +298,10 @@ int choose_conv_h2_variant(const ConvArgs& a) {
     // per CU, register weights) halve the requests: +10..14 % on 768 / 960 / 1152 -> 384 / 576, +4..7 % on 384 / 576 -> 384, level or
     // behind on 192-channel outputs (profiles/r6D_1x1_tile_245.txt); bitwise the same results
     if (ksize == 1 && a.w_single && n16 >= 24 && a.cin >= 384 && conv_h2s_supported(a)) bv = 245;
+    // The stride-2 3x3 layers request a 16 KB tile per TAP and 96-channel tile (7.4 TB/s of requests on 96 -> 192): the same tile
+    // gives +10..12 % on 96 -> 192, +23..31 % on 192 -> 192 / 384 / 576 (profiles/r6F_s2_tile_246.txt); taken where 192-channel tiles
+    // waste at most a fifth of their columns
+    if (ksize == 3 && a.stride == 2 && n16 >= 10 && (float)(((n16 + 11) / 12) * 12) <= 1.2f * (float)n16 && conv_h2s3_supported(a)) bv = 246;
     if (conv_h2p_supported(a)) {
         struct P { int nf; float sp; };
         // (the 6-fragment patch tile accumulates its main product in ONE level — registers — and measured no faster than the

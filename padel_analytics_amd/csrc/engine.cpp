@@ -783,7 +783,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             if (h2 && (lv == 323 || lv == 324)) { bm = 128; bn = 96; }
             else if (h2 && lv == 325) { bm = 128; bn = 64; }
             else if (h2 && lv == 244) { bm = 128; bn = 96; }
-            else if (h2 && lv == 245) { bm = 128; bn = 192; }
+            else if (h2 && (lv == 245 || lv == 246)) { bm = 128; bn = 192; }
             else if (h2 && lv >= 341 && lv <= 343) { bm = 256; bn = (lv - 340) * 16; }      // wide patch kernel: 16 x 16 pixels                       // quad patch kernel: 8 x 16 pixels x 96 channels
             else if (h2 && (lv == 243 || lv == 239)) conv_variant_shape(lv - 230, &bm, &bn);      // deep-ring tap tiles: the shape of 213 / 209
             else if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }
@@ -902,7 +902,9 @@ static int ensure_operand_copies(pa_model* m) {
             if (o.kind != PA_OP_CONV) continue;
             const bool few = o.cin == 16 || o.cin == 32 || o.cin == 48;
             const bool whole = o.stride == 1 && (o.cin & 31) == 0 && o.cin >= 64;
-            if (!((o.ksize == 3 && (whole || few)) || (o.ksize == 1 && whole && (o.flags & PA_CONV_W_SINGLE)))) continue;
+            // conv_1x1_h2s.hip's stride-2 3x3 form: whole chunks, two products
+            const bool s2 = o.ksize == 3 && o.stride == 2 && (o.cin & 31) == 0 && o.cin >= 32 && (o.flags & PA_CONV_W_SINGLE);
+            if (!((o.ksize == 3 && (whole || few)) || s2 || (o.ksize == 1 && whole && (o.flags & PA_CONV_W_SINGLE)))) continue;
             m->wr_off[i] = (long long)total;
             total += conv_h2r_copy_bytes(o.npad / 16, o.cin, o.ksize);
         }

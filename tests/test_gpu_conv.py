@@ -29,6 +29,7 @@ CASES = [
     (2, 18, 26, 16, 32, 3, 1, G.ACT_SILU, False),     # stride 1 with the tail block only (n-scale's 16 channels), partial patches
     (2, 20, 24, 64, 192, 3, 1, G.ACT_SILU, True),     # two full 96-channel tiles (quad patch kernel: both channel halves), partial patches in y and x
     (1, 20, 27, 688, 96, 1, 1, G.ACT_SILU, False),    # 1x1 with long K: 21 full chunks + a 16-channel tail = three accumulation blocks (9 + 9 + 4), M tail
+    (3, 18, 22, 96, 208, 3, 2, G.ACT_SILU, True),     # stride 2 to an odd map (9 x 11 outputs: M tail, every border), 13 fragments = two 192-channel tiles, residual
 ]
 
 TAP_VARIANTS = (6, 7, 9, 10, 11, 12, 13, 14, 15, 20)

@@ -18,7 +18,7 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 244, 245, 303, 304, 313, 323, 324, 325, 341, 342, 343)      # 324 / 325: the register-weights quad kernels (round 6; 96-channel tiles, two-product layers only / 64-channel tiles, two or three products); 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
+H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 244, 245, 246, 303, 304, 313, 323, 324, 325, 341, 342, 343)      # 324 / 325: the register-weights quad kernels (round 6; 96-channel tiles, two-product layers only / 64-channel tiles, two or three products); 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
 H2_SINGLE_LEVEL = ()            # (the 6-fragment patch tile 306 — main product accumulated in ONE level — was removed in round 5)
 
 def _graph(case, w, b, wr, dtype):
@@ -102,8 +102,8 @@ def test_h2_conv_variants(gpu_engine, case):
     assert rms(ref) <= 1.25 * rms(y32) + 1e-9, (rms(ref), rms(y32))
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[5], CASES[7], CASES[8], CASES[11], CASES[12]],
-                         ids=["3x3", "3x3-tail-res", "1x1", "1x1-res", "s2-res", "odd-size", "quad-192", "1x1-long-K"])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[3], CASES[5], CASES[7], CASES[8], CASES[11], CASES[12], CASES[13]],
+                         ids=["3x3", "3x3-tail-res", "1x1", "1x1-res", "s2-res", "odd-size", "quad-192", "1x1-long-K", "s2-odd-13-fragments"])
 def test_h2_two_product_mode_on_fp16_weights(gpu_engine, case):
     """Round 5: a checkpoint's conv weights are fp16 numbers (Ultralytics stores ``model.half()``); with BatchNorm's scale kept
     in the conv's per-channel OUTPUT scale instead of multiplied into them (``Graph.conv(out_scale=)``), the packed weights'

@@ -58,6 +58,14 @@ SHAPES = [
     ("tn 256->256 72x128", 64, 72, 128, 256, 256, 3, 1),
     ("tn 512->512 36x64", 64, 36, 64, 512, 512, 3, 1),
     ("pose.head 192->64 P3", 64, 160, 160, 192, 64, 3, 1),
+    # stride-2 3x3 layers (backbone L3 / L5 / L7, the PAN's downsampling convs) of the pose graph (1280^2) and the players graph
+    ("s2 pose.L3 96->192", 64, 320, 320, 96, 192, 3, 2),
+    ("s2 pose.L5 192->384", 64, 160, 160, 192, 384, 3, 2),
+    ("s2 pose.L7 384->576", 64, 80, 80, 384, 576, 3, 2),
+    ("s2 pose.pan 192->192", 64, 160, 160, 192, 192, 3, 2),
+    ("s2 pose.pan 384->384", 64, 80, 80, 384, 384, 3, 2),
+    ("s2 players.L3 96->192", 64, 96, 160, 96, 192, 3, 2),
+    ("s2 players.L5 192->384", 64, 48, 80, 192, 384, 3, 2),
     ("pose.head 64->64 P3", 64, 160, 160, 64, 64, 3, 1),
 ]
 
