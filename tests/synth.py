@@ -10,8 +10,11 @@ from __future__ import annotations
 import numpy as np
 
 
-def synthetic_frames(n: int, h: int, w: int, seed: int = 0) -> np.ndarray:
+def synthetic_frames(n: int, h: int, w: int, seed: int = 0, return_rects: bool = False):
+    """``return_rects``: also the painted rectangles per frame, (x0, y0, x1, y1) in frame pixels in paint order (a later one covers
+    an earlier one) — the ground truth the least-squares head fit of oracle/synth_weights.py regresses."""
     rng = np.random.default_rng(seed)
+    rects = []
     ys = np.linspace(0, 1, h, dtype=np.float32)[:, None]
     xs = np.linspace(0, 1, w, dtype=np.float32)[None, :]
     out = np.empty((n, h, w, 3), np.uint8)
@@ -22,13 +25,15 @@ def synthetic_frames(n: int, h: int, w: int, seed: int = 0) -> np.ndarray:
             ph = rng.uniform(0, 6.28, 2)
             img[..., c] = 120 + 60 * np.sin(a * 6.28 * xs + ph[0]) * np.cos(b * 6.28 * ys + ph[1]) \
                 + 30 * np.sin(p * 6.28 * (xs + ys)) + 10 * np.cos(q * 12.56 * (xs - ys))
+        rects.append([])
         for _ in range(int(rng.integers(4, 9))):
             rh, rw = int(rng.integers(h // 12, h // 3)), int(rng.integers(w // 24, w // 6))
             y0, x0 = int(rng.integers(0, h - rh)), int(rng.integers(0, w - rw))
             img[y0:y0 + rh, x0:x0 + rw] = rng.uniform(0, 255, 3).astype(np.float32)
+            rects[-1].append((x0, y0, x0 + rw, y0 + rh))
         img += rng.normal(0, 3.0, img.shape).astype(np.float32)
         out[i] = np.clip(img, 0, 255).astype(np.uint8)
-    return out
+    return (out, rects) if return_rects else out
 
 
 def _query(p: str) -> dict:

@@ -395,3 +395,45 @@ def test_ball_n_nc1_tight_ratio_over_seeds(gpu_engine):
             m.close()
             yield f"detect-n-nc1-tight seeds {fseed}/{wseed} [{E.fp32_mode()}]", sd, 1, None, srcs, got, 0.25, 640
     _ratio_over_seeds(gpu_engine, "detect-n-nc1-tight", runs())
+
+
+@pytest.mark.parametrize("graph", ["players-m", "ball-n-nc1", "pose-m-1280"])
+def test_least_squares_heads_full_scale(gpu_engine, graph):
+    """the three bench graphs on checkpoints whose heads are FITTED instead of random — the last conv of the box
+    (DFL), class and keypoint branches is the ridge regression of a trained head's outputs on the clip's own rectangles
+    (oracle/synth_weights.py:fitted_state_dict; closed form on the fp64 penultimate features, fp16 numbers) — at FULL scale: no
+    attenuated last layers.  Measured first on CPU (tests/test_noise_floor.py): the fp32 oracle is still 2e-3 px (yolov8n) to
+    2.5e-2 px (yolov8m) from its own fp64 evaluation on such heads, so the literal 1e-3 px cannot be asked of ANY fp32 evaluation
+    here, the reference's included.  Asserted: identical detection sets and class ids, the raw head maps against fp64, and the
+    engine as close to the exact result as the reference's fp32 arithmetic is (`_check`); the three distances go to the report."""
+    from PIL import Image
+    from tests import helpers
+    if graph == "pose-m-1280":
+        S, kpt, nc, conf, scale = 1280, (13, 3), 1, 0.25, "m"
+        frames, rects = synth.synthetic_frames(1, 720, 1280, seed=61, return_rects=True)
+        pil = [np.asarray(Image.fromarray(fr[..., ::-1].copy()).resize((S, S))) for fr in frames]
+        srcs = [p[..., ::-1] for p in pil]
+        sd, rep = helpers.fitted_state_dict(scale, nc, kpt, srcs, rects, (720, 1280), S, conf, seed=67, stretch=True)
+        kw = dict(imgsz=S, conf=conf, iou=0.7, classes=[0], pre_mode=E.PRE_PIL_STRETCH, channel_reverse=True)
+    else:
+        S, kpt = 640, None
+        nc, conf, scale = (80, 0.5, "m") if graph == "players-m" else (1, 0.25, "n")
+        frames, rects = synth.synthetic_frames(2, 720, 1280, seed=61, return_rects=True)
+        srcs = [f[..., ::-1] for f in frames]
+        sd, rep = helpers.fitted_state_dict(scale, nc, kpt, srcs, rects, (720, 1280), S, conf, seed=67)
+        kw = dict(imgsz=S, conf=conf, iou=0.7, classes=[0] if nc > 1 else None, channel_reverse=False)
+    m, got = _engine_predict(gpu_engine, sd, nc, kpt, frames, **kw)
+    tag = f"least-squares heads {graph} [{E.fp32_mode()}]"
+    _check_heads(tag, m, sd, nc, kpt, srcs, S, len(frames))
+    m.close()
+    _check(tag, sd, nc, kpt, srcs, got, conf, 0.7, S)
+    REPORT[tag]["fit"] = rep
+    if kpt is None:                                    # the fit is real: the kept boxes overlap the painted rectangles
+        iou = np.concatenate([helpers.best_iou_with_rects(got[0][i, :got[2][i]], rects[i]) for i in range(len(frames))])
+        REPORT[tag]["mean_best_iou_with_a_rectangle"] = float(iou.mean())
+        assert iou.mean() > 0.3, iou.mean()
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump(REPORT, f, indent=1, default=str)
+    print(tag, {k: v for k, v in REPORT[tag].items() if k != "fit"})
