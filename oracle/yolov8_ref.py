@@ -377,13 +377,14 @@ def keypoints_xy(kpts: torch.Tensor) -> torch.Tensor:
 
 @torch.no_grad()
 def predict(model: YoloV8Ref, sources: Sequence[np.ndarray], conf: float, iou: float, imgsz: int,
-            classes=None, max_det: int = 300):
+            classes=None, max_det: int = 300, heads=None):
     """-> list of dicts {boxes (n,6) [x1,y1,x2,y2,conf,cls], kpts (n,K,ndim) | None, margins}.
 
     ``margins`` carries the smallest |score - conf| over all anchors of the image and is used by
-    the parity harness to detect threshold-adjacent decisions."""
+    the parity harness to detect threshold-adjacent decisions.  ``heads``: the (det, kpt) raw head maps of
+    ``model.head_raw(model.features(preprocess(sources, imgsz)))`` if the caller already holds them (the tests look at both)."""
     im = preprocess(sources, imgsz)
-    pred = model.forward(im)
+    pred = model.forward(im) if heads is None else model.decode(*heads)
     dets, cands = non_max_suppression(pred, conf, iou, classes, max_det, nc=model.nc, return_candidates=True)
     res = []
     for i, d in enumerate(dets):

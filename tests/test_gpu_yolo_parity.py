@@ -56,7 +56,8 @@ def _oracle_predict(sd, nc, kpt, srcs, conf, iou, imgsz, dtype=torch.float32):
     key = _content_key(sd, srcs, nc, kpt, conf, iou, imgsz, str(dtype), "predict")
     if key not in _ORACLE_CACHE:
         model = ref.YoloV8Ref(sd, nc, kpt) if dtype == torch.float32 else ref.YoloV8Ref(sd, nc, kpt, dtype=dtype)
-        _ORACLE_CACHE[key] = ref.predict(model, srcs, conf, iou, imgsz, classes=[0])
+        # the conv stack is evaluated once per (checkpoint, clip, dtype): the head-map checks and the predictions share it
+        _ORACLE_CACHE[key] = ref.predict(model, srcs, conf, iou, imgsz, classes=[0], heads=_oracle_heads(sd, nc, kpt, srcs, imgsz, dtype))
     return _ORACLE_CACHE[key]
 
 
