@@ -40,19 +40,36 @@ typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
 // tile of a pixel tile requests the same 16 KB per k-step again (7.4 TB/s of requests on 1152 -> 384: the chip's LDS-DMA fill
 // rate) —, and with all MFMAs compiled out (PROBE) the kernel is exactly as fast: 265 vs 264 / 309 vs 331 TFLOP/s
 // (profiles/r6B_1x1_probe.txt).  Twice the channels per workgroup is half the requests.
-// PROBE (tuning word bit 6, wrong results): 1 = no MFMAs and no operand reads — what the request stream alone sustains
-template <int WC, int PROBE = 0>
-__global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a) {
-    constexpr int MF = 4, NF = 3;
+// PROBE (tuning word bit 6, wrong results): 1 = no MFMAs and no operand reads — what the request stream alone sustains; 2 (+ bit 8):
+// the activation requests alone; 3 (+ bit 9): the weight loads alone
+// D = how many k-steps ahead a wave loads its weights (D + 1 register sets).  A wave's memory requests complete IN ORDER (one vmcnt
+// counter): waiting for W(K), issued D steps ago, also waits for every activation request issued before it — the ring's requests
+// have min(ring depth, D + 1) steps to arrive, not the ring depth: D = 2 leaves an eight-step ring a three-step window.  Measured
+// (profiles/r6I_1x1_weight_lookahead.txt): D = 4 (five-step window, 246 VGPRs) is 0..1 % SLOWER on every long-K layer, D = 3 on the
+// 128 x 96 tile likewise — the window is not what bounds these layers; D = 2 stays, the other is tuning bit 3.
+// What does (profiles/r6J_1x1_stream_probes.txt, 1152 -> 384, TFLOP/s-equivalent of the kernel's time): whole kernel 405; both
+// request streams without MFMAs 472; the activation requests alone 596 — and the same 590..630 whether they ask for half lines or
+// whole 128-byte records, walk the tile in address order, or are plain register loads instead of LDS-DMA; the weight loads alone
+// 1 380; half of the weight loads answered by zero-record descriptors: 475.  1 / 596 + 1 / 1380 = 1 / 416: the two streams nearly
+// ADD, MFMAs hide under them, and neither the L2 (50 % hits, 6 TB/s of 34) nor HBM (3 + 1 TB/s read + write: activations are
+// fetched once, TCC counters) is at its roof — the per-CU vector-memory path serialises them.
+// WR = waves along the pixels: 2 (128-pixel tiles) or 1 (WC = 4 only: 64 x 192 tiles of FOUR waves, two workgroups per CU with
+// nine 8 KB stages each — the bytes of the 128 x 192 tile per product, but two independent barrier domains per CU)
+template <int WC, int PROBE = 0, int D = 2, int WR = 2>
+__global__ void __launch_bounds__(64 * WR * WC, 2) conv_h2s_kernel(const ConvArgs a) {
+    constexpr int MF = 4, NF = 3, NSET = D + 1;
+    constexpr int kSPlaneB = 64 * WR * 64;         // one fp16 plane of a 32-channel chunk: 64 WR pixels x 64 B
+    constexpr int kSStageB = 2 * kSPlaneB;         // h | m of one k-step
     constexpr int kSStages = WC == 2 ? 5 : 9;
     constexpr int kSAhead = kSStages - 1;          // request distance in k-steps
-    constexpr int NA = 8 / (2 * WC) * 2;           // activation requests per wave and k-step: 16 spans x planes over 2 WC waves
+    constexpr int NA = 8 / (2 * WC) * 2;           // activation requests per wave and k-step: 8 WR spans x planes over WR x WC waves
+    static_assert(WR == 2 || WC == 4, "64-pixel tiles: one span per wave");
     __shared__ __attribute__((aligned(16))) float lds[(kSStages * kSStageB) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave & 1, wc = wave >> 1;      // pixel half (64 pixels), channel half (3 fragments)
+    const int wr = WR == 2 ? (wave & 1) : 0, wc = WR == 2 ? (wave >> 1) : wave;      // pixel half (64 pixels), channel part (3 fragments)
     const int lr = lane & 15, lq = lane >> 4;
 
     // XCD-aware 1-D tile map: the channel tiles of one pixel tile are neighbours on one XCD (they share its activations in the L2)
@@ -62,7 +79,7 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
     const int mloc = idx / nnt, nt = idx - mloc * nnt;
     if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
     const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
-    const int m0 = mt * 128;
+    const int m0 = mt * (64 * WR);
     const int f0 = nt * WC * NF;
     const int nch = a.cin >> 5;                   // k-steps
 
@@ -82,19 +99,34 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
     unsigned voA[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) voA[k] = (unsigned)(((wave + 4 * k) * 16 + (lane >> 2)) * (unsigned)pix_b) + p_piece;     // (WC = 4: one span per wave)
+    unsigned voL[2];                              // PROBE 4: whole 128-byte records, 8 pixels per request (wrong LDS layout)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) voL[k] = (unsigned)((wave * 16 + 8 * k + (lane >> 3)) * (unsigned)pix_b) + (unsigned)(lane & 7) * 16u;
+    hs_i32x4 sink[2] = {};                        // PROBE 6: the activation requests as plain register loads (no LDS-DMA)
+    unsigned voQ[2];                              // PROBE 5: the tile's bytes in address order — 16 KB contiguous per k-step (wrong data)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) voQ[k] = (unsigned)(wave * 2048 + k * 1024 + lane * 16);
     const unsigned lp0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds);
     const unsigned lpw = __builtin_amdgcn_readfirstlane(lp0 + (unsigned)wave * 1024u);
     // k-step K_ into the stage at byte offset SB_; k-steps beyond the last go through a descriptor of zero records (the request
     // count per step — and with it every counted wait — is static)
 #define PADEL_HS_REQA(SB_, K_)                                                                                    \
-    do {                                                                                                          \
+    if constexpr (PROBE != 3) {                                                                                   \
         const unsigned so_ = (unsigned)(K_) * 128u;                                                               \
         const unsigned lb_ = lpw + (unsigned)(SB_);                                                               \
         i32x4 rs_ = rsrcA;                                                                                        \
         if ((int)(K_) >= nch) rs_[2] = 0;                                                                         \
+        if constexpr (PROBE == 4) { dma3<0>(voL[0], rs_, so_, lb_); dma3<kSPlaneB>(voL[1], rs_, so_, lb_); }      \
+        else if constexpr (PROBE == 6) {                                                                          \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(sink[0]) : "v"(voA[0]), "s"(rs_), "s"(so_) : "memory"); \
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(sink[1]) : "v"(voA[0]), "s"(rs_), "s"(so_ + 32u) : "memory"); \
+        }                                                                                                         \
+        else if constexpr (PROBE == 5) { dma3<0>(voQ[0], rs_, so_ * 128u, lb_); dma3<kSPlaneB>(voQ[1], rs_, so_ * 128u, lb_); } \
+        else {                                                                                                    \
         dma3<0>(voA[0], rs_, so_, lb_); if constexpr (WC == 2) dma3<4096>(voA[1], rs_, so_, lb_);                 \
         dma3<kSPlaneB>(voA[0], rs_, so_ + 32u, lb_); if constexpr (WC == 2) dma3<kSPlaneB + 4096>(voA[1], rs_, so_ + 32u, lb_); \
-    } while (0)
+        }                                                                                                         \
+    }
 
     // ---- weights: a.wr = [fragment][k-step][h | m][lane][16 bytes]; NF requests per wave and k-step
     const unsigned fragb = (unsigned)nch * 2048u;
@@ -105,16 +137,17 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
         const int frag = min(f0 + NF * wc + j, a.n16 - 1);   // fragments beyond the matrix: any valid rows (never stored)
         rsrcW[j] = make_rsrc3(reinterpret_cast<const char*>(a.wr) + (long long)frag * fragb);
     }
-    hs_i32x4 w[3][NF];
+    hs_i32x4 w[NSET][NF];
     // (k-steps beyond the last read the next fragment's first k-steps, or the slack behind the copy — never multiplied)
 #define PADEL_HS_LOADW(SET_, K_)                                                                                  \
-    do {                                                                                                          \
+    if constexpr (PROBE != 2 && PROBE < 4 || PROBE == 7) {                                                        \
         const unsigned so_ = (unsigned)(K_) * 2048u;                                                              \
+        if (PROBE == 7 && wr == 1) rsrcW[0][2] = rsrcW[1][2] = rsrcW[2][2] = 0;     /* one wave of a pair loads */ \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                            \
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[SET_][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory"); \
-    } while (0)
+    }
 #define PADEL_HS_WAITW(SET_, N_)                                                                                  \
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(N_) : "memory")
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(PROBE == 2 || (PROBE >= 4 && PROBE != 7) ? (N_) * NA / (NF + NA) : PROBE == 3 ? (N_) * NF / (NF + NA) : (N_)) : "memory")
 
     // ---- operand reads: pixel fragment f of the wave = pixels 64 wr + 16 f + lr: hs_off's swizzle depends on lr only, everything
     // else is the stage's offset (scalar, walks the ring) and an immediate
@@ -133,13 +166,13 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
             part[F_][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, w[SET_][j]), ah[F_], part[F_][j], 0, 0, 0); \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
-    // k-step K_ (weight set SET_ = K_ % 3, statically: the loop is unrolled by three; the stage walks the ring through s_rd / s_wr).
-    // Queue of the wave behind W(K_) when it waits: A(K_ + 2) x 4, W(K_ + 1) x 3, A(K_ + 3) x 4, W(K_ + 2) x 3 — 14 requests; in
-    // front of it, in order: A(K_), W(K_ - 1), A(K_ + 1).
+    // k-step K_ (weight set SET_ = K_ % NSET, statically: the loop is unrolled by NSET; the stage walks the ring through s_rd / s_wr).
+    // Queue of the wave behind W(K_) when it waits (D = 2, WC = 2): A(K_ + 2) x 4, W(K_ + 1) x 3, A(K_ + 3) x 4, W(K_ + 2) x 3 — 14
+    // requests = D x (NF + NA); in front of it, in order: A(K_), W(K_ - 1), A(K_ + 1).
 #define PADEL_HS_STEP(K_, SET_)                                                                                   \
     do {                                                                                                          \
-        PADEL_HS_LOADW(((SET_) + 2) % 3, (K_) + 2);                                                               \
-        PADEL_HS_WAITW(SET_, 2 * NF + 2 * NA);                                                                    \
+        PADEL_HS_LOADW(((SET_) + D) % NSET, (K_) + D);                                                            \
+        PADEL_HS_WAITW(SET_, D * (NF + NA));                                                                      \
         __builtin_amdgcn_s_barrier();             /* stage s_rd is published; the stage read in step K_ - 1 (= s_wr) is free */ \
         asm volatile("" ::: "memory");                                                                            \
         PADEL_HS_REQA(s_wr, (K_) + kSAhead);                                                                      \
@@ -164,20 +197,21 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
 
     int kblk = 0;
     unsigned s_rd = 0, s_wr = (unsigned)((kSStages - 1) * kSStageB);      // stage of the current step / the stage the previous step read
-    // prologue — the order the steady state leaves behind W(0): A(2), W(1), A(3) (14 / 10 requests); everything further ahead
-    // (A(4) .. A(kSAhead - 1), WC = 4) goes in front of it, with A(0), A(1)
-    PADEL_HS_REQA(0 * kSStageB, 0); PADEL_HS_REQA(1 * kSStageB, 1);
+    // prologue — the order the steady state leaves: A(0) .. A(kSAhead - D - 1), then W(i), A(kSAhead - D + i) for i < D
+    static_assert(kSAhead >= D, "the ring is at least as deep as the weight look-ahead");
 #pragma unroll
-    for (int k = 4; k < kSAhead; ++k) PADEL_HS_REQA(k * kSStageB, k);
-    PADEL_HS_LOADW(0, 0);
-    PADEL_HS_REQA(2 * kSStageB, 2);
-    PADEL_HS_LOADW(1, 1);
-    PADEL_HS_REQA(3 * kSStageB, 3);
+    for (int k = 0; k < kSAhead - D; ++k) PADEL_HS_REQA(k * kSStageB, k);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        PADEL_HS_LOADW(i, i);
+        PADEL_HS_REQA((kSAhead - D + i) * kSStageB, kSAhead - D + i);
+    }
 #pragma unroll 1
-    for (int k = 0; k < nch; k += 3) {
+    for (int k = 0; k < nch; k += NSET) {
         PADEL_HS_STEP(k, 0);
-        if (k + 1 < nch) PADEL_HS_STEP(k + 1, 1);
-        if (k + 2 < nch) PADEL_HS_STEP(k + 2, 2);
+#pragma unroll
+        for (int i = 1; i < NSET; ++i)
+            if (k + i < nch) PADEL_HS_STEP(k + i, i);
     }
     if (kblk != 0) {
 #pragma unroll
@@ -187,7 +221,9 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
     }
     // the look-ahead requests behind the last step (zero-record activations, weights nobody uses) before the LDS is released and
     // before the epilogue may reuse the weight registers
-    PADEL_HS_WAITW(0, 0); PADEL_HS_WAITW(1, 0); PADEL_HS_WAITW(2, 0);
+#pragma unroll
+    for (int i = 0; i < NSET; ++i) PADEL_HS_WAITW(i, 0);
+    if constexpr (PROBE == 6) asm volatile("" :: "v"(sink[0]), "v"(sink[1]));
 #undef PADEL_HS_STEP
 #undef PADEL_HS_MFMA
 #undef PADEL_HS_WAITW
@@ -201,7 +237,7 @@ __global__ void __launch_bounds__(128 * WC, 2) conv_h2s_kernel(const ConvArgs a)
         mpix[f] = m < a.M ? m : -1;
     }
     const int fw = f0 + NF * wc;
-    const bool fast = m0 + 128 <= a.M && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
+    const bool fast = m0 + 64 * WR <= a.M && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
                       (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
     if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
 }
@@ -401,9 +437,17 @@ bool conv_h2s_supported(const ConvArgs& a) {
            !a.in2 && (long long)128 * a.in_cs * 4 < 0x7FFFFFFFll;
 }
 
-hipError_t launch_conv_h2s(const ConvArgs& a_in, bool nf12, hipStream_t s) {
+hipError_t launch_conv_h2s(const ConvArgs& a_in, bool nf12, hipStream_t s, bool m64) {
     if (!conv_h2s_supported(a_in)) return hipErrorNotSupported;
     ConvArgs a = a_in;
+    if (nf12 && m64) {                          // 64 x 192 tiles: four waves, two workgroups per CU
+        a.n_mtiles = (a.M + 63) / 64;
+        a.n_ntiles = (a.n16 + 11) / 12;
+        dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+        if (a.tune & 64) hipLaunchKernelGGL((conv_h2s_kernel<4, 1, 2, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2s_kernel<4, 0, 2, 1>), grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     a.n_mtiles = (a.M + 127) / 128;
     const bool wide = nf12;                     // 128 x 192 tiles: 8 waves, one workgroup per CU
     a.n_ntiles = wide ? (a.n16 + 11) / 12 : (a.n16 + 5) / 6;
@@ -414,10 +458,18 @@ hipError_t launch_conv_h2s(const ConvArgs& a_in, bool nf12, hipStream_t s) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2s_kernel<4, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 0);
             attr = true;
         }
-        if (a.tune & 64) hipLaunchKernelGGL((conv_h2s_kernel<4, 1>), grid, dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((conv_h2s_kernel<4, 0>), grid, dim3(512), 0, s, a);
+        if ((a.tune & 64) && (a.tune & 4096)) hipLaunchKernelGGL((conv_h2s_kernel<4, 7>), grid, dim3(512), 0, s, a);               // both streams, one wave of a pair loads weights
+        else if ((a.tune & 64) && (a.tune & 2048)) hipLaunchKernelGGL((conv_h2s_kernel<4, 6>), grid, dim3(512), 0, s, a);               // activations alone, to registers
+        else if ((a.tune & 64) && (a.tune & 1024)) hipLaunchKernelGGL((conv_h2s_kernel<4, 5>), grid, dim3(512), 0, s, a);               // activations alone, in address order
+        else if ((a.tune & 64) && (a.tune & 256) && (a.tune & 512)) hipLaunchKernelGGL((conv_h2s_kernel<4, 4>), grid, dim3(512), 0, s, a);  // activations alone, whole records
+        else if ((a.tune & 64) && (a.tune & 256)) hipLaunchKernelGGL((conv_h2s_kernel<4, 2>), grid, dim3(512), 0, s, a);      // activations only
+        else if ((a.tune & 64) && (a.tune & 512)) hipLaunchKernelGGL((conv_h2s_kernel<4, 3>), grid, dim3(512), 0, s, a); // weights only
+        else if (a.tune & 64) hipLaunchKernelGGL((conv_h2s_kernel<4, 1>), grid, dim3(512), 0, s, a);
+        else if (a.tune & 8) hipLaunchKernelGGL((conv_h2s_kernel<4, 0, 4>), grid, dim3(512), 0, s, a);        // weights four steps ahead: a five-step window (A/B: no faster)
+        else hipLaunchKernelGGL((conv_h2s_kernel<4, 0, 2>), grid, dim3(512), 0, s, a);
     } else if (a.tune & 64) hipLaunchKernelGGL((conv_h2s_kernel<2, 1>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_h2s_kernel<2, 0>), grid, dim3(256), 0, s, a);
+    else if (a.tune & 8) hipLaunchKernelGGL((conv_h2s_kernel<2, 0, 3>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_h2s_kernel<2, 0, 2>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

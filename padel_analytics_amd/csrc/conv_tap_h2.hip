@@ -245,6 +245,10 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         if (conv_h2s3_supported(a)) return launch_conv_h2s3(a, s);
         variant = 213;
     }
+    if (variant == 247) {                  // 64 x 192 tiles of the 1x1 register-weights kernel (four waves, two workgroups per CU)
+        if (conv_h2s_supported(a)) return launch_conv_h2s(a, true, s, true);
+        variant = 243;
+    }
     if (variant == 244 || variant == 245) {   // 1x1 with register weights and a deep activation ring (conv_1x1_h2s.hip): 128 x 96 / 128 x 192; elsewhere the deep-ring tile
         if (conv_h2s_supported(a)) return launch_conv_h2s(a, variant == 245, s);
         variant = 243;
@@ -298,6 +302,11 @@ int choose_conv_h2_variant(const ConvArgs& a) {
     // per CU, register weights) halve the requests: +10..14 % on 768 / 960 / 1152 -> 384 / 576, +4..7 % on 384 / 576 -> 384, level or
     // behind on 192-channel outputs (profiles/r6D_1x1_tile_245.txt); bitwise the same results
     if (ksize == 1 && a.w_single && n16 >= 24 && a.cin >= 384 && conv_h2s_supported(a)) bv = 245;
+    // ... and the same bytes as 64 x 192 tiles of FOUR waves, two workgroups per CU (two barrier domains instead of eight waves in
+    // lock step): +8..10 % over the better of the two on 192 / 384 / 576 -> 192 and 384 / 576 -> 384, level at 768 -> 384, 1152 -> 576,
+    // -2 % at K = 1152 -> 384 (profiles/r6L_1x1_tile_247.txt); taken for K < 960 where 192-channel tiles fit
+    if (ksize == 1 && a.w_single && n16 >= 12 && (float)(((n16 + 11) / 12) * 12) <= 1.1f * (float)n16 && a.cin >= 192 && a.cin < 960 &&
+        conv_h2s_supported(a)) bv = 247;
     // The stride-2 3x3 layers request a 16 KB tile per TAP and 96-channel tile (7.4 TB/s of requests on 96 -> 192): the same tile
     // gives +10..12 % on 96 -> 192, +23..31 % on 192 -> 192 / 384 / 576 (profiles/r6F_s2_tile_246.txt); taken where 192-channel tiles
     // waste at most a fifth of their columns
