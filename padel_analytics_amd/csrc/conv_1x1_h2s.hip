@@ -250,16 +250,18 @@ __global__ void __launch_bounds__(64 * WR * WC, 2) conv_h2s_kernel(const ConvArg
 // the taps column-major like every h2 kernel and the main sums flushed per chunk (= the tap kernels' blocks of 9 k-steps): bitwise
 // conv_h2_kernel.  A lane's request offset is its pixel's top-left input pixel relative to the tile's; the tap enters through the
 // scalar offset, taps outside the image through a per-lane validity mask (3 row bits + 3 column bits).
-template <int PROBE = 0>
-__global__ void __launch_bounds__(512, 2) conv_h2s3_kernel(const ConvArgs a) {
+// WR = 1: 64 x 192 tiles of four waves, two workgroups per CU (nine 8 KB stages each), as conv_h2s_kernel<4, .., 1>
+template <int PROBE = 0, int WR = 2>
+__global__ void __launch_bounds__(256 * WR, 2) conv_h2s3_kernel(const ConvArgs a) {
     constexpr int MF = 4, NF = 3, WC = 4;
+    constexpr int kSPlaneB = 64 * WR * 64, kSStageB = 2 * kSPlaneB;
     constexpr int kSStages = 9, kSAhead = 8, NA = 2;
     __shared__ __attribute__((aligned(16))) float lds[(kSStages * kSStageB) / 4];
     char* const ldsb = reinterpret_cast<char*>(lds);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave & 1, wc = wave >> 1;
+    const int wr = WR == 2 ? (wave & 1) : 0, wc = WR == 2 ? (wave >> 1) : wave;
     const int lr = lane & 15, lq = lane >> 4;
 
     const int nmt = a.n_mtiles, nnt = a.n_ntiles;
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2s3_kernel(const ConvArgs a) {
     const int mloc = idx / nnt, nt = idx - mloc * nnt;
     if (mloc >= q8 + (xcd < r8 ? 1 : 0)) return;
     const int mt = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + mloc;
-    const int m0 = mt * 128;
+    const int m0 = mt * (64 * WR);
     const int f0 = nt * WC * NF;
     const int nch = a.cin >> 5;
     const int HoWo = a.Ho * a.Wo;
@@ -411,7 +413,7 @@ __global__ void __launch_bounds__(512, 2) conv_h2s3_kernel(const ConvArgs a) {
         mpix[f] = m < a.M ? m : -1;
     }
     const int fw = f0 + NF * wc;
-    const bool fast = m0 + 128 <= a.M && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
+    const bool fast = m0 + 64 * WR <= a.M && (fw + NF) * 16 <= a.cout && (((a.out_choff | a.out_cs) & 3) == 0) &&
                       (!a.res || (((a.res_choff | a.res_cs) & 3) == 0));
     if (fw < a.n16) h2_epilogue<MF, NF>(a, acc, cross, mpix, fw, lq, fast);
 }
@@ -421,12 +423,17 @@ bool conv_h2s3_supported(const ConvArgs& a) {
            a.Ho <= (a.H + 1) / 2 && a.Wo <= (a.W + 1) / 2 && (long long)4 * a.W * a.in_cs * 4 < 0x3FFFFFFFll;
 }
 
-hipError_t launch_conv_h2s3(const ConvArgs& a_in, hipStream_t s) {
+hipError_t launch_conv_h2s3(const ConvArgs& a_in, hipStream_t s, bool m64) {
     if (!conv_h2s3_supported(a_in)) return hipErrorNotSupported;
     ConvArgs a = a_in;
-    a.n_mtiles = (a.M + 127) / 128;
+    a.n_mtiles = m64 ? (a.M + 63) / 64 : (a.M + 127) / 128;
     a.n_ntiles = (a.n16 + 11) / 12;
     dim3 grid(8u * (unsigned)((a.n_mtiles + 7) / 8) * (unsigned)a.n_ntiles, 1, 1);
+    if (m64) {
+        if (a.tune & 64) hipLaunchKernelGGL((conv_h2s3_kernel<1, 1>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_h2s3_kernel<0, 1>), grid, dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.tune & 64) hipLaunchKernelGGL((conv_h2s3_kernel<1>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_h2s3_kernel<0>), grid, dim3(512), 0, s, a);
     return hipGetLastError();

@@ -241,6 +241,10 @@ hipError_t launch_conv_h2(const ConvArgs& a, int variant, hipStream_t s) {
         variant = (nf == 3 || nf == 13) ? 220 : (nf == 4 || nf == 14) ? 209 : 213;      // where the patch kernel does not apply: its tap sibling
     }
     if (a.in2 && a.ksize == 3) return hipErrorNotSupported;
+    if (variant == 248) {                  // ... as 64 x 192 tiles of four waves
+        if (conv_h2s3_supported(a)) return launch_conv_h2s3(a, s, true);
+        variant = 213;
+    }
     if (variant == 246) {                  // stride-2 3x3 on the register-weights ring machine (conv_1x1_h2s.hip: 128 x 192); elsewhere the 128 x 96 tap tile
         if (conv_h2s3_supported(a)) return launch_conv_h2s3(a, s);
         variant = 213;
@@ -311,6 +315,8 @@ int choose_conv_h2_variant(const ConvArgs& a) {
     // gives +10..12 % on 96 -> 192, +23..31 % on 192 -> 192 / 384 / 576 (profiles/r6F_s2_tile_246.txt); taken where 192-channel tiles
     // waste at most a fifth of their columns
     if (ksize == 3 && a.stride == 2 && n16 >= 10 && (float)(((n16 + 11) / 12) * 12) <= 1.2f * (float)n16 && conv_h2s3_supported(a)) bv = 246;
+    // (as 64 x 192 four-wave tiles, two workgroups per CU: +3..5 % at 96 and 384 input channels, -1..3 % at 192 — profiles/r6N_s2_tile_248.txt)
+    if (bv == 246 && a.cin != 192) bv = 248;
     if (conv_h2p_supported(a)) {
         struct P { int nf; float sp; };
         // (the 6-fragment patch tile accumulates its main product in ONE level — registers — and measured no faster than the

@@ -784,7 +784,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             else if (h2 && lv == 325) { bm = 128; bn = 64; }
             else if (h2 && lv == 244) { bm = 128; bn = 96; }
             else if (h2 && (lv == 245 || lv == 246)) { bm = 128; bn = 192; }
-            else if (h2 && lv == 247) { bm = 64; bn = 192; }
+            else if (h2 && (lv == 247 || lv == 248)) { bm = 64; bn = 192; }
             else if (h2 && lv >= 341 && lv <= 343) { bm = 256; bn = (lv - 340) * 16; }      // wide patch kernel: 16 x 16 pixels                       // quad patch kernel: 8 x 16 pixels x 96 channels
             else if (h2 && (lv == 243 || lv == 239)) conv_variant_shape(lv - 230, &bm, &bn);      // deep-ring tap tiles: the shape of 213 / 209
             else if ((f16 || h2) && lv >= 300) { bm = 128; bn = ((lv - 300) % 10) * 16; }

@@ -90,7 +90,7 @@ hipError_t launch_h2r_repack(const float* w, void* wr, int n16, int cin, int ksi
 bool conv_h2s_supported(const ConvArgs& a);            // conv_1x1_h2s.hip (round 6): 1x1, two products, register weights, one barrier per two k-steps
 hipError_t launch_conv_h2s(const ConvArgs& a, bool nf12, hipStream_t s, bool m64 = false);
 bool conv_h2s3_supported(const ConvArgs& a);           // the same machine for stride-2 3x3 layers (tile 246: 128 x 192, two products, whole chunks)
-hipError_t launch_conv_h2s3(const ConvArgs& a, hipStream_t s);      // tile 244: 128 x 96 (4 waves), 245: 128 x 192 (8 waves, one workgroup per CU)
+hipError_t launch_conv_h2s3(const ConvArgs& a, hipStream_t s, bool m64 = false);   // m64: 64 x 192 tiles of four waves (tile 248)      // tile 244: 128 x 96 (4 waves), 245: 128 x 192 (8 waves, one workgroup per CU)
 // *flag |= 1 when any m-plane bit of `rows_x_ksteps` packed 128-byte k-step records is set (the PA_CONV_W_SINGLE promise, checked once per model)
 hipError_t launch_h2_mplane_check(const float* w, long long rows_x_ksteps, unsigned* flag, hipStream_t s);
 hipError_t launch_conv_h2_deep(const ConvArgs& a, int variant, hipStream_t s);     // conv_tap_h2p.hip: tap tiles with a 3-stage activation ring (239, 243); hipErrorNotSupported where they do not apply

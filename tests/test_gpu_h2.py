@@ -18,7 +18,7 @@ from tests.test_gpu_conv import CASES
 
 pytestmark = pytest.mark.gpu
 
-H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 244, 245, 246, 247, 303, 304, 313, 323, 324, 325, 341, 342, 343)      # 324 / 325: the register-weights quad kernels (round 6; 96-channel tiles, two-product layers only / 64-channel tiles, two or three products); 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
+H2_TILES = (207, 209, 211, 213, 220, 225, 239, 243, 244, 245, 246, 247, 248, 303, 304, 313, 323, 324, 325, 341, 342, 343)      # 324 / 325: the register-weights quad kernels (round 6; 96-channel tiles, two-product layers only / 64-channel tiles, two or three products); 239 / 243: tap tiles with the three-stage activation ring (conv_tap_h2p.hip); 31x: software-pipelined patch schedule; 323: the quad patch kernel; 34x: the wide patch kernel (cin 16 / 32 / 48)
 H2_SINGLE_LEVEL = ()            # (the 6-fragment patch tile 306 — main product accumulated in ONE level — was removed in round 5)
 
 def _graph(case, w, b, wr, dtype):
