@@ -503,7 +503,7 @@ def main():
             "engine_only_frames_per_s": None, "fp32_strict_frames_per_s": None,
             "parity_linf_px_vs_fp32_oracle": None, "parity_oracle_floor_px": None, "parity_linf_px_vs_fp64": None,
             "parity_low_noise_linf_px": None,
-            "timed_path": "TrackingRunner.run(), trackers in sequence, batches pipelined (submit k+1 before wait k), objects built inside",
+            "timed_path": "TrackingRunner.run(): trackers in sequence, submit k+1 before wait k; queued host stages drain beside the next tracker",
         },
     }
 
@@ -537,6 +537,7 @@ def main():
             out["value"] = round(world * B * K / dt, 2)
             out["ms_per_step"] = round(1e3 * dt / K, 3)
             out["config"]["runner_seconds_per_tracker_rank0"] = {k: round(v["seconds"], 4) for k, v in runner.timings.items()}
+            out["config"]["runner_host_tail_seconds_rank0"] = {k: round(v["host_tail_seconds"], 4) for k, v in runner.timings.items() if "host_tail_seconds" in v}
             if world > 1:
                 # N > 1: the path BASELINE configs[3] names (reference trackers/runner.py:185-236 over ONE clip): a single clip
                 # of world x K x B frames, TrackingRunner(distributed=True) — every rank runs the stateless part of each tracker

@@ -34,7 +34,7 @@ from .tracker import NoPredictFrames, Tracker, _sampler
 class TrackingRunner:
     def __init__(self, trackers: list, video_path: str | Path, inference_path: str | Path, start: int = 0,
                  end: Optional[int] = None, collect_data: bool = False, *, distributed: bool = False,
-                 fanout: bool = False, engine=None) -> None:
+                 fanout: bool = False, engine=None, host_queue_depth: int = 8) -> None:
         self.video_path = video_path
         self.inference_path = inference_path
         self.start = start
@@ -56,6 +56,10 @@ class TrackingRunner:
         self.distributed = distributed
         self.fanout = fanout
         self.engine = engine
+        # host stages (zone, ByteTrack, result objects) a batch tracker may have queued behind its device stage; what is still
+        # queued when its device loop ends drains beside the NEXT tracker's device work (1: the loop waits for its own tail)
+        self.host_queue_depth = host_queue_depth
+        self._tails: list = []
 
     def restart(self) -> None:
         for tracker in self.trackers.values():
@@ -86,14 +90,21 @@ class TrackingRunner:
                     tracker.to(tracker.DEVICE)
                     print(f"{str(tracker)}: Running on {tracker.DEVICE} ...")
                     t0 = timeit.default_timer()
+                    tail: list = []
                     if self.distributed:
                         self._predict_sharded(tracker)
                     else:
-                        self._predict(tracker)
+                        tracker.host_queue_depth = max(1, int(self.host_queue_depth))
+                        self._predict(tracker, defer=tail)
                     t1 = timeit.default_timer()
                     tracker.to("cpu")
                     if self._merges and self._merges[-1][0] is tracker:
                         self._merges[-1] += (t0, t1)      # reported when the merge is done: shard time and the merge's own span apart
+                        continue
+                    # the trackers before this one had this tracker's whole device loop to finish their queued host stages
+                    self._join_tails()
+                    if tail:
+                        self._tails.append((tracker, tail, t0, t1))
                         continue
                     self._report(tracker, t0, t1)
                     if not self.distributed or D.rank() == 0:
@@ -101,21 +112,44 @@ class TrackingRunner:
         finally:
             #  a tracker that raises must not leave finished merges unsaved or the worker pool alive; a merge's own
             # exception surfaces here, after the merges before it were saved
-            self._join_merges()
+            try:
+                self._join_tails()
+            finally:
+                self._join_merges()
         self.draw_and_collect_data()
 
-    def _predict(self, tracker: Tracker) -> None:
+    def _predict(self, tracker: Tracker, defer: Optional[list] = None) -> None:
         """One tracker over the whole clip.  A stream tracker on the h2 arithmetic whose activations left the fp16
         range has switched itself to the full-range path and asks to be run again (engine.RangeOverflow); batch
-        trackers repeat the offending batch themselves (yolo.YOLO.infer_frames)."""
+        trackers repeat the offending batch themselves (yolo.YOLO.infer_frames).  ``defer``: Tracker._predict_batches."""
         from .. import engine as E
         try:
-            tracker.predict_and_update(self._frames(), total_frames=self.total_frames)
+            tracker.predict_and_update(self._frames(), defer=defer, total_frames=self.total_frames)
         except E.RangeOverflow as ex:
             print(f"{str(tracker)}: {ex}")
             tracker.restart()
             tracker.to(tracker.DEVICE)
-            tracker.predict_and_update(self._frames(), total_frames=self.total_frames)
+            tracker.predict_and_update(self._frames(), defer=defer, total_frames=self.total_frames)
+
+    def _join_tails(self) -> None:
+        """Collect the host stages that were still queued when their trackers' device loops ended.  ``timings``: "seconds" is the
+        device loop's span, "host_tail_seconds" what was left to wait for here — after the next tracker's loop, normally nothing."""
+        tails, self._tails = self._tails, []
+        first_error = None
+        for tracker, fins, t0, t1 in tails:
+            ts = timeit.default_timer()
+            try:
+                for f in fins:
+                    f()
+            except BaseException as exc:           # keep collecting: the tails behind this one are finished work too
+                first_error = first_error or exc
+                continue
+            self._report(tracker, t0, t1)
+            self.timings[str(tracker)].update(host_tail_seconds=timeit.default_timer() - ts, host_tail_overlapped=True)
+            if not self.distributed or D.rank() == 0:
+                tracker.save_predictions()
+        if first_error is not None:
+            raise first_error
 
     def _report(self, tracker, t0, t1) -> None:
         print(f"{str(tracker)}: {t1 - t0} inference time.")

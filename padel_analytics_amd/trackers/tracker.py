@@ -135,6 +135,15 @@ class relaxed_gc:
         return False
 
 
+def _own_arrays(raw):
+    """A device stage's result with its arrays copied (they may be a model's recycled page-locked sets)."""
+    if isinstance(raw, np.ndarray):
+        return raw.copy()
+    if isinstance(raw, (tuple, list)):
+        return type(raw)(_own_arrays(x) for x in raw)
+    return raw
+
+
 def pack_ragged(items: list) -> Optional[list]:
     """[ndarray (k_i, ...)] with one dtype / trailing shape -> [counts (n,) int32, rows (sum k_i, ...)]; None if the items
     are anything else."""
@@ -267,9 +276,17 @@ class Tracker(ABC):
     def _has_stages(self) -> bool:
         return type(self).infer_sample is not Tracker.infer_sample and type(self).post_sample is not Tracker.post_sample
 
-    def _predict_batches(self, frame_generator, update, **kwargs) -> None:
+    #: host stages a batch loop may have queued behind its device stage (``TrackingRunner`` raises it: the host stage of a
+    #: detector with many tracks is slower than its device stage, and what queues up drains beside the NEXT tracker's device work)
+    host_queue_depth = 1
+
+    def _predict_batches(self, frame_generator, update, defer: Optional[list] = None, **kwargs) -> None:
         """Batch loop of reference tracker.py:319-326.  With the two-stage form, post_sample(batch k) runs on one
-        worker thread (in batch order) while infer_sample(batch k+1) occupies the GPU."""
+        worker thread (in batch order) while infer_sample(batch k+1) occupies the GPU.
+
+        ``defer`` (a list): host stages still queued when the device loop ends are not waited for here — a ``finish()`` callable
+        that collects them (in order, through ``update``) is appended instead, for the caller to run once the next tracker's
+        device work is under way.  Results are identical either way: one worker, batch order."""
         if not self._has_stages():
             for sample in _sampler(frame_generator, self.batch_size):
                 update(self.predict_sample(sample, **kwargs))
@@ -280,16 +297,21 @@ class Tracker(ABC):
         interval = sys.getswitchinterval()
         sys.setswitchinterval(min(interval, 2e-4))
         # at most three result sets are alive here (the batch in the host stage, the submitted batch being collected, the batch
-        # submitted behind it): the device stage may hand out the model's recycled page-locked arrays (engine.Model.OUT_RING)
+        # submitted behind it): the device stage may hand out the model's recycled page-locked arrays (engine.Model.OUT_RING).
+        # A deeper host queue owns copies of what it holds.
         self._reuse_outputs = True
+        depth = max(1, int(self.host_queue_depth))
         submitted = None                                    # the token of the batch that is queued on the GPU and not collected yet
+        pool = ThreadPoolExecutor(max_workers=1)
+        pending = []
+        handed_over = False
         try:
-            with relaxed_gc(), ThreadPoolExecutor(max_workers=1) as pool:
-                pending = []
-
+            with relaxed_gc():
                 def host_stage(raw):
+                    if depth > 1:
+                        raw = _own_arrays(raw)
                     pending.append(pool.submit(self.post_sample, raw, **kwargs))
-                    while len(pending) > 1:                 # keep one host stage in flight behind the device stage
+                    while len(pending) > depth:             # keep `depth` host stages queued behind the device stage
                         update(pending.pop(0).result())
 
                 # Trackers with the two-call device stage (submit_sample / collect_sample: pa_yolo_submit / pa_yolo_wait) have
@@ -309,12 +331,26 @@ class Tracker(ABC):
                 if submitted is not None:
                     token, submitted = submitted, None
                     host_stage(self.collect_sample(token))
-                for f in pending:
-                    update(f.result())
+
+                def finish():
+                    try:
+                        with relaxed_gc():
+                            while pending:
+                                update(pending.pop(0).result())
+                    finally:
+                        pool.shutdown(wait=True, cancel_futures=True)
+
+                if defer is not None and depth > 1 and pending:
+                    defer.append(finish)
+                    handed_over = True
+                else:
+                    finish()
         finally:
             self._reuse_outputs = False
             sys.setswitchinterval(interval)
             self._drain(submitted)
+            if not handed_over:
+                pool.shutdown(wait=True, cancel_futures=True)
 
     def _raw_batches(self, frame_generator, **kwargs):
         """Yield ``infer_sample``'s result for every batch of the stream, in order — with the next batch already submitted
@@ -352,13 +388,22 @@ class Tracker(ABC):
             except Exception as exc:                         # the loop is already unwinding: report, do not mask what ended it
                 print(f"{self.__str__()}: could not release the batch still in flight ({exc!r})")
 
-    def predict_and_update(self, frame_generator: Iterable[np.ndarray], **kwargs) -> TrackingResults:
+    def predict_and_update(self, frame_generator: Iterable[np.ndarray], defer: Optional[list] = None, **kwargs) -> TrackingResults:
+        """``defer``: see ``_predict_batches`` — the results are complete once every callable appended to it has run."""
+        tail = [] if defer is not None else None
         try:
             predictions = self.predict_frames(frame_generator, **kwargs)
             self.results.predictions = predictions
         except NoPredictFrames:
-            self._predict_batches(frame_generator, self.results.update, **kwargs)
-        print(f"{self.__str__()}: {len(self.results)} predictions.")
+            self._predict_batches(frame_generator, self.results.update, defer=tail, **kwargs)
+        if tail:
+            def finish():
+                for f in tail:
+                    f()
+                print(f"{self.__str__()}: {len(self.results)} predictions.")
+            defer.append(finish)
+        else:
+            print(f"{self.__str__()}: {len(self.results)} predictions.")
         return self.results
 
     # ---- sharded prediction (SURVEY.md §8(e)): frames [first, first + n) of the clip live on this rank

@@ -187,3 +187,92 @@ def test_relaxed_gc_is_reentrant_across_threads_and_restores_the_thresholds():
     leave.set()
     t.join()
     assert gc.get_threshold() == before
+
+
+class _Slow(_Toy):
+    """The host stage is the slow one (a detector with many tracks): arrays out of a two-set 'ring' that the device stage
+    overwrites on every other call, like engine.Model's recycled page-locked result sets."""
+
+    def __init__(self, delay=0.01):
+        super().__init__()
+        self.delay = delay
+        self.ring = [np.zeros(4, np.int64), np.zeros(4, np.int64)]
+        self.calls = 0
+        self.post_threads = set()
+
+    def collect_sample(self, token):
+        s = token["sample"]
+        a = self.ring[self.calls % 2]
+        self.calls += 1
+        a[:] = -1
+        a[:len(s)] = s
+        self.log.append(("collect", s[0]))
+        return (a, len(s))
+
+    def post_sample(self, raw, **kw):
+        import threading, time
+        time.sleep(self.delay)
+        self.post_threads.add(threading.get_ident())
+        a, n = raw
+        return [int(f) * 10 for f in a[:n]]
+
+
+def test_a_deeper_host_queue_owns_its_arrays_and_hands_its_tail_over():
+    """Round 6: with ``host_queue_depth`` > 1 the device loop does not wait for a slow host stage — the queued batches hold
+    COPIES of the recycled arrays, keep batch order, and what is still queued when the device loop ends is handed to the
+    caller (``defer``), who collects it later: same results as the depth-1 loop."""
+    import time
+    ref = _Slow(delay=0.0)
+    ref.predict_and_update(iter(range(30)))
+    assert ref.results.predictions == [f * 10 for f in range(30)]
+
+    t = _Slow(delay=0.02)
+    t.host_queue_depth = 6
+    tail = []
+    t0 = time.perf_counter()
+    t.predict_and_update(iter(range(30)), defer=tail)             # 8 batches x 20 ms of host stage
+    dt_loop = time.perf_counter() - t0
+    assert len(tail) == 1 and len(t.results.predictions) < 30     # the device loop is done, the host stages are not
+    assert dt_loop < 0.12, dt_loop                                # it did not wait for 8 x 20 ms
+    tail[0]()
+    assert t.results.predictions == ref.results.predictions       # order kept, no array overwritten under a queued batch
+    assert len(t.post_threads) == 1 and not t._reuse_outputs
+    # without a `defer` list the loop collects its own tail
+    t2 = _Slow(delay=0.0)
+    t2.host_queue_depth = 6
+    t2.predict_and_update(iter(range(30)))
+    assert t2.results.predictions == ref.results.predictions
+
+
+def test_runner_collects_a_tracker_tail_after_the_next_tracker_loop(tmp_path):
+    """TrackingRunner: the first tracker's queued host stages drain beside the second tracker's device loop and are collected
+    after it; results and per-tracker timings are complete when run() returns."""
+    from padel_analytics_amd import video
+    from padel_analytics_amd.trackers.runner import TrackingRunner
+
+    n = 30
+    video.register_source("ints", lambda p: video.VideoInfo(8, 8, 30, n), lambda p, start, end, stride: iter(range(start, n if end is None else min(end, n), stride)))
+
+    class A(_Slow):
+        def __str__(self): return "a"
+
+    class B(_Slow):
+        def __str__(self): return "b"
+
+    a, b = A(delay=0.02), B(delay=0.0)
+    for t in (a, b):
+        t.to = lambda device: None
+        t.save_predictions = lambda: None
+    r = TrackingRunner([a, b], "ints://clip", tmp_path / "out.mp4", host_queue_depth=6)
+    r.run()
+    assert a.results.predictions == [f * 10 for f in range(n)] and b.results.predictions == a.results.predictions
+    assert r.timings["a"]["frames"] == n and r.timings["a"].get("host_tail_overlapped") is True
+    assert r.timings["b"]["frames"] == n
+    # depth 1: the old schedule, same results
+    a1, b1 = A(delay=0.0), B(delay=0.0)
+    for t in (a1, b1):
+        t.to = lambda device: None
+        t.save_predictions = lambda: None
+    r1 = TrackingRunner([a1, b1], "ints://clip", tmp_path / "out.mp4", host_queue_depth=1)
+    r1.run()
+    assert a1.results.predictions == a.results.predictions and "host_tail_overlapped" not in r1.timings["a"]
