@@ -102,7 +102,7 @@ def parse():
                          "carries \"fake_engine\": true and is not a measurement")
     ap.add_argument("--traffic", default="live", choices=["live", "static", "none"],
                     help="roofline.traffic: live = two rocprofv3 --pmc passes over this script's engine-only step (needs rocprofv3; "
-                         "falls back to static), static = the committed measurement profiles/r5_traffic.json")
+                         "falls back to static), static = the committed measurement profiles/r6_traffic.json")
     ap.add_argument("--no-eager", action="store_true", help="skip the eager-result-objects leg (value_eager_objects)")
     ap.add_argument("--quick", action="store_true", help="tuning runs: runner + engine-only + roofline only (no CPU leg, host-frames leg, reference-default leg)")
     ap.add_argument("--no-tight", action="store_true", help="skip the low-noise-head parity leg of the CPU baseline section")
@@ -201,7 +201,9 @@ def make_state_dict(name, cfg, frames, frac=0.01, seed_offset=0):
     return sd
 
 
-H2_CONV3_KERNELS = {"h2": ("conv_h2p_kernel", "conv_h2q_kernel", "conv_h2w_kernel", "conv_h2_kernel"),
+# every kernel a 3x3 conv op of the graph can be launched as (conv_tap_h2.hip:launch_conv_h2's dispatch)
+H2_CONV3_KERNELS = {"h2": ("conv_h2p_kernel", "conv_h2q_kernel", "conv_h2w_kernel", "conv_h2_kernel", "conv_h2r_kernel", "conv_h2v_kernel",
+                           "conv_h2s3_kernel"),
                     "bx3": ("conv_bx3p_kernel", "conv_bx3_kernel"), "tap": ("conv_tap_kernel",)}
 
 
@@ -251,6 +253,12 @@ def measure_traffic(a, ops_rows, tmp):
             n_ops += 1
     if not n_ops:
         return None
+    # the counted launches must be whole steps of exactly the graph's 3x3 ops: an average over a subset (a kernel name missing from
+    # the list above) would be compared with the wrong algorithmic figure
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        if tot[c][1] % n_ops:
+            sys.stderr.write(f"bench: PMC pass {c} counted {tot[c][1]} launches of the 3x3 kernels, the graph has {n_ops} per step: not used\n")
+            return None
     fetch = tot["FETCH_SIZE"][0] * 1024 * 2 / tot["FETCH_SIZE"][1]
     write = tot["WRITE_SIZE"][0] * 1024 / tot["WRITE_SIZE"][1]
     return {"bytes_per_launch": round(fetch + write), "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
@@ -769,7 +777,7 @@ def main():
                 rows_all += trackers[name].model._model.profile_rows()
             with contextlib.redirect_stdout(sys.stderr):
                 traffic = measure_traffic(a, rows_all, tmp)
-        tpath = ROOT / "profiles" / "r5_traffic.json"
+        tpath = ROOT / "profiles" / "r6_traffic.json"
         if traffic is None and a.traffic != "none" and tpath.exists():
             tj = json.loads(tpath.read_text()).get(f"{a.workload}-{a.impl}" if a.dtype == "f32" else "none")
             if tj:
@@ -777,7 +785,7 @@ def main():
                            "write_bytes_per_launch": tj["write_bytes_per_launch"],
                            "algorithmic_bytes_per_launch": tj["algorithmic_bytes_per_launch"],
                            "ratio_to_algorithmic": tj.get("ratio_to_algorithmic"), "static": True,
-                           "source": ("profiles/r5_traffic.json: " + tj["source"])[:118]}
+                           "source": ("profiles/r6_traffic.json: " + tj["source"])[:118]}
         out["roofline"] = {
             "kernel": ("conv_p16 / conv_p16q (stride-1 3x3 patch kernels) + conv_tap16 (stride 2); v_mfma_f32_16x16x32_f16" if a.dtype == "f16" else
                        "conv_h2r / h2q / h2p / h2w (stride-1 3x3 patch kernels) + conv_h2 (stride 2); 2-3 x v_mfma_f32_16x16x32_f16 per block" if a.impl == "h2" else

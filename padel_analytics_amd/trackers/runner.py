@@ -21,6 +21,7 @@ Additions (all off by default, the reference's sequential semantics stay the def
 from __future__ import annotations
 
 import threading
+import os
 import timeit
 from pathlib import Path
 from typing import Optional
@@ -34,7 +35,7 @@ from .tracker import NoPredictFrames, Tracker, _sampler
 class TrackingRunner:
     def __init__(self, trackers: list, video_path: str | Path, inference_path: str | Path, start: int = 0,
                  end: Optional[int] = None, collect_data: bool = False, *, distributed: bool = False,
-                 fanout: bool = False, engine=None, host_queue_depth: int = 8) -> None:
+                 fanout: bool = False, engine=None, host_queue_depth: Optional[int] = None) -> None:
         self.video_path = video_path
         self.inference_path = inference_path
         self.start = start
@@ -58,7 +59,7 @@ class TrackingRunner:
         self.engine = engine
         # host stages (zone, ByteTrack, result objects) a batch tracker may have queued behind its device stage; what is still
         # queued when its device loop ends drains beside the NEXT tracker's device work (1: the loop waits for its own tail)
-        self.host_queue_depth = host_queue_depth
+        self.host_queue_depth = int(os.environ.get("PADEL_HOST_QUEUE_DEPTH", 8)) if host_queue_depth is None else host_queue_depth
         self._tails: list = []
 
     def restart(self) -> None:
