@@ -152,7 +152,7 @@ def conv1x1_roofline(c1, fl1, ms1, peak1, a):
     es = 2 if a.dtype == "f16" else 4
     cls = {"hbm": [0.0, 0.0, 0.0, 0], "mfma": [0.0, 0.0, 0.0, 0]}      # ms, bytes, flops, launches
     for r in c1:
-        byts = float(r["M"]) * (r["cin"] + r["cout"]) * es
+        byts = float(r["M"]) * (r["cin"] + r["cout"] * (1 + int(r.get("res", 0)))) * es
         t_hbm = byts / (HBM_ACHIEVABLE_TBS * 1e12)
         t_mfma = r["flops"] / (peak1 * 1e12)
         k = "hbm" if t_hbm >= t_mfma else "mfma"
@@ -250,6 +250,7 @@ def measure_traffic(a, ops_rows, tmp):
         if r["kind"] == 2 and r["ksize"] == 3:
             st = r["stride"]
             alg += r["M"] * st * st * r["cin"] * 4 + r["M"] * r["cout"] * 4 + 9 * r["cin"] * r["cout"] * (6 if a.impl == "bx3" else 4)
+            alg += r["M"] * r["cout"] * 4 * int(r.get("res", 0))          # a conv that adds a residual input reads it
             n_ops += 1
     if not n_ops:
         return None
@@ -737,11 +738,11 @@ def main():
         eng.set_profiling(False)
         if a.dump_ops:
             with open(a.dump_ops, "w") as f:
-                f.write("tracker,kind,ksize,M,cout,cin,stride,bm,bn,ms,flops\n")
+                f.write("tracker,kind,ksize,M,cout,cin,stride,bm,bn,ms,flops,res\n")
                 for name in names:
                     for r in trackers[name].model._model.profile_rows():
                         f.write(f"{name},{r['kind']},{r['ksize']},{r['M']},{r['cout']},{r['cin']},{r['stride']},"
-                                f"{r['mf']},{r['nf']},{r['ms']:.5f},{r['flops']:.0f}\n")
+                                f"{r['mf']},{r['nf']},{r['ms']:.5f},{r['flops']:.0f},{r.get('res', 0)}\n")
         c3 = [r for r in recs if r["kind"] == 2 and r["ksize"] == 3]
         c1 = [r for r in recs if r["kind"] == 2 and r["ksize"] == 1]
         ms3, fl3 = sum(r["ms"] for r in c3), sum(r["flops"] for r in c3)

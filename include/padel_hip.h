@@ -292,7 +292,8 @@ int pa_bytetrack_update_batch(pa_bytetrack* b, const float* boxes, const int32_t
  * engine's stream.  kinds/ms/flops are host arrays of capacity cap; returns the number of records. */
 int pa_engine_set_profiling(pa_engine* eng, int enable);
 int pa_model_last_profile(pa_model* m, int cap, int32_t* kinds, float* ms, double* flops, int32_t* ksizes);
-/* same records as CSV text: kind,ksize,M,cout,cin,stride,mf,nf,ms,flops per line; returns bytes written */
+/* same records as CSV text: kind,ksize,M,cout,cin,stride,mf,nf,ms,flops,res per line (mf, nf: the workgroup tile's pixels and
+ * channels; res: 1 if the conv adds a residual input it has to read); returns bytes written */
 int pa_model_profile_text(pa_model* m, char* buf, size_t cap);
 
 #ifdef __cplusplus

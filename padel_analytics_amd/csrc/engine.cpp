@@ -74,7 +74,7 @@ static int env_int(const char* k, int dflt) { const char* v = getenv(k); return 
         }                                                                                  \
     } while (0)
 
-struct ProfRec { int kind; int ksize; double flops; hipEvent_t e0, e1; float ms; int M, cout, cin, stride, mf, nf; };
+struct ProfRec { int kind; int ksize; double flops; hipEvent_t e0, e1; float ms; int M, cout, cin, stride, mf, nf, res; };
 
 struct pa_model {
     pa_engine* e = nullptr;
@@ -689,7 +689,7 @@ static ProfRec* prof_begin(pa_model* m, size_t idx, int kind, int ksize, double 
     }
     ProfRec* r = &m->prof[idx];
     r->kind = kind; r->ksize = ksize; r->flops = flops; r->ms = 0.f;
-    r->M = r->cout = r->cin = r->stride = r->mf = r->nf = 0;
+    r->M = r->cout = r->cin = r->stride = r->mf = r->nf = r->res = 0;
     hipEventRecord(r->e0, m->e->stream);
     return r;
 }
@@ -792,7 +792,7 @@ static int run_ops(pa_model* m, int n, size_t* pi) {
             else if (lv >= 300) { bm = 128; bn = (lv - 300) * 16; }          // patch kernel: 8 x 16 pixels x nf fragments
             else conv_variant_shape(lv >= 200 ? lv - 200 : lv, &bm, &bn);   // profile rows carry BM, BN of the workgroup tile
             pr = prof_begin(m, (*pi)++, o.kind, o.ksize, 2.0 * a.M * (double)o.cout * o.cin * o.ksize * o.ksize);
-            if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = bm; pr->nf = bn; }
+            if (pr) { pr->M = a.M; pr->cout = o.cout; pr->cin = o.cin; pr->stride = o.stride; pr->mf = bm; pr->nf = bn; pr->res = a.res != nullptr; }
             // tuning only ("timeline"): collect the s_memtime timeline of this launch into timeline_path
             unsigned long long* dbg_dev = nullptr;
             size_t dbg_bytes = 0;
@@ -1587,8 +1587,8 @@ int pa_model_profile_text(pa_model* m, char* buf, size_t cap) {
     size_t off = 0;
     for (size_t i = 0; i < m->n_prof && i < m->prof.size(); ++i) {
         const ProfRec& r = m->prof[i];
-        int n = snprintf(buf + off, off < cap ? cap - off : 0, "%d,%d,%d,%d,%d,%d,%d,%d,%.5f,%.0f\n", r.kind, r.ksize, r.M, r.cout,
-                         r.cin, r.stride, r.mf, r.nf, r.ms, r.flops);
+        int n = snprintf(buf + off, off < cap ? cap - off : 0, "%d,%d,%d,%d,%d,%d,%d,%d,%.5f,%.0f,%d\n", r.kind, r.ksize, r.M, r.cout,
+                         r.cin, r.stride, r.mf, r.nf, r.ms, r.flops, r.res);
         if (n < 0 || off + n >= cap) break;
         off += n;
     }

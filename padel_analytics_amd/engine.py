@@ -610,9 +610,9 @@ class Model:
         self.engine.lib.pa_model_profile_text(self.handle, buf, len(buf))
         rows = []
         for line in buf.value.decode().splitlines():
-            k, ks, M, co, ci, st, mf, nf, ms, fl = line.split(",")
+            k, ks, M, co, ci, st, mf, nf, ms, fl, res = (line.split(",") + ["0"])[:11]
             rows.append(dict(kind=int(k), ksize=int(ks), M=int(M), cout=int(co), cin=int(ci), stride=int(st),
-                             mf=int(mf), nf=int(nf), ms=float(ms), flops=float(fl)))
+                             mf=int(mf), nf=int(nf), ms=float(ms), flops=float(fl), res=int(res)))
         return rows
 
     def close(self):
