@@ -26,9 +26,6 @@ namespace padel {
 
 namespace {
 
-constexpr int kSPlaneB = 128 * 64;              // one fp16 plane of a 32-channel chunk: 128 pixels x 64 B
-constexpr int kSStageB = 2 * kSPlaneB;          // h | m of one k-step
-
 __device__ __forceinline__ unsigned hs_off(int p, int q) { return (unsigned)(p * 64 + ((q ^ (((p >> 2) & 1) << 1)) << 4)); }
 
 typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
@@ -36,12 +33,14 @@ typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
 }  // namespace
 
 // WC = waves along the channels: 2 (128 x 96 tile, 4 waves, 2 workgroups per CU, 5-stage ring) or 4 (128 x 192 tile, 8 waves, ONE
-// workgroup per CU, 9-stage ring): what bounds a 1x1 layer is the LDS-DMA fill stream of its activation tile — every 96-channel
-// tile of a pixel tile requests the same 16 KB per k-step again (7.4 TB/s of requests on 1152 -> 384: the chip's LDS-DMA fill
-// rate) —, and with all MFMAs compiled out (PROBE) the kernel is exactly as fast: 265 vs 264 / 309 vs 331 TFLOP/s
-// (profiles/r6B_1x1_probe.txt).  Twice the channels per workgroup is half the requests.
-// PROBE (tuning word bit 6, wrong results): 1 = no MFMAs and no operand reads — what the request stream alone sustains; 2 (+ bit 8):
-// the activation requests alone; 3 (+ bit 9): the weight loads alone
+// workgroup per CU, 9-stage ring): what bounds a long-K 1x1 layer is the request stream of its activation tile — every 96-channel
+// tile of a pixel tile requests the same 16 KB per k-step again (7.4 TB/s of requests on 1152 -> 384) —, and with all MFMAs compiled
+// out (PROBE) the kernel is exactly as fast: 265 vs 264 / 309 vs 331 TFLOP/s (profiles/r6B_1x1_probe.txt).  Twice the channels per
+// workgroup is half the requests.
+// PROBE (tuning word bit 6, WRONG results; the eight-wave tile only beyond 1): 1 = no MFMAs and no operand reads — what the two
+// request streams alone sustain; 2 (+ bit 8): the activation requests alone; 3 (+ bit 9): the weight loads alone; 4 (+ bits 8, 9):
+// activations alone as whole 128-byte records; 5 (+ bit 10): activations alone in address order; 6 (+ bit 11): activations alone as
+// plain register loads; 7 (+ bit 12): both streams, one wave of each pair answered by a zero-record descriptor
 // D = how many k-steps ahead a wave loads its weights (D + 1 register sets).  A wave's memory requests complete IN ORDER (one vmcnt
 // counter): waiting for W(K), issued D steps ago, also waits for every activation request issued before it — the ring's requests
 // have min(ring depth, D + 1) steps to arrive, not the ring depth: D = 2 leaves an eight-step ring a three-step window.  Measured
