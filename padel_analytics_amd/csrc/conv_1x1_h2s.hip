@@ -51,9 +51,13 @@ typedef int hs_i32x4 __attribute__((ext_vector_type(4)));
 // whole 128-byte records, walk the tile in address order, or are plain register loads instead of LDS-DMA; the weight loads alone
 // 1 380; half of the weight loads answered by zero-record descriptors: 475.  1 / 596 + 1 / 1380 = 1 / 416: the two streams nearly
 // ADD, MFMAs hide under them, and neither the L2 (50 % hits, 6 TB/s of 34) nor HBM (3 + 1 TB/s read + write: activations are
-// fetched once, TCC counters) is at its roof — the per-CU vector-memory path serialises them.
+// fetched once, TCC counters) is at its roof — the per-CU vector-memory path serialises them.  The activation-only numbers do not depend
+// on how many steps the probe leaves in flight behind its wait either (2 / 4 / 7: 600 / 617 / 592; -DPADEL_HS_AWIN).
 // WR = waves along the pixels: 2 (128-pixel tiles) or 1 (WC = 4 only: 64 x 192 tiles of FOUR waves, two workgroups per CU with
 // nine 8 KB stages each — the bytes of the 128 x 192 tile per product, but two independent barrier domains per CU)
+#ifndef PADEL_HS_AWIN
+#define PADEL_HS_AWIN D        // activation-only probes: steps that may stay in flight behind the wait (the real kernel's queue leaves D)
+#endif
 template <int WC, int PROBE = 0, int D = 2, int WR = 2>
 __global__ void __launch_bounds__(64 * WR * WC, 2) conv_h2s_kernel(const ConvArgs a) {
     constexpr int MF = 4, NF = 3, NSET = D + 1;
@@ -146,7 +150,7 @@ __global__ void __launch_bounds__(64 * WR * WC, 2) conv_h2s_kernel(const ConvArg
             asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(w[SET_][j]) : "v"(voffW), "s"(rsrcW[j]), "s"(so_) : "memory"); \
     }
 #define PADEL_HS_WAITW(SET_, N_)                                                                                  \
-    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(PROBE == 2 || (PROBE >= 4 && PROBE != 7) ? (N_) * NA / (NF + NA) : PROBE == 3 ? (N_) * NF / (NF + NA) : (N_)) : "memory")
+    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"(PROBE == 2 || (PROBE >= 4 && PROBE != 7) ? ((N_) == 0 ? 0 : (PADEL_HS_AWIN) * NA) : PROBE == 3 ? (N_) * NF / (NF + NA) : (N_)) : "memory")
 
     // ---- operand reads: pixel fragment f of the wave = pixels 64 wr + 16 f + lr: hs_off's swizzle depends on lr only, everything
     // else is the stage's offset (scalar, walks the ring) and an immediate
