@@ -576,3 +576,27 @@ def test_h2v_register_weight_wide_kernel_equals_the_wide_kernel(gpu_engine, cin,
     ref = outs["303"]
     for name, y in outs.items():
         assert np.array_equal(y, ref), f"{name} differs from the 48-channel patch tile (max {np.abs(y - ref).max():.3e}, {int((y != ref).sum())} values)"
+
+
+def test_profile_rows_flag_the_convs_that_read_a_residual(gpu_engine):
+    """bench.py prices a conv's HBM traffic against input + output + weights + the residual input it adds: the per-op profile
+    rows (pa_model_profile_text, 11th column) say which convs have one.  yolov8n: every second 3x3 of the backbone's bottlenecks
+    (C2f with shortcut: model.2 / 4 / 6 / 8 -> 1 + 2 + 2 + 1 blocks), none in the neck, no 1x1."""
+    from padel_analytics_amd import yolo_arch
+    from tests import synth
+    frames = synth.synthetic_frames(1, 180, 320, seed=2)
+    sd = yolo_arch.synth_state_dict("n", 80, None, seed=3, cls_bias=-1.0)
+    m = E.Model(gpu_engine, G.build_yolov8(sd, 80, None, dtype="h2"))
+    m.set_max_batch(1)
+    gpu_engine.set_profiling(True)
+    try:
+        m.yolo_infer(frames, 1, 180, 320, imgsz=320, conf=0.25, iou=0.7)
+        rows = m.profile_rows()
+    finally:
+        gpu_engine.set_profiling(False)
+        m.close()
+    convs = [r for r in rows if r["kind"] == G.OP_CONV]
+    assert convs and all("res" in r for r in convs)
+    with_res = [r for r in convs if r["res"]]
+    assert len(with_res) == 6, [(r["ksize"], r["cin"], r["cout"]) for r in with_res]
+    assert all(r["ksize"] == 3 and r["stride"] == 1 and r["cin"] == r["cout"] for r in with_res)
