@@ -90,6 +90,9 @@ __device__ __forceinline__ HrTile hr_tile(const ConvArgs& a, int v, int vmax, in
 // workgroup in the CU's odd thread-group slot — the tile log of the probe build shows the two workgroups of a CU are not in phase
 // anyway (the older one gets the pipe first: 64.5 k vs 83 k ticks per tile, epilogues 0.9 beside the partner's main loop), no
 // change; `nt` on the patch requests (-6 .. -8 %), `sc0` on the weight loads (0).
+#ifndef PADEL_HR_LATEW
+#define PADEL_HR_LATEW 1
+#endif
 template <int NF, bool WS, bool DBG = false, int ABL = 0, int PRIO = 0>
 __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, const int vmax) {
     constexpr int MF = 4;
@@ -100,6 +103,11 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
     constexpr int NBUF = 2;                       // double-buffered patch
     constexpr int NPL = WS ? 1 : 2;               // weight planes fetched per fragment
     constexpr int NW = NF * NPL;                  // weight requests per tap and wave
+    // the requests of tap T + 2 go out behind tap T's first row of products (their issue time — ~110 cycles for six loads — under the
+    // matrix pipe) instead of in front of its counted wait: +1.0..1.4 % on 96 -> 96, +0.2 % on 192 -> 192 with 96-channel tiles, -0.4..1.4 %
+    // with 64-channel tiles (four rows of FOUR products hide less): profiles/r7a_h2r_late_weight_requests.txt
+    constexpr bool kLateW = PADEL_HR_LATEW != 0 && NF == 3;
+    constexpr int kWQ = kLateW ? 1 : 2;           // taps of weight requests that are younger than W(T) when tap T waits for it
     constexpr int DBG_B = DBG ? (4 * kRDbgSteps * 5 + 4 * 64) * 8 : 0;
     constexpr int PATCH_B = (NBUF - 1) * kRBufStride + kRPatchB;
     constexpr int PVO_B = 2 * 3 * 256 * 4;       // the lane offsets of the patch requests, two tiles' worth
@@ -212,12 +220,12 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
 #define PADEL_HR_WAITW(SET_, BASE_)                                                                               \
     do {                                                                                                          \
         if constexpr (NF == 3)                                                                                    \
-            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"((BASE_) + 2 * NW) : "memory"); \
+            asm volatile("s_waitcnt vmcnt(%3)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(w[SET_][2]) : "n"((BASE_) + kWQ * NW) : "memory"); \
         else if constexpr (WS)                                                                                    \
-            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]) : "n"((BASE_) + 2 * NW) : "memory"); \
+            asm volatile("s_waitcnt vmcnt(%2)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]) : "n"((BASE_) + kWQ * NW) : "memory"); \
         else                                                                                                      \
             asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[SET_][0]), "+v"(w[SET_][1]), "+v"(wm[SET_][0]), "+v"(wm[SET_][WS ? 0 : 1]) \
-                         : "n"((BASE_) + 2 * NW) : "memory");                                                     \
+                         : "n"((BASE_) + kWQ * NW) : "memory");                                                   \
     } while (0)
 
     // ---- row reads: patch pixel p = p0 + d with p0 = 72 wr + lr (the wave's row 0 at kx = 0) and d = 18 R + KX; hr_off's swizzle
@@ -270,7 +278,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         constexpr int kx_ = h2_tap_kx(T_), ky_ = h2_tap_ky(T_), set_ = (T_) % 3;                                  \
         PADEL_HR_STAMP(T_, 0);                                                                                    \
         PADEL_HR_PRIO(0);                                                                                         \
-        if constexpr (PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                                 \
+        if constexpr (!kLateW && PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                      \
         PADEL_HR_WAITW(set_, (T_) < 2 ? 6 : 0);                                                                   \
         PADEL_HR_STAMP(T_, 1);                                                                                    \
         if constexpr ((T_) != 8) PADEL_HR_STAMP(T_, 2);                                                           \
@@ -278,6 +286,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         if constexpr (ky_ == 0) {                                                                                 \
             PADEL_HR_MFMA_ROW(0, 0, set_, (T_) == 0 && !(ABL & 32));                                              \
+            if constexpr (kLateW && PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);   /* its issue under this row's products */ \
             PADEL_HR_STAMP(T_, 3);                                                                                \
             if constexpr ((T_) == 0 && !(ABL & 32)) PADEL_HR_FLUSH(1);   /* the previous chunk's last row (chunk 0: + 0) */ \
             if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(4, kx_);   /* slot 0, first used by row 3 of ky = 1 */ \
@@ -287,6 +296,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
             PADEL_HR_MFMA_ROW(2, 0, set_, (T_) == 0 && !(ABL & 32)); PADEL_HR_MFMA_ROW(3, 0, set_, (T_) == 0 && !(ABL & 32)); \
         } else if constexpr (ky_ == 1) {                                                                          \
             PADEL_HR_MFMA_ROW(0, 1, set_, false);                                                                 \
+            if constexpr (kLateW && PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);   /* its issue under this row's products */ \
             PADEL_HR_STAMP(T_, 3);                                                                                \
             if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(5, kx_);   /* slot 1, first used by row 3 of ky = 2 */ \
             PADEL_HR_PRIO(2);                                                                                     \
@@ -294,6 +304,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
             PADEL_HR_MFMA_ROW(1, 1, set_, false); PADEL_HR_PRIO(3); PADEL_HR_MFMA_ROW(2, 1, set_, false); PADEL_HR_MFMA_ROW(3, 1, set_, false); \
         } else if constexpr (kx_ < 2) {                    /* ky = 2: rows 2, 3, 0, 1 free slots 0, 1, 2, 3 for the next column */ \
             PADEL_HR_MFMA_ROW(2, 2, set_, false);                                                                 \
+            if constexpr (kLateW && PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);   /* its issue under this row's products */ \
             PADEL_HR_STAMP(T_, 3);                                                                                \
             if constexpr (PADEL_HR_ON(512)) PADEL_HR_READROW(0, kx_ + 1);                                         \
             PADEL_HR_PRIO(2);                                                                                     \
@@ -310,6 +321,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
             __builtin_amdgcn_sched_barrier(0);                                                                    \
         } else {                                           /* tap 8: the chunk barrier sits behind the first row's products */ \
             PADEL_HR_MFMA_ROW(2, 2, set_, false);                                                                 \
+            if constexpr (kLateW && PADEL_HR_ON(256)) PADEL_HR_LOADW(((T_) + 2) % 3, (T_) + 2);                   \
             /* every read of this chunk's patch has returned (row 5 was read under tap 7; lgkmcnt(0) costs nothing here), */ \
             /* and the wave's own requests of the next chunk's patch landed long ago (in order in front of W(8)) */ \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
@@ -406,7 +418,7 @@ __global__ void __launch_bounds__(256, 2) conv_h2r_kernel(const ConvArgs a, cons
         PADEL_HR_PRIO(0);
         // the look-ahead requests of the last chunk (taps 9 / 10: weights nobody uses, issued to keep the counted waits static) target
         // register sets 0 and 1: they must have landed before the epilogue may reuse those registers
-        PADEL_HR_WAITW(0, -2 * NW); PADEL_HR_WAITW(1, -2 * NW);           // vmcnt(0), both sets' registers through it
+        PADEL_HR_WAITW(0, -kWQ * NW); PADEL_HR_WAITW(1, -kWQ * NW);       // vmcnt(0), both sets' registers through it
         PADEL_HR_FLUSH(1);
         if constexpr ((ABL & 32) != 0) { PADEL_HR_FLUSH(0); PADEL_HR_FLUSH(2); PADEL_HR_FLUSH(3); }      // (probe: one main chain, flushed once)
 
